@@ -1,0 +1,127 @@
+/*
+ * ukbb_fcn.h -- C ABI of the MI355X (gfx950) FCN / U-Net segmentation engine.
+ *
+ * This boundary replaces the TensorFlow session of the reference deployment
+ * scripts.  Each entry point cites the reference interface it stands for
+ * (paths relative to the reference repository root):
+ *
+ *   ukbb_fcn_create        tf.Session() + tf.train.import_meta_graph(...) +
+ *                          saver.restore(sess, model_path)
+ *                          (common/deploy_network.py:44-49,
+ *                           common/deploy_network_ao.py:53-58)
+ *   ukbb_fcn_forward_host  sess.run(['prob:0','pred:0'],
+ *                                   feed_dict={'image:0': x, 'training:0': False})
+ *                          (common/deploy_network.py:110-111,195-196;
+ *                           common/deploy_network_ao.py:121-122,252-253)
+ *   ukbb_fcn_forward       same call with inputs/outputs already resident in
+ *                          HBM (no reference counterpart: TF always copies)
+ *   ukbb_fcn_destroy       leaving the `with tf.Session() as sess:` block
+ *
+ * The graph evaluated is the one common/train_network.py:142-199 builds with
+ * common/network.py:170-230 (build_FCN) or common/network_ao.py:18-64 (UNet),
+ * in inference mode ('training:0' = False): conv -> BN(moving stats) -> ReLU.
+ *
+ * Conventions: plain C types only; tensors are dense NHWC float32 / int32;
+ * no exceptions cross the ABI: functions return 0 on success or a negative
+ * UKBB_E* code and leave a message retrievable with ukbb_fcn_last_error()
+ * (thread-local).  A handle belongs to one device and must not be used from
+ * two threads at once (the reference is single-threaded too).
+ * There is NO CPU fallback: create() fails when no gfx950 device is usable.
+ */
+#ifndef UKBB_FCN_H
+#define UKBB_FCN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UKBB_FCN_ABI_VERSION 1
+#define UKBB_FCN_MAX_LEVEL 8
+
+#define UKBB_OK 0
+#define UKBB_EINVAL (-1)   /* bad argument (shape not a multiple of 16, NULL, ...) */
+#define UKBB_EARCH (-2)    /* architecture not supported by the kernels */
+#define UKBB_EDEVICE (-3)  /* HIP runtime error / no device */
+#define UKBB_ENOMEM (-4)
+
+#define UKBB_KIND_FCN 0    /* common/network.py:170 build_FCN */
+#define UKBB_KIND_UNET 1   /* common/network_ao.py:18 UNet    */
+
+/* Hyper-parameters of build_FCN / UNet as bound in common/train_network.py:174-195
+ * and common/train_network_ao.py:268,275-284. */
+typedef struct ukbb_fcn_arch {
+    int32_t kind;
+    int32_t n_class;
+    int32_t n_level;
+    int32_t n_filter[UKBB_FCN_MAX_LEVEL];
+    int32_t n_block[UKBB_FCN_MAX_LEVEL];
+    int32_t same_dim;   /* FCN only (32) */
+    int32_t fc;         /* FCN only (64) */
+} ukbb_fcn_arch;
+
+typedef struct ukbb_fcn_handle ukbb_fcn_handle;
+
+int ukbb_fcn_abi_version(void);
+const char *ukbb_fcn_last_error(void);
+
+/* Number of floats ukbb_fcn_create expects for this architecture, or 0 if the
+ * architecture is malformed.  Layout: for every layer in graph order
+ * (encoder convs; FCN: same_dim0..4, out0, out1, logits; UNet: per decoder
+ * level the transposed conv then its convs, logits): kernel in TF layout
+ * (HWIO; [kh,kw,Cout,Cin] for the transposed conv), then gamma, beta,
+ * moving_mean, moving_variance -- or bias for the logits layer. */
+size_t ukbb_fcn_weight_count(const ukbb_fcn_arch *arch);
+
+/* Bind a model to `device` (HIP ordinal).  Folds BN into the kernels, packs
+ * MFMA operand fragments and uploads them.  `weights` is host memory and is
+ * not referenced after return.  NULL on failure. */
+ukbb_fcn_handle *ukbb_fcn_create(const ukbb_fcn_arch *arch, const float *weights,
+                                 size_t n_floats, int device);
+void ukbb_fcn_destroy(ukbb_fcn_handle *h);
+
+/* Pre-size the activation workspace for batches up to n x h x w (optional;
+ * forward() grows it on demand, which synchronises the device). */
+int ukbb_fcn_reserve(ukbb_fcn_handle *h, int n, int height, int width);
+
+/* One forward pass, everything in device memory, asynchronous on `stream`
+ * (a hipStream_t; NULL = the null stream).  image: [n,h,w,1] float32 with
+ * h % 16 == 0 and w % 16 == 0 (the reference pads to that,
+ * common/deploy_network.py:97).  Any of logits / prob ([n,h,w,n_class]
+ * float32) and pred ([n,h,w] int32, = argmax over classes, lowest index on
+ * ties) may be NULL to skip producing it. */
+int ukbb_fcn_forward(ukbb_fcn_handle *h, const float *image, int n, int height, int width,
+                     float *logits, float *prob, int32_t *pred, void *stream);
+
+/* Same with host buffers: H2D copy, forward, D2H copy, synchronous --
+ * the exact shape of the reference's sess.run call. */
+int ukbb_fcn_forward_host(ukbb_fcn_handle *h, const float *image, int n, int height, int width,
+                          float *logits, float *prob, int32_t *pred);
+
+/* ---- measurement / introspection (bench.py, tests) ---------------------- */
+
+/* Kernel launches of one forward, in launch order. */
+int ukbb_fcn_num_kernels(const ukbb_fcn_handle *h);
+const char *ukbb_fcn_kernel_name(const ukbb_fcn_handle *h, int i);
+/* Algorithmic MACs kernel i performs for the LAST forward's shape. */
+double ukbb_fcn_kernel_macs(const ukbb_fcn_handle *h, int i);
+
+/* When enabled, every launch of forward() is bracketed by hipEvents recorded
+ * on the forward's own stream; ukbb_fcn_kernel_times() then synchronises and
+ * returns, per kernel, the summed duration in ms and the number of timed
+ * launches since the last reset. */
+int ukbb_fcn_set_timing(ukbb_fcn_handle *h, int enable);
+int ukbb_fcn_kernel_times(ukbb_fcn_handle *h, double *sum_ms, int64_t *count, int n, int reset);
+
+/* Copy an intermediate activation of the LAST forward to host (tests only).
+ * Names: "conv0".."conv4" (level outputs), "sq1".."sq4" (FCN squeezed maps),
+ * "up3".."up0" (UNet decoder outputs).  Returns the number of floats, or a
+ * negative error; with dst == NULL only the size is returned. */
+int64_t ukbb_fcn_get_activation(ukbb_fcn_handle *h, const char *name, float *dst, int64_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UKBB_FCN_H */

@@ -1,0 +1,97 @@
+"""ctypes binding of include/ukbb_fcn.h (the only way Python reaches the kernels).
+
+Fails loudly: if ``libukbb_fcn.so`` has not been built
+(``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C ukbb_cardiac_amd/csrc``) importing this module raises -- there is no
+CPU fallback on the product path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libukbb_fcn.so')
+ABI_VERSION = 1
+MAX_LEVEL = 8
+
+# every symbol include/ukbb_fcn.h declares
+EXPORTS = [
+    'ukbb_fcn_abi_version', 'ukbb_fcn_last_error', 'ukbb_fcn_weight_count', 'ukbb_fcn_create',
+    'ukbb_fcn_destroy', 'ukbb_fcn_reserve', 'ukbb_fcn_forward', 'ukbb_fcn_forward_host',
+    'ukbb_fcn_num_kernels', 'ukbb_fcn_kernel_name', 'ukbb_fcn_kernel_macs', 'ukbb_fcn_set_timing',
+    'ukbb_fcn_kernel_times', 'ukbb_fcn_get_activation',
+]
+
+
+class ArchStruct(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('n_class', C.c_int32), ('n_level', C.c_int32),
+                ('n_filter', C.c_int32 * MAX_LEVEL), ('n_block', C.c_int32 * MAX_LEVEL),
+                ('same_dim', C.c_int32), ('fc', C.c_int32)]
+
+
+def arch_struct(arch) -> ArchStruct:
+    s = ArchStruct()
+    s.kind, s.n_class, s.n_level = arch.kind, arch.n_class, arch.n_level
+    for i in range(arch.n_level):
+        s.n_filter[i] = arch.n_filter[i]
+        s.n_block[i] = arch.n_block[i]
+    s.same_dim, s.fc = arch.same_dim, arch.fc
+    return s
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            'ukbb_cardiac_amd: %s is missing. Build the gfx950 HIP library first '
+            '(python -c "import __graft_entry__ as g; g.build()"). There is no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, f32p, i32p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)
+    lib.ukbb_fcn_abi_version.restype = C.c_int
+    lib.ukbb_fcn_last_error.restype = C.c_char_p
+    lib.ukbb_fcn_weight_count.restype = C.c_size_t
+    lib.ukbb_fcn_weight_count.argtypes = [C.POINTER(ArchStruct)]
+    lib.ukbb_fcn_create.restype = vp
+    lib.ukbb_fcn_create.argtypes = [C.POINTER(ArchStruct), f32p, C.c_size_t, C.c_int]
+    lib.ukbb_fcn_destroy.restype = None
+    lib.ukbb_fcn_destroy.argtypes = [vp]
+    lib.ukbb_fcn_reserve.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    lib.ukbb_fcn_forward.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
+    lib.ukbb_fcn_forward_host.argtypes = [vp, f32p, C.c_int, C.c_int, C.c_int, f32p, f32p, i32p]
+    lib.ukbb_fcn_num_kernels.argtypes = [vp]
+    lib.ukbb_fcn_kernel_name.restype = C.c_char_p
+    lib.ukbb_fcn_kernel_name.argtypes = [vp, C.c_int]
+    lib.ukbb_fcn_kernel_macs.restype = C.c_double
+    lib.ukbb_fcn_kernel_macs.argtypes = [vp, C.c_int]
+    lib.ukbb_fcn_set_timing.argtypes = [vp, C.c_int]
+    lib.ukbb_fcn_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int, C.c_int]
+    lib.ukbb_fcn_get_activation.restype = C.c_int64
+    lib.ukbb_fcn_get_activation.argtypes = [vp, C.c_char_p, f32p, C.c_int64]
+    if lib.ukbb_fcn_abi_version() != ABI_VERSION:
+        raise ImportError('libukbb_fcn.so ABI %d != binding ABI %d: rebuild' % (lib.ukbb_fcn_abi_version(), ABI_VERSION))
+    return lib
+
+
+lib = _load()
+
+
+class UkbbFcnError(RuntimeError):
+    pass
+
+
+def last_error() -> str:
+    return lib.ukbb_fcn_last_error().decode()
+
+
+def check(rc: int, what: str):
+    if rc < 0:
+        raise UkbbFcnError('%s failed (%d): %s' % (what, rc, last_error()))
+    return rc
+
+
+def f32ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def i32ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))

@@ -1,0 +1,670 @@
+// Engine behind include/ukbb_fcn.h: owns device weights (BN folded, packed in
+// MFMA fragment order), the activation workspace in HBM and the launch plan.
+//
+// Reference counterpart: the TensorFlow session + restored graph of
+// common/deploy_network.py:44-49 and the sess.run call at :110-111.
+#include "../../include/ukbb_fcn.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+using namespace ukbb;
+
+namespace {
+
+thread_local std::string g_err;
+
+void set_err(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+#define HIP_TRY(expr, code)                                                            \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return code;                                                               \
+        }                                                                              \
+    } while (0)
+
+constexpr float BN_EPS = 1e-3f;   // tf.layers.batch_normalization default
+
+struct HostLayer {            // one conv(+BN) unit with BN folded (fp32, same op order as
+    std::string name;         // ukbb_cardiac_amd/weights.py fold_bn)
+    int ks = 0, cin = 0, cout = 0;
+    bool transposed = false, relu = true;
+    std::vector<float> w;     // [ks][ks][cin][cout], scale folded in
+    std::vector<float> b;     // [cout]
+};
+
+struct DevBuf {
+    float *p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t ensure(size_t want) {
+        if (want <= n) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; n = 0; }
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), want * sizeof(float));
+        if (e == hipSuccess) n = want;
+        return e;
+    }
+    hipError_t upload(const std::vector<float> &v) {
+        hipError_t e = ensure(v.size());
+        if (e != hipSuccess) return e;
+        return hipMemcpy(p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice);
+    }
+};
+
+enum OpKind { OP_FIRST, OP_CONV, OP_HEAD, OP_TCONV, OP_LOGITS };
+
+struct Op {                    // one kernel launch of the plan
+    OpKind kind;
+    std::string name;
+    int layer = -1;            // index into host layers (OP_FIRST/OP_CONV/OP_TCONV/OP_LOGITS)
+    int cfg = -1;              // conv config id
+    int in0 = -1, in1 = -1;    // activation buffer ids (-1: network input / none)
+    int out = -1;
+    int sq[4] = {-1, -1, -1, -1};   // OP_HEAD: squeezed maps of levels 1..4
+    int H = 0, W = 0, Ho = 0, Wo = 0, stride = 1, pad_y = 0, pad_x = 0;
+    double macs_per_image = 0; // algorithmic
+    const float *wpk = nullptr, *bias = nullptr;
+};
+
+}  // namespace
+
+struct ukbb_fcn_handle {
+    ukbb_fcn_arch arch{};
+    int device = 0;
+    std::vector<HostLayer> layers;
+    std::map<std::string, int> layer_index;
+
+    // device-side parameters
+    std::map<std::string, std::unique_ptr<DevBuf>> dev;   // keyed by "<layer>/<what>"
+
+    // activation workspace
+    std::vector<std::unique_ptr<DevBuf>> act;
+    std::vector<size_t> act_per_image;        // floats per image at the planned H,W
+    std::vector<std::string> act_name;
+    DevBuf io_image, io_logits, io_prob, io_pred;   // staging for forward_host
+
+    // plan
+    int plan_h = 0, plan_w = 0, cap_n = 0;
+    std::vector<Op> ops;
+    int last_n = 0;
+
+    // timing
+    bool timing = false;
+    std::vector<hipEvent_t> ev;               // 2 per op
+    std::vector<double> t_sum;
+    std::vector<int64_t> t_cnt;
+    bool ev_pending = false;
+
+    ~ukbb_fcn_handle() {
+        for (auto e : ev) (void)hipEventDestroy(e);
+    }
+};
+
+namespace {
+
+const float *dev_ptr(ukbb_fcn_handle *h, const std::string &key) {
+    auto it = h->dev.find(key);
+    return it == h->dev.end() ? nullptr : it->second->p;
+}
+
+int upload(ukbb_fcn_handle *h, const std::string &key, const std::vector<float> &v) {
+    auto &slot = h->dev[key];
+    if (!slot) slot.reset(new DevBuf);
+    HIP_TRY(slot->upload(v), UKBB_EDEVICE);
+    return UKBB_OK;
+}
+
+// ---- architecture walk ---------------------------------------------------------
+struct Spec { std::string name; int ks, cin, cout; bool bn, bias, transposed; };
+
+bool arch_specs(const ukbb_fcn_arch &a, std::vector<Spec> &out) {
+    out.clear();
+    if (a.n_level < 1 || a.n_level > UKBB_FCN_MAX_LEVEL || a.n_class < 1) return false;
+    int cin = 1;
+    char nm[64];
+    for (int l = 0; l < a.n_level; ++l) {
+        if (a.n_block[l] < 1 || a.n_filter[l] < 1) return false;
+        for (int i = 0; i < a.n_block[l]; ++i) {
+            snprintf(nm, sizeof nm, "conv%d_%d", l, i);
+            out.push_back({nm, 3, cin, a.n_filter[l], true, false, false});
+            cin = a.n_filter[l];
+        }
+    }
+    if (a.kind == UKBB_KIND_FCN) {
+        for (int l = 0; l < a.n_level; ++l) {
+            snprintf(nm, sizeof nm, "same_dim%d", l);
+            out.push_back({nm, 1, a.n_filter[l], a.same_dim, true, false, false});
+        }
+        out.push_back({"out0", 1, a.same_dim * a.n_level, a.fc, true, false, false});
+        out.push_back({"out1", 1, a.fc, a.fc, true, false, false});
+        out.push_back({"logits", 1, a.fc, a.n_class, false, true, false});
+    } else if (a.kind == UKBB_KIND_UNET) {
+        for (int l = a.n_level - 2; l >= 0; --l) {
+            snprintf(nm, sizeof nm, "up%d_t", l);
+            out.push_back({nm, 3, a.n_filter[l + 1], a.n_filter[l], true, false, true});
+            int c = 2 * a.n_filter[l];
+            for (int i = 0; i < a.n_block[l]; ++i) {
+                snprintf(nm, sizeof nm, "up%d_%d", l, i);
+                out.push_back({nm, 3, c, a.n_filter[l], true, false, false});
+                c = a.n_filter[l];
+            }
+        }
+        out.push_back({"logits", 1, a.n_filter[0], a.n_class, false, true, false});
+    } else {
+        return false;
+    }
+    return true;
+}
+
+size_t spec_floats(const Spec &s) {
+    size_t n = (size_t)s.ks * s.ks * s.cin * s.cout;
+    if (s.bn) n += 4 * (size_t)s.cout;
+    if (s.bias) n += s.cout;
+    return n;
+}
+
+bool supported(const ukbb_fcn_arch &a, std::string &why) {
+    if (a.n_level != 5) { why = "n_level must be 5"; return false; }
+    if (a.n_filter[0] != 16) { why = "n_filter[0] must be 16"; return false; }
+    for (int l = 1; l < a.n_level; ++l)
+        if (a.n_filter[l] % 32) { why = "n_filter[l>0] must be multiples of 32"; return false; }
+    if (a.kind == UKBB_KIND_FCN) {
+        if (a.same_dim != 32 || a.fc != 64) { why = "FCN head kernel is built for same_dim=32, fc=64"; return false; }
+        if (a.n_class < 2 || a.n_class > 6) { why = "n_class must be in 2..6"; return false; }
+    } else {
+        if (a.n_class < 2 || a.n_class > 4) { why = "UNet n_class must be in 2..4"; return false; }
+    }
+    return true;
+}
+
+// ---- conv tiling choice --------------------------------------------------------
+int override_cfg(const std::string &layer) {
+    const char *env = getenv("UKBB_CONV_CFG");     // e.g. "conv0_1:7,conv4_1:6"
+    if (!env) return -1;
+    std::string s(env);
+    size_t pos = 0;
+    while (pos < s.size()) {
+        size_t e = s.find(',', pos);
+        if (e == std::string::npos) e = s.size();
+        std::string item = s.substr(pos, e - pos);
+        size_t c = item.find(':');
+        if (c != std::string::npos && item.substr(0, c) == layer) return atoi(item.c_str() + c + 1);
+        pos = e + 1;
+    }
+    return -1;
+}
+
+int choose_cfg(const std::string &layer, int ks, int stride, int c0, int c1, int cout, int Ho, int Wo, int N) {
+    int forced = override_cfg(layer);
+    double best = 1e300;
+    int best_id = -1;
+    for (int i = 0; i < num_conv_configs(); ++i) {
+        const ConvConfig &c = conv_config(i);
+        if (c.ks != ks || c.stride != stride) continue;
+        const int group = c.mb * c.cb * c.wm;
+        if (cout % group || c0 % c.kc || c1 % c.kc) continue;
+        if (c.id == forced) return c.id;
+        const int tiles = ((Ho + c.th - 1) / c.th) * ((Wo + c.tw - 1) / c.tw);
+        const int npb = (c.th * c.tw + c.mb - 1) / c.mb;
+        const int pbw = (npb + c.wn - 1) / c.wn;
+        const double cyc = (double)pbw * c.cb * (ks * ks * (c0 + c1) / (c.mb == 32 ? 2 : 4)) * (c.mb == 32 ? 64 : 32);
+        const double wgs = (double)tiles * N * (cout / group);
+        // total matrix-pipe time if perfectly spread, with a floor of one full wave of workgroups
+        double cost = std::max(wgs, 256.0) * cyc;
+        // prefer >= 2 resident workgroups per CU (staging of one overlaps MFMA of another)
+        if (c.lds_bytes > 80 * 1024) cost *= 1.15;
+        if (cost < best) { best = cost; best_id = c.id; }
+    }
+    return best_id;
+}
+
+int find_cfg(int id, ConvConfig &out) {
+    for (int i = 0; i < num_conv_configs(); ++i)
+        if (conv_config(i).id == id) { out = conv_config(i); return 0; }
+    return -1;
+}
+
+// ---- plan ------------------------------------------------------------------------
+int new_act(ukbb_fcn_handle *h, const std::string &name, size_t per_image) {
+    h->act.emplace_back(new DevBuf);
+    h->act_per_image.push_back(per_image);
+    h->act_name.push_back(name);
+    return (int)h->act.size() - 1;
+}
+
+int ensure_packed(ukbb_fcn_handle *h, int layer, const ConvConfig &c, const float **wpk) {
+    const HostLayer &L = h->layers[layer];
+    char key[128];
+    snprintf(key, sizeof key, "%s/pk_mb%d_kc%d", L.name.c_str(), c.mb, c.kc);
+    if (!dev_ptr(h, key)) {
+        std::vector<float> pk(L.w.size());
+        pack_conv_weights(L.w.data(), L.ks, L.cin, L.cout, c.mb, c.kc, pk.data());
+        int rc = upload(h, key, pk);
+        if (rc) return rc;
+    }
+    *wpk = dev_ptr(h, key);
+    return UKBB_OK;
+}
+
+int add_conv(ukbb_fcn_handle *h, const std::string &lname, int in0, int in1, int c1, int H, int W, int stride,
+             int n_hint, int *out_buf) {
+    const int li = h->layer_index.at(lname);
+    const HostLayer &L = h->layers[li];
+    Op op;
+    op.kind = OP_CONV; op.name = lname; op.layer = li; op.in0 = in0; op.in1 = in1;
+    op.H = H; op.W = W; op.stride = stride;
+    op.Ho = (H + stride - 1) / stride; op.Wo = (W + stride - 1) / stride;
+    // TF 'SAME' pad_before
+    op.pad_y = std::max((op.Ho - 1) * stride + L.ks - H, 0) / 2;
+    op.pad_x = std::max((op.Wo - 1) * stride + L.ks - W, 0) / 2;
+    const int c0 = L.cin - c1;
+    op.cfg = choose_cfg(lname, L.ks, stride, c0, c1, L.cout, op.Ho, op.Wo, n_hint);
+    if (op.cfg < 0) { set_err("no conv tiling for layer %s (ks %d stride %d cin %d+%d cout %d)", lname.c_str(), L.ks, stride, c0, c1, L.cout); return UKBB_EARCH; }
+    ConvConfig c;
+    find_cfg(op.cfg, c);
+    int rc = ensure_packed(h, li, c, &op.wpk);
+    if (rc) return rc;
+    op.bias = dev_ptr(h, lname + "/bias");
+    op.out = new_act(h, lname, (size_t)op.Ho * op.Wo * L.cout);
+    op.macs_per_image = (double)op.Ho * op.Wo * L.ks * L.ks * L.cin * L.cout;
+    h->ops.push_back(op);
+    *out_buf = op.out;
+    return UKBB_OK;
+}
+
+int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
+    h->ops.clear();
+    h->act.clear(); h->act_per_image.clear(); h->act_name.clear();
+    h->cap_n = 0;
+    const ukbb_fcn_arch &a = h->arch;
+    char nm[64];
+    // encoder (network.py:179-189 / network_ao.py:31-41)
+    int cur = -1, ch = 1, cw = 1;
+    std::vector<int> level_out(a.n_level), lh(a.n_level), lw(a.n_level);
+    int hh = H, ww = W;
+    for (int l = 0; l < a.n_level; ++l) {
+        for (int i = 0; i < a.n_block[l]; ++i) {
+            snprintf(nm, sizeof nm, "conv%d_%d", l, i);
+            const int stride = (l > 0 && i == 0) ? 2 : 1;
+            if (l == 0 && i == 0) {
+                Op op; op.kind = OP_FIRST; op.name = nm; op.layer = h->layer_index.at(nm);
+                op.H = op.Ho = H; op.W = op.Wo = W;
+                op.out = new_act(h, nm, (size_t)H * W * a.n_filter[0]);
+                op.macs_per_image = (double)H * W * 9 * a.n_filter[0];
+                h->ops.push_back(op);
+                cur = op.out;
+            } else {
+                int out;
+                int rc = add_conv(h, nm, cur, -1, 0, hh, ww, stride, n_hint, &out);
+                if (rc) return rc;
+                cur = out;
+                if (stride == 2) { hh = (hh + 1) / 2; ww = (ww + 1) / 2; }
+            }
+        }
+        level_out[l] = cur; lh[l] = hh; lw[l] = ww;
+        h->act_name[cur] = std::string("conv") + std::to_string(l);
+    }
+    (void)ch; (void)cw;
+    if (a.kind == UKBB_KIND_FCN) {
+        std::vector<int> sq(a.n_level, -1);
+        for (int l = 1; l < a.n_level; ++l) {     // same_dim0 lives inside the head kernel
+            snprintf(nm, sizeof nm, "same_dim%d", l);
+            int out;
+            int rc = add_conv(h, nm, level_out[l], -1, 0, lh[l], lw[l], 1, n_hint, &out);
+            if (rc) return rc;
+            sq[l] = out;
+            h->act_name[out] = std::string("sq") + std::to_string(l);
+        }
+        Op op; op.kind = OP_HEAD; op.name = "head"; op.in0 = level_out[0];
+        op.H = op.Ho = H; op.W = op.Wo = W;
+        op.macs_per_image = (double)H * W * (a.n_filter[0] * a.same_dim + a.same_dim * a.n_level * a.fc +
+                                             a.fc * a.fc + a.fc * a.n_class);
+        for (int l = 1; l < 5; ++l) op.sq[l - 1] = sq[l];
+        h->ops.push_back(op);
+    } else {
+        set_err("UNet plan not built yet");
+        return UKBB_EARCH;
+    }
+    h->plan_h = H; h->plan_w = W;
+    // events
+    for (auto e : h->ev) (void)hipEventDestroy(e);
+    h->ev.clear();
+    h->t_sum.assign(h->ops.size(), 0.0);
+    h->t_cnt.assign(h->ops.size(), 0);
+    h->ev_pending = false;
+    return UKBB_OK;
+}
+
+int ensure_capacity(ukbb_fcn_handle *h, int n) {
+    if (n <= h->cap_n) return UKBB_OK;
+    for (size_t i = 0; i < h->act.size(); ++i)
+        HIP_TRY(h->act[i]->ensure(h->act_per_image[i] * (size_t)n), UKBB_ENOMEM);
+    h->cap_n = n;
+    return UKBB_OK;
+}
+
+int check_shape(int n, int H, int W) {
+    if (n < 1 || H < 16 || W < 16 || (H % 16) || (W % 16)) {
+        set_err("invalid batch shape n=%d h=%d w=%d: h and w must be positive multiples of 16 "
+                "(the reference pads to that, common/deploy_network.py:97)", n, H, W);
+        return UKBB_EINVAL;
+    }
+    if ((long long)n * H * W > (1ll << 31) - 1) { set_err("batch too large for 32-bit pixel indexing"); return UKBB_EINVAL; }
+    return UKBB_OK;
+}
+
+int prepare(ukbb_fcn_handle *h, int n, int H, int W) {
+    int rc = check_shape(n, H, W);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(h->device), UKBB_EDEVICE);
+    if (H != h->plan_h || W != h->plan_w) {
+        HIP_TRY(hipDeviceSynchronize(), UKBB_EDEVICE);
+        rc = build_plan(h, H, W, n);
+        if (rc) { h->plan_h = h->plan_w = 0; return rc; }
+    }
+    if (n > h->cap_n) {
+        HIP_TRY(hipDeviceSynchronize(), UKBB_EDEVICE);
+        rc = ensure_capacity(h, n);
+        if (rc) return rc;
+    }
+    return UKBB_OK;
+}
+
+int collect_events(ukbb_fcn_handle *h) {
+    if (!h->ev_pending) return UKBB_OK;
+    HIP_TRY(hipEventSynchronize(h->ev.back()), UKBB_EDEVICE);
+    for (size_t i = 0; i < h->ops.size(); ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]), UKBB_EDEVICE);
+        h->t_sum[i] += ms;
+        h->t_cnt[i] += 1;
+    }
+    h->ev_pending = false;
+    return UKBB_OK;
+}
+
+int run_plan(ukbb_fcn_handle *h, const float *image, int n, float *logits, float *prob, int32_t *pred,
+             hipStream_t s) {
+    const ukbb_fcn_arch &a = h->arch;
+    if (h->timing) {
+        int rc = collect_events(h);
+        if (rc) return rc;
+        if (h->ev.size() != 2 * h->ops.size()) {
+            for (auto e : h->ev) (void)hipEventDestroy(e);
+            h->ev.assign(2 * h->ops.size(), nullptr);
+            for (auto &e : h->ev) HIP_TRY(hipEventCreate(&e), UKBB_EDEVICE);
+        }
+    }
+    for (size_t i = 0; i < h->ops.size(); ++i) {
+        const Op &op = h->ops[i];
+        if (h->timing) HIP_TRY(hipEventRecord(h->ev[2 * i], s), UKBB_EDEVICE);
+        hipError_t e = hipSuccess;
+        switch (op.kind) {
+            case OP_FIRST: {
+                const HostLayer &L = h->layers[op.layer];
+                FirstArgs fa{image, dev_ptr(h, L.name + "/w"), dev_ptr(h, L.name + "/bias"), h->act[op.out]->p,
+                             n, op.H, op.W, L.cout};
+                e = launch_first(fa, s);
+                break;
+            }
+            case OP_CONV: {
+                const HostLayer &L = h->layers[op.layer];
+                ConvConfig c;
+                find_cfg(op.cfg, c);
+                ConvArgs ca{};
+                ca.in0 = h->act[op.in0]->p;
+                ca.in1 = op.in1 >= 0 ? h->act[op.in1]->p : nullptr;
+                ca.C1 = op.in1 >= 0 ? (int)(h->act_per_image[op.in1] / ((size_t)op.H * op.W)) : 0;
+                ca.C0 = L.cin - ca.C1;
+                ca.wpk = op.wpk; ca.bias = op.bias; ca.out = h->act[op.out]->p;
+                ca.N = n; ca.H = op.H; ca.W = op.W; ca.Ho = op.Ho; ca.Wo = op.Wo; ca.Cout = L.cout;
+                ca.pad_y = op.pad_y; ca.pad_x = op.pad_x;
+                ca.tiles_y = (op.Ho + c.th - 1) / c.th; ca.tiles_x = (op.Wo + c.tw - 1) / c.tw;
+                ca.relu = L.relu ? 1 : 0;
+                e = launch_conv(op.cfg, ca, s);
+                break;
+            }
+            case OP_HEAD: {
+                HeadArgs ha{};
+                ha.conv0 = h->act[op.in0]->p;
+                for (int l = 0; l < 4; ++l) ha.sq[l] = h->act[op.sq[l]]->p;
+                ha.w_s0 = dev_ptr(h, "head/w_s0"); ha.b_s0 = dev_ptr(h, "same_dim0/bias");
+                ha.w_o0 = dev_ptr(h, "head/w_o0"); ha.b_o0 = dev_ptr(h, "out0/bias");
+                ha.w_o1 = dev_ptr(h, "head/w_o1"); ha.b_o1 = dev_ptr(h, "out1/bias");
+                ha.w_lg = dev_ptr(h, "head/w_lg"); ha.b_lg = dev_ptr(h, "logits/bias");
+                ha.logits = logits; ha.prob = prob; ha.pred = pred;
+                ha.N = n; ha.H = op.H; ha.W = op.W; ha.n_class = a.n_class;
+                e = launch_head(ha, s);
+                break;
+            }
+            default:
+                set_err("op kind %d not implemented", (int)op.kind);
+                return UKBB_EARCH;
+        }
+        if (e != hipSuccess) { set_err("launch of %s failed: %s", op.name.c_str(), hipGetErrorString(e)); return UKBB_EDEVICE; }
+        if (h->timing) HIP_TRY(hipEventRecord(h->ev[2 * i + 1], s), UKBB_EDEVICE);
+    }
+    if (h->timing) h->ev_pending = true;
+    h->last_n = n;
+    return UKBB_OK;
+}
+
+}  // namespace
+
+// =============================== C ABI ===========================================
+extern "C" {
+
+int ukbb_fcn_abi_version(void) { return UKBB_FCN_ABI_VERSION; }
+
+const char *ukbb_fcn_last_error(void) { return g_err.c_str(); }
+
+size_t ukbb_fcn_weight_count(const ukbb_fcn_arch *arch) {
+    if (!arch) return 0;
+    std::vector<Spec> specs;
+    if (!arch_specs(*arch, specs)) return 0;
+    size_t n = 0;
+    for (auto &s : specs) n += spec_floats(s);
+    return n;
+}
+
+ukbb_fcn_handle *ukbb_fcn_create(const ukbb_fcn_arch *arch, const float *weights, size_t n_floats, int device) {
+    if (!arch || !weights) { set_err("create: NULL argument"); return nullptr; }
+    std::vector<Spec> specs;
+    if (!arch_specs(*arch, specs)) { set_err("create: malformed architecture descriptor"); return nullptr; }
+    std::string why;
+    if (!supported(*arch, why)) { set_err("create: unsupported architecture: %s", why.c_str()); return nullptr; }
+    size_t want = 0;
+    for (auto &s : specs) want += spec_floats(s);
+    if (want != n_floats) { set_err("create: expected %zu weight floats, got %zu", want, n_floats); return nullptr; }
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+        set_err("create: no HIP device visible (this library has no CPU fallback)");
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev) { set_err("create: device %d out of range (0..%d)", device, ndev - 1); return nullptr; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { set_err("create: hipGetDeviceProperties failed"); return nullptr; }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_err("create: device %d is %s; kernels are built for gfx950 (MI355X) only", device, prop.gcnArchName);
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) { set_err("create: hipSetDevice failed"); return nullptr; }
+
+    std::unique_ptr<ukbb_fcn_handle> h(new ukbb_fcn_handle);
+    h->arch = *arch;
+    h->device = device;
+
+    // ---- fold BN (fp32; same op order as weights.py fold_bn) --------------------------
+    const float *p = weights;
+    for (auto &s : specs) {
+        HostLayer L;
+        L.name = s.name; L.ks = s.ks; L.cin = s.cin; L.cout = s.cout; L.transposed = s.transposed;
+        L.relu = s.bn;
+        const size_t nk = (size_t)s.ks * s.ks * s.cin * s.cout;
+        const float *k = p; p += nk;
+        std::vector<float> scale(s.cout, 1.f);
+        L.b.assign(s.cout, 0.f);
+        if (s.bn) {
+            const float *gamma = p, *beta = p + s.cout, *mean = p + 2 * s.cout, *var = p + 3 * s.cout;
+            p += 4 * (size_t)s.cout;
+            for (int c = 0; c < s.cout; ++c) {
+                const volatile float sc = gamma[c] / sqrtf(var[c] + BN_EPS);
+                const volatile float ms = mean[c] * sc;            // volatile: no fma contraction
+                scale[c] = sc;
+                L.b[c] = beta[c] - ms;
+            }
+        }
+        if (s.bias) { for (int c = 0; c < s.cout; ++c) L.b[c] = p[c]; p += s.cout; }
+        L.w.resize(nk);
+        if (!s.transposed) {
+            for (size_t i = 0; i < nk; ++i) L.w[i] = k[i] * scale[i % s.cout];
+        } else {
+            // TF transposed filter [kh][kw][Cout][Cin] -> [kh][kw][Cin][Cout]
+            for (int t = 0; t < s.ks * s.ks; ++t)
+                for (int co = 0; co < s.cout; ++co)
+                    for (int ci = 0; ci < s.cin; ++ci)
+                        L.w[((size_t)t * s.cin + ci) * s.cout + co] = k[((size_t)t * s.cout + co) * s.cin + ci] * scale[co];
+        }
+        h->layer_index[L.name] = (int)h->layers.size();
+        h->layers.push_back(std::move(L));
+    }
+
+    // ---- upload biases and the non-MFMA weights ------------------------------------------
+    for (auto &L : h->layers)
+        if (upload(h.get(), L.name + "/bias", L.b)) return nullptr;
+    {
+        const HostLayer &L0 = h->layers[h->layer_index.at("conv0_0")];
+        if (upload(h.get(), "conv0_0/w", L0.w)) return nullptr;      // [9][16]
+    }
+    if (arch->kind == UKBB_KIND_FCN) {
+        const HostLayer &s0 = h->layers[h->layer_index.at("same_dim0")];
+        const HostLayer &o0 = h->layers[h->layer_index.at("out0")];
+        const HostLayer &o1 = h->layers[h->layer_index.at("out1")];
+        const HostLayer &lg = h->layers[h->layer_index.at("logits")];
+        std::vector<float> v;
+        v.assign(64 * 8, 0.f);              pack_head_s0(s0.w.data(), v.data());
+        if (upload(h.get(), "head/w_s0", v)) return nullptr;
+        v.assign(5 * 2 * 16 * 64, 0.f);     pack_head_o0(o0.w.data(), v.data());
+        if (upload(h.get(), "head/w_o0", v)) return nullptr;
+        v.assign(2 * 2 * 16 * 64, 0.f);     pack_head_o1(o1.w.data(), v.data());
+        if (upload(h.get(), "head/w_o1", v)) return nullptr;
+        v.assign(2 * arch->n_class * 32, 0.f); pack_head_lg(lg.w.data(), arch->n_class, v.data());
+        if (upload(h.get(), "head/w_lg", v)) return nullptr;
+    } else {
+        const HostLayer &lg = h->layers[h->layer_index.at("logits")];
+        if (upload(h.get(), "logits/w", lg.w)) return nullptr;
+    }
+    return h.release();
+}
+
+void ukbb_fcn_destroy(ukbb_fcn_handle *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    delete h;
+}
+
+int ukbb_fcn_reserve(ukbb_fcn_handle *h, int n, int height, int width) {
+    if (!h) { set_err("reserve: NULL handle"); return UKBB_EINVAL; }
+    return prepare(h, n, height, width);
+}
+
+int ukbb_fcn_forward(ukbb_fcn_handle *h, const float *image, int n, int height, int width,
+                     float *logits, float *prob, int32_t *pred, void *stream) {
+    if (!h || !image) { set_err("forward: NULL argument"); return UKBB_EINVAL; }
+    int rc = prepare(h, n, height, width);
+    if (rc) return rc;
+    return run_plan(h, image, n, logits, prob, pred, static_cast<hipStream_t>(stream));
+}
+
+int ukbb_fcn_forward_host(ukbb_fcn_handle *h, const float *image, int n, int height, int width,
+                          float *logits, float *prob, int32_t *pred) {
+    if (!h || !image) { set_err("forward_host: NULL argument"); return UKBB_EINVAL; }
+    int rc = prepare(h, n, height, width);
+    if (rc) return rc;
+    const size_t npix = (size_t)n * height * width, ncls = h->arch.n_class;
+    HIP_TRY(h->io_image.ensure(npix), UKBB_ENOMEM);
+    if (logits) HIP_TRY(h->io_logits.ensure(npix * ncls), UKBB_ENOMEM);
+    if (prob) HIP_TRY(h->io_prob.ensure(npix * ncls), UKBB_ENOMEM);
+    if (pred) HIP_TRY(h->io_pred.ensure(npix), UKBB_ENOMEM);
+    HIP_TRY(hipMemcpyAsync(h->io_image.p, image, npix * sizeof(float), hipMemcpyHostToDevice, nullptr), UKBB_EDEVICE);
+    rc = run_plan(h, h->io_image.p, n, logits ? h->io_logits.p : nullptr, prob ? h->io_prob.p : nullptr,
+                  pred ? reinterpret_cast<int32_t *>(h->io_pred.p) : nullptr, nullptr);
+    if (rc) return rc;
+    if (logits) HIP_TRY(hipMemcpyAsync(logits, h->io_logits.p, npix * ncls * sizeof(float), hipMemcpyDeviceToHost, nullptr), UKBB_EDEVICE);
+    if (prob) HIP_TRY(hipMemcpyAsync(prob, h->io_prob.p, npix * ncls * sizeof(float), hipMemcpyDeviceToHost, nullptr), UKBB_EDEVICE);
+    if (pred) HIP_TRY(hipMemcpyAsync(pred, h->io_pred.p, npix * sizeof(int32_t), hipMemcpyDeviceToHost, nullptr), UKBB_EDEVICE);
+    HIP_TRY(hipStreamSynchronize(nullptr), UKBB_EDEVICE);
+    return UKBB_OK;
+}
+
+int ukbb_fcn_num_kernels(const ukbb_fcn_handle *h) { return h ? (int)h->ops.size() : 0; }
+
+const char *ukbb_fcn_kernel_name(const ukbb_fcn_handle *h, int i) {
+    if (!h || i < 0 || i >= (int)h->ops.size()) return "";
+    return h->ops[i].name.c_str();
+}
+
+double ukbb_fcn_kernel_macs(const ukbb_fcn_handle *h, int i) {
+    if (!h || i < 0 || i >= (int)h->ops.size()) return 0.0;
+    return h->ops[i].macs_per_image * h->last_n;
+}
+
+int ukbb_fcn_set_timing(ukbb_fcn_handle *h, int enable) {
+    if (!h) { set_err("set_timing: NULL handle"); return UKBB_EINVAL; }
+    if (!enable && h->timing) { int rc = collect_events(h); if (rc) return rc; }
+    h->timing = enable != 0;
+    return UKBB_OK;
+}
+
+int ukbb_fcn_kernel_times(ukbb_fcn_handle *h, double *sum_ms, int64_t *count, int n, int reset) {
+    if (!h) { set_err("kernel_times: NULL handle"); return UKBB_EINVAL; }
+    int rc = collect_events(h);
+    if (rc) return rc;
+    const int m = std::min<int>(n, (int)h->ops.size());
+    for (int i = 0; i < m; ++i) {
+        if (sum_ms) sum_ms[i] = h->t_sum[i];
+        if (count) count[i] = h->t_cnt[i];
+    }
+    if (reset) { std::fill(h->t_sum.begin(), h->t_sum.end(), 0.0); std::fill(h->t_cnt.begin(), h->t_cnt.end(), 0); }
+    return m;
+}
+
+int64_t ukbb_fcn_get_activation(ukbb_fcn_handle *h, const char *name, float *dst, int64_t cap) {
+    if (!h || !name) { set_err("get_activation: NULL argument"); return UKBB_EINVAL; }
+    for (size_t i = 0; i < h->act.size(); ++i) {
+        if (h->act_name[i] != name) continue;
+        const int64_t n = (int64_t)h->act_per_image[i] * h->last_n;
+        if (!dst) return n;
+        if (cap < n) { set_err("get_activation: buffer too small (%lld < %lld)", (long long)cap, (long long)n); return UKBB_EINVAL; }
+        if (hipSetDevice(h->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+            hipMemcpy(dst, h->act[i]->p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
+            set_err("get_activation: device copy failed");
+            return UKBB_EDEVICE;
+        }
+        return n;
+    }
+    set_err("get_activation: no activation named '%s'", name);
+    return UKBB_EINVAL;
+}
+
+}  // extern "C"

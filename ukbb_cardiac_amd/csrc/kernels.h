@@ -1,0 +1,111 @@
+// Internal interface between the engine (engine.cpp) and the gfx950 kernels.
+// Not part of the public ABI (that is include/ukbb_fcn.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ukbb {
+
+// ---------------------------------------------------------------------------
+// Generic implicit-GEMM convolution (3x3 or 1x1, stride 1 or 2) + bias + ReLU
+// on the f32 MFMA pipes.  NHWC activations, weights pre-packed in MFMA
+// A-fragment order by pack_conv_weights().
+// ---------------------------------------------------------------------------
+struct ConvArgs {
+    const float *in0;   // first source  [N,H,W,C0]
+    const float *in1;   // optional second source [N,H,W,C1] (U-Net skip concat, network_ao.py:51)
+    int C0, C1;
+    const float *wpk;   // packed A fragments
+    const float *bias;  // [Cout] folded BN shift (or conv bias)
+    float *out;         // [N,Ho,Wo,Cout]
+    int N, H, W;        // input spatial size
+    int Ho, Wo, Cout;
+    int pad_y, pad_x;   // TF 'SAME' pad_before (oracle/fcn_oracle.py same_pads)
+    int tiles_y, tiles_x;
+    int relu;
+};
+
+// One compiled tiling of the conv kernel.
+struct ConvConfig {
+    int id;
+    int ks, stride;     // kernel size (1|3), stride (1|2)
+    int mb;             // MFMA M block: 16 -> v_mfma_f32_16x16x4_f32, 32 -> v_mfma_f32_32x32x2_f32
+    int th, tw;         // output tile per workgroup
+    int kc;             // input channels staged in LDS per pass
+    int wm, wn, cb;     // waves along Cout / along pixels; Cout blocks per wave
+    int lds_bytes;
+    const char *name;
+};
+
+int num_conv_configs();
+const ConvConfig &conv_config(int id);
+// cout handled by one workgroup = mb*cb*wm
+hipError_t launch_conv(int cfg_id, const ConvArgs &a, hipStream_t s);
+
+// Host-side: pack folded weights W[ks][ks][Cin][Cout] into A-fragment order
+// for tiling (mb, kc).  Returns floats written (= ks*ks*Cin*Cout).
+size_t pack_conv_weights(const float *w, int ks, int cin, int cout, int mb, int kc, float *dst);
+
+// ---------------------------------------------------------------------------
+// First layer: conv3x3, C_in = 1 (network.py:186 with l = 0), direct stencil.
+// ---------------------------------------------------------------------------
+struct FirstArgs {
+    const float *in;    // [N,H,W,1]
+    const float *w;     // [9][Cout] folded
+    const float *bias;  // [Cout]
+    float *out;         // [N,H,W,Cout]
+    int N, H, W, Cout;
+};
+hipError_t launch_first(const FirstArgs &a, hipStream_t s);
+
+// ---------------------------------------------------------------------------
+// Fused FCN head (network.py:201-229 + train_network.py:198-199):
+// same_dim0 1x1 -> [gather-upsample of sq1..sq4] -> out0 -> out1 -> logits
+// -> softmax / argmax.  The 160-channel concat is never materialised.
+// ---------------------------------------------------------------------------
+struct HeadArgs {
+    const float *conv0;      // [N,H,W,16] level-0 features
+    const float *sq[4];      // squeezed maps of levels 1..4: [N,H>>l,W>>l,32]
+    const float *w_s0;       // packed A frags same_dim0   (16 -> 32)
+    const float *b_s0;       // [32]
+    const float *w_o0;       // packed A frags out0        (160 -> 64)
+    const float *b_o0;       // [64]
+    const float *w_o1;       // packed A frags out1        (64 -> 64)
+    const float *b_o1;       // [64]
+    const float *w_lg;       // packed logits weights [2][n_class][32]
+    const float *b_lg;       // [n_class]
+    float *logits;           // optional [N,H,W,n_class]
+    float *prob;             // optional
+    int32_t *pred;           // optional [N,H,W]
+    int N, H, W, n_class;
+};
+hipError_t launch_head(const HeadArgs &a, hipStream_t s);
+// packers for the head's weights (see kernels_head.hip for the k-order)
+void pack_head_s0(const float *w /*[16][32] folded*/, float *dst /*64*8*/);
+void pack_head_o0(const float *w /*[160][64] folded*/, float *dst /*5*2*16*64*/);
+void pack_head_o1(const float *w /*[64][64] folded*/, float *dst /*2*2*16*64*/);
+void pack_head_lg(const float *w /*[64][n_class]*/, int n_class, float *dst /*2*n_class*32*/);
+
+// ---------------------------------------------------------------------------
+// U-Net pieces (network_ao.py:48-63)
+// ---------------------------------------------------------------------------
+struct TconvArgs {          // conv2d_transpose 3x3 stride 2 'SAME' + bias + ReLU
+    const float *in;        // [N,h,w,Cin]
+    const float *wpk;       // packed per phase
+    const float *bias;
+    float *out;             // [N,2h,2w,Cout]
+    int N, h, w, Cin, Cout;
+};
+hipError_t launch_tconv(const TconvArgs &a, hipStream_t s);
+size_t pack_tconv_weights(const float *w /*[3][3][Cout][Cin] folded*/, int cin, int cout, float *dst);
+
+struct LogitsArgs {         // 1x1 conv C -> n_class + bias, softmax / argmax (network_ao.py:63,159-160)
+    const float *in;        // [N,H,W,C]
+    const float *w;         // [C][n_class]
+    const float *bias;
+    float *logits; float *prob; int32_t *pred;
+    int64_t npix; int C, n_class;
+};
+hipError_t launch_logits(const LogitsArgs &a, hipStream_t s);
+
+}  // namespace ukbb

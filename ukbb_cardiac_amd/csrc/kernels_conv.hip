@@ -1,0 +1,324 @@
+// conv3x3 / conv1x1 (+ folded BN bias, ReLU) as implicit GEMM on the gfx950
+// f32 MFMA pipes.  Replaces the TF ops behind conv2d_bn_relu
+// (reference common/network.py:19-25) in inference mode.
+//
+// GEMM view (per image):  D[cout][pixel] = sum_{tap,ci} W'[tap][ci][cout] * X[pixel+tap][ci]
+//   MFMA A operand = weights  (M = output channels)
+//   MFMA B operand = pixels   (N = output pixels)   -> the accumulator holds,
+//   per lane, 4 consecutive output channels of ONE pixel: NHWC float4 stores.
+//
+// Data movement per workgroup (256 threads = 4 waves):
+//   * the input halo tile of KC channels is staged once into LDS in PLANAR
+//     form lds[ci][halo pixel] (transposed on the fly from NHWC float4 loads);
+//     every one of the 9 taps then re-reads it with plain ds_read_b32 whose
+//     address is lane_base + compile-time immediate (tap shift, channel plane),
+//     conflict-free because the 16/32 pixel lanes of a fragment are adjacent.
+//   * weights are pre-packed on the host in A-fragment order, so a lane reads
+//     its KC/KK k-steps of one tap as one 16/32-byte global load (L1/L2 hits:
+//     every workgroup of a layer streams the same few KB).
+// The f32 MFMA rate equals the vector rate (64 FLOP/clk/SIMD) and one
+// 32x32x2 issue takes 64 cycles, so one LDS read + 1/8 global load per MFMA
+// leaves the matrix pipe as the only bound; there is nothing to gain from
+// wider LDS reads here (MI355X_MICROARCH.md, "Matrix cores").
+#include "kernels.h"
+
+namespace ukbb {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int MB> struct Mfma;
+template <> struct Mfma<32> {
+    using Acc = f32x16;
+    static constexpr int KK = 2;    // k per instruction
+    static constexpr int NACC = 16;
+    static __device__ __forceinline__ Acc run(float a, float b, Acc c) {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mfma<16> {
+    using Acc = f32x4;
+    static constexpr int KK = 4;
+    static constexpr int NACC = 4;
+    static __device__ __forceinline__ Acc run(float a, float b, Acc c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+};
+
+__host__ __device__ constexpr int plane_pad(int hp) {
+    // plane stride == 2 (mod 8): the 4 transposing ds_write_b32 of a staging
+    // float4 then land on distinct bank octets (at worst a free 2-way conflict).
+    int p = hp;
+    while ((p & 7) != 2) ++p;
+    return p;
+}
+
+template <int N> struct VecLoad;
+template <> struct VecLoad<2> {
+    static __device__ __forceinline__ void ld(const float *p, float *d) {
+        float2 v = *reinterpret_cast<const float2 *>(p); d[0] = v.x; d[1] = v.y; }
+};
+template <> struct VecLoad<4> {
+    static __device__ __forceinline__ void ld(const float *p, float *d) {
+        float4 v = *reinterpret_cast<const float4 *>(p); d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
+};
+template <> struct VecLoad<8> {
+    static __device__ __forceinline__ void ld(const float *p, float *d) {
+        VecLoad<4>::ld(p, d); VecLoad<4>::ld(p + 4, d + 4); }
+};
+
+template <int KS, int STRIDE, int MB, int TH, int TW, int KC, int WM, int WN, int CB>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
+    using M = Mfma<MB>;
+    using Acc = typename M::Acc;
+    constexpr int KK = M::KK, KSTEPS = KC / KK, PB = MB;
+    constexpr int NPIX = TH * TW, NPB = (NPIX + PB - 1) / PB, PBW = (NPB + WN - 1) / WN;
+    constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
+    constexpr int HP = IH * IW, PLANE = plane_pad(HP), C4 = KC / 4, KS2 = KS * KS;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(KC % 4 == 0 && KC % KK == 0, "KC");
+
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [KC][PLANE]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int g = lane / PB, pl = lane % PB;
+
+    int bid = blockIdx.x;
+    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y;
+    const int n = bid / a.tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int cbg = blockIdx.y * (WM * CB) + wm * CB;     // first Cout block of this wave
+
+    int lbase[PBW];
+#pragma unroll
+    for (int pb = 0; pb < PBW; ++pb) {
+        int q = (wn + pb * WN) * PB + pl;
+        if (q >= NPIX) q = 0;
+        const int oy = q / TW, ox = q % TW;
+        lbase[pb] = g * PLANE + (oy * STRIDE) * IW + ox * STRIDE;
+    }
+
+    Acc acc[CB][PBW];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int pb = 0; pb < PBW; ++pb)
+#pragma unroll
+            for (int r = 0; r < M::NACC; ++r) acc[cb][pb][r] = 0.f;
+
+    const int nchunk = (a.C0 + a.C1) / KC;
+    const int iy0 = oy0 * STRIDE - a.pad_y, ix0 = ox0 * STRIDE - a.pad_x;
+
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const float *src; int cs, coff;
+        if (ch * KC < a.C0) { src = a.in0; cs = a.C0; coff = ch * KC; }
+        else                { src = a.in1; cs = a.C1; coff = ch * KC - a.C0; }
+        if (ch > 0) __syncthreads();
+        // ---- stage halo tile: NHWC global -> planar LDS ----------------------
+        for (int idx = tid; idx < HP * C4; idx += 256) {
+            const int pix = idx / C4, c4 = idx % C4;
+            const int iy = pix / IW, ix = pix % IW;
+            const int gy = iy0 + iy, gx = ix0 + ix;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
+                v = *reinterpret_cast<const float4 *>(
+                    src + ((size_t)(n * a.H + gy) * a.W + gx) * cs + coff + 4 * c4);
+            float *d = lds + (4 * c4) * PLANE + pix;
+            d[0] = v.x; d[PLANE] = v.y; d[2 * PLANE] = v.z; d[3 * PLANE] = v.w;
+        }
+        __syncthreads();
+        // ---- MFMA over the taps ---------------------------------------------
+        // kh is a real loop (keeps the live A fragments to one kernel row),
+        // kw / k-steps / pixel blocks are unrolled so every LDS address is
+        // lane_base + kh*IW + immediate.
+#pragma unroll 1
+        for (int kh = 0; kh < KS; ++kh) {
+            const float *wrow = a.wpk + ((((size_t)cbg * nchunk + ch) * KS2 + kh * KS) * 64 + lane) * KSTEPS;
+            const float *lrow = lds + kh * IW;
+#pragma unroll
+            for (int kw = 0; kw < KS; ++kw) {
+                float av[CB][KSTEPS];
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb)
+                    VecLoad<KSTEPS>::ld(wrow + ((size_t)cb * nchunk * KS2 + kw) * 64 * KSTEPS, av[cb]);
+#pragma unroll
+                for (int s = 0; s < KSTEPS; ++s) {
+#pragma unroll
+                    for (int pb = 0; pb < PBW; ++pb) {
+                        const float b = lrow[lbase[pb] + kw + s * KK * PLANE];
+#pragma unroll
+                        for (int cb = 0; cb < CB; ++cb) acc[cb][pb] = M::run(av[cb][s], b, acc[cb][pb]);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: + bias, ReLU, NHWC float4 stores -----------------------------
+    constexpr int NJ = M::NACC / 4;              // float4 groups per accumulator (4 or 1)
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        const int co0 = (cbg + cb) * MB + 4 * g;  // MB=32: + 8j ; MB=16: NJ = 1
+        float4 bi[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bi[j] = *reinterpret_cast<const float4 *>(a.bias + co0 + 8 * j);
+#pragma unroll
+        for (int pb = 0; pb < PBW; ++pb) {
+            const int q = (wn + pb * WN) * PB + pl;
+            const int oy = oy0 + q / TW, ox = ox0 + q % TW;
+            if (q < NPIX && oy < a.Ho && ox < a.Wo) {
+                float *o = a.out + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.Cout + co0;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    float4 v;
+                    v.x = acc[cb][pb][4 * j + 0] + bi[j].x;
+                    v.y = acc[cb][pb][4 * j + 1] + bi[j].y;
+                    v.z = acc[cb][pb][4 * j + 2] + bi[j].z;
+                    v.w = acc[cb][pb][4 * j + 3] + bi[j].w;
+                    if (a.relu) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+                        v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                    *reinterpret_cast<float4 *>(o + 8 * j) = v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Compiled tilings.  X(id, KS, STRIDE, MB, TH, TW, KC, WM, WN, CB)
+// ---------------------------------------------------------------------------
+#define UKBB_CONV_CONFIGS(X)                         \
+    /* 3x3 stride 1 */                               \
+    X(0, 3, 1, 16, 16, 52, 16, 1, 4, 1)              \
+    X(1, 3, 1, 16, 8, 26, 16, 2, 2, 1)               \
+    X(2, 3, 1, 32, 24, 26, 16, 1, 4, 1)              \
+    X(3, 3, 1, 16, 12, 26, 16, 2, 2, 1)              \
+    X(4, 3, 1, 32, 12, 26, 16, 2, 2, 1)              \
+    X(5, 3, 1, 16, 12, 13, 16, 2, 2, 1)              \
+    X(6, 3, 1, 16, 12, 13, 16, 4, 1, 1)              \
+    X(7, 3, 1, 16, 16, 16, 16, 1, 4, 1)              \
+    X(8, 3, 1, 16, 16, 16, 16, 2, 2, 1)              \
+    X(9, 3, 1, 32, 16, 16, 16, 2, 2, 1)              \
+    /* 3x3 stride 2 */                               \
+    X(20, 3, 2, 16, 8, 26, 16, 2, 2, 1)              \
+    X(21, 3, 2, 16, 12, 26, 8, 2, 2, 1)              \
+    X(22, 3, 2, 32, 12, 26, 8, 2, 2, 1)              \
+    X(23, 3, 2, 16, 12, 13, 16, 2, 2, 1)             \
+    X(24, 3, 2, 16, 12, 13, 16, 4, 1, 1)             \
+    X(25, 3, 2, 16, 8, 16, 16, 2, 2, 1)              \
+    /* 1x1 */                                        \
+    X(40, 1, 1, 16, 8, 52, 16, 2, 2, 1)              \
+    X(41, 1, 1, 16, 12, 26, 16, 2, 2, 1)             \
+    X(42, 1, 1, 16, 12, 13, 16, 2, 2, 1)             \
+    X(43, 1, 1, 16, 16, 16, 16, 2, 2, 1)
+
+#define UKBB_CFG_ENTRY(ID, KS, S, MB, TH, TW, KC, WM, WN, CB)                                   \
+    {ID, KS, S, MB, TH, TW, KC, WM, WN, CB,                                                     \
+     KC * plane_pad(((TH - 1) * S + KS) * ((TW - 1) * S + KS)) * 4,                             \
+     "conv" #KS "x" #KS "s" #S "_mb" #MB "_t" #TH "x" #TW "_kc" #KC "_w" #WM "x" #WN "_cb" #CB},
+
+static const ConvConfig g_cfgs[] = {UKBB_CONV_CONFIGS(UKBB_CFG_ENTRY)};
+
+int num_conv_configs() { return (int)(sizeof(g_cfgs) / sizeof(g_cfgs[0])); }
+const ConvConfig &conv_config(int i) { return g_cfgs[i]; }
+
+hipError_t launch_conv(int cfg_id, const ConvArgs &a, hipStream_t s) {
+    const ConvConfig *c = nullptr;
+    for (const auto &e : g_cfgs) if (e.id == cfg_id) c = &e;
+    if (!c) return hipErrorInvalidValue;
+    const int group = c->mb * c->cb * c->wm;
+    if (a.Cout % group || (a.C0 + a.C1) % c->kc || a.C0 % c->kc) return hipErrorInvalidValue;
+    dim3 grid((unsigned)(a.N * a.tiles_y * a.tiles_x), (unsigned)(a.Cout / group), 1);
+    switch (cfg_id) {
+#define UKBB_CFG_CASE(ID, KS, S, MB, TH, TW, KC, WM, WN, CB)                                    \
+    case ID: {                                                                                  \
+        auto k = conv_mfma_kernel<KS, S, MB, TH, TW, KC, WM, WN, CB>;                           \
+        static bool attr_done = false;                                                          \
+        if (!attr_done) {                                                                       \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),               \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                               c->lds_bytes);                                   \
+            if (e != hipSuccess) return e;                                                      \
+            attr_done = true;                                                                   \
+        }                                                                                       \
+        hipLaunchKernelGGL(k, grid, dim3(256), c->lds_bytes, s, a);                             \
+        break;                                                                                  \
+    }
+        UKBB_CONV_CONFIGS(UKBB_CFG_CASE)
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+size_t pack_conv_weights(const float *w, int ks, int cin, int cout, int mb, int kc, float *dst) {
+    // dst[cb][chunk][tap][lane][s] = W[tap][ci][co]
+    //   mb = 32: lane = (g<<5)|m, ci = chunk*kc + 2*s + g, co = cb*32 + m
+    //   mb = 16: lane = (g<<4)|m, ci = chunk*kc + 4*s + g, co = cb*16 + m
+    const int kk = (mb == 32) ? 2 : 4, ksteps = kc / kk, ks2 = ks * ks, nchunk = cin / kc;
+    size_t o = 0;
+    for (int cb = 0; cb < cout / mb; ++cb)
+        for (int ch = 0; ch < nchunk; ++ch)
+            for (int tap = 0; tap < ks2; ++tap)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int m = lane % mb, g = lane / mb;
+                    for (int s = 0; s < ksteps; ++s) {
+                        const int ci = ch * kc + kk * s + g, co = cb * mb + m;
+                        dst[o++] = w[((size_t)tap * cin + ci) * cout + co];
+                    }
+                }
+    return o;
+}
+
+// ---------------------------------------------------------------------------
+// First layer (C_in = 1): direct 3x3 stencil on the vector ALU.  K = 9 is too
+// thin for the matrix pipe and the layer is 0.4 % of the MACs.
+// One thread = one pixel x all Cout; weights broadcast from LDS.
+// ---------------------------------------------------------------------------
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_first_kernel(const FirstArgs a) {
+    __shared__ float wl[9 * COUT + COUT];
+    for (int i = threadIdx.x; i < 9 * COUT; i += 256) wl[i] = a.w[i];
+    for (int i = threadIdx.x; i < COUT; i += 256) wl[9 * COUT + i] = a.bias[i];
+    __syncthreads();
+    const size_t total = (size_t)a.N * a.H * a.W;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (size_t)gridDim.x * 256) {
+        const int x = (int)(q % a.W);
+        const int y = (int)((q / a.W) % a.H);
+        const float *img = a.in + (q - (size_t)y * a.W - x);
+        float v[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            v[t] = ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W) ? img[(size_t)yy * a.W + xx] : 0.f;
+        }
+        float *o = a.out + q * COUT;
+#pragma unroll
+        for (int c = 0; c < COUT; c += 4) {
+            float4 r;
+            float *rp = &r.x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) s = fmaf(v[t], wl[t * COUT + c + j], s);
+                rp[j] = fmaxf(s + wl[9 * COUT + c + j], 0.f);
+            }
+            *reinterpret_cast<float4 *>(o + c) = r;
+        }
+    }
+}
+
+hipError_t launch_first(const FirstArgs &a, hipStream_t s) {
+    const size_t total = (size_t)a.N * a.H * a.W;
+    unsigned grid = (unsigned)((total + 255) / 256);
+    if (grid > 256u * 16u) grid = 256u * 16u;
+    if (a.Cout == 16) hipLaunchKernelGGL(conv_first_kernel<16>, dim3(grid), dim3(256), 0, s, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+}  // namespace ukbb
