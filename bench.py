@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Headline benchmark: short-axis FCN inference, batch = 64 synthetic 192x208
+slices per GPU, fp32 (BASELINE.json configs[1]).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one forward of the hot path over one batch of 64 slices already
+resident in HBM, label map (int32) left in HBM.  One process per GPU, batch
+split only, no data-path collective (weak scaling); the process group is used
+for the barrier and the max-over-ranks time only.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+BATCH, H, W = 64, 192, 208
+
+
+def cpu_baseline(arch, params, target_seconds=12.0):
+    """C restatement of the reference graph (oracle/fcn_oracle.c, OpenMP) timed
+    on this host's cores on a bounded sample of the same workload."""
+    import numpy as np
+    from oracle import c_oracle
+    from ukbb_cardiac_amd.phantom import uniform_slices
+    from ukbb_cardiac_amd.weights import pack_flat
+    flat = pack_flat(arch, params)
+    img = uniform_slices(8, H, W, seed=1)
+    c_oracle.forward(arch, flat, img[:1], want_logits=False)           # warm-up / page-in
+    t0 = time.perf_counter()
+    c_oracle.forward(arch, flat, img[:2], want_logits=False)
+    per = (time.perf_counter() - t0) / 2
+    chunks = int(max(1, min(32, round(target_seconds / (per * 8)))))
+    t0 = time.perf_counter()
+    for _ in range(chunks):
+        c_oracle.forward(arch, flat, img, want_logits=False)
+    dt = time.perf_counter() - t0
+    n = 8 * chunks
+    return {'value': n / dt, 'unit': 'slices/s', 'cores': c_oracle.num_threads(), 'kind': 'port',
+            'sample': '%d slices of %dx%d (batches of 8) through oracle/fcn_oracle.c (fp32, OpenMP, unfused '
+                      'restatement of common/network.py build_FCN; TensorFlow itself is not installable here), '
+                      '%.1f s' % (n, H, W, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=BATCH)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-events', action='store_true',
+                    help='do not bracket kernels with HIP events in the timed region (roofline becomes null)')
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus != world:
+        if args.gpus > 1:
+            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d '
+                     '(WORLD_SIZE is %d)' % (args.gpus, args.gpus, world))
+    if not torch.cuda.is_available():
+        sys.exit('bench.py needs a GPU: the HIP path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from ukbb_cardiac_amd.arch import MODELS, fcn_macs_per_slice
+    from ukbb_cardiac_amd.engine import Engine
+    from ukbb_cardiac_amd.phantom import uniform_slices
+    from ukbb_cardiac_amd.weights import synthetic_params
+
+    arch = MODELS['FCN_sa']
+    params = synthetic_params(arch, 1234)
+    eng = Engine(arch, params, device=local_rank)
+    n = args.batch
+    x = torch.from_numpy(uniform_slices(n, H, W, seed=1 + rank)).to(dev)
+    pred = torch.empty((n, H, W), dtype=torch.int32, device=dev)
+    eng.reserve(n, H, W)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        eng.run_device(x.data_ptr(), n, H, W, pred_ptr=pred.data_ptr(), stream=stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    use_events = not args.no_kernel_events
+    if use_events:
+        eng.set_timing(True)
+        eng.kernel_times(reset=True)
+
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed_max = float(t.item())
+
+    m3, m1 = fcn_macs_per_slice(arch, H, W)
+    roofline = None
+    detail = None
+    if use_events:
+        ms, cnt = eng.kernel_times(reset=True)
+        eng.set_timing(False)
+        names, macs = eng.kernel_names(), eng.kernel_macs()
+        avg = [m / max(c, 1) for m, c in zip(ms, cnt)]
+        dom = max(range(len(avg)), key=lambda i: avg[i])
+        tf = lambda mac, t_ms: 2.0 * mac / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0
+        ach = tf(macs[dom], avg[dom])
+        roofline = {'bound': 'mfma', 'kernel': names[dom], 'achieved': round(ach, 2),
+                    'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                    'traffic': None, 'avg_launch_us': round(avg[dom] * 1e3, 2),
+                    'algorithmic_flop_per_launch': 2.0 * macs[dom]}
+        is3 = [nm.startswith('conv') and nm != 'conv0_0' for nm in names]
+        t3 = sum(a for a, f in zip(avg, is3) if f)
+        mac3 = sum(m for m, f in zip(macs, is3) if f)
+        tall = sum(avg)
+        detail = {
+            'conv3x3_mfma_stack': {'tflops': round(tf(mac3, t3), 2), 'frac': round(tf(mac3, t3) / PEAK_FP32_MFMA_TFLOPS, 4),
+                                   'us_per_step': round(t3 * 1e3, 1)},
+            'all_kernels': {'tflops': round(tf(sum(macs), tall), 2),
+                            'frac': round(tf(sum(macs), tall) / PEAK_FP32_MFMA_TFLOPS, 4), 'us_per_step': round(tall * 1e3, 1)},
+            'per_kernel_us': {nm: round(a * 1e3, 1) for nm, a in zip(names, avg)},
+            'per_kernel_frac': {nm: round(tf(m, a) / PEAK_FP32_MFMA_TFLOPS, 3) for nm, m, a in zip(names, macs, avg)},
+        }
+
+    if rank == 0:
+        slices = world * n * args.steps
+        value = slices / elapsed_max
+        flops_per_slice = 2.0 * (m3 + m1)
+        out = {
+            'metric': '192x208 SAX slices/sec', 'value': round(value, 1), 'unit': 'slices/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed_max / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'short-axis FCN (FCN_sa, 4 classes) inference, batch=%d synthetic 192x208 slices '
+                                   'per GPU resident in HBM, int32 label map out (BASELINE.json configs[1])' % n,
+                       'slices_per_gpu_per_step': n, 'height': H, 'width': W, 'weights': 'synthetic seed 1234',
+                       'parallelism': 'batch split x%d, no collectives' % world},
+            'e2e_tflops_algorithmic': round(value * flops_per_slice / 1e12, 2),
+            'e2e_frac_of_fp32_mfma_peak': round(value * flops_per_slice / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world), 4),
+            'roofline': roofline,
+        }
+        if detail:
+            out['roofline_detail'] = detail
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(arch, params)
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
