@@ -253,10 +253,10 @@ int new_act(ukbb_fcn_handle *h, const std::string &name, size_t per_image) {
 int ensure_packed(ukbb_fcn_handle *h, int layer, const ConvConfig &c, const float **wpk) {
     const HostLayer &L = h->layers[layer];
     char key[128];
-    snprintf(key, sizeof key, "%s/pk_mb%d_kc%d", L.name.c_str(), c.mb, c.kc);
+    snprintf(key, sizeof key, "%s/pk_mb%d_kc%d_g%d", L.name.c_str(), c.mb, c.kc, c.wm * c.cb);
     if (!dev_ptr(h, key)) {
         std::vector<float> pk(L.w.size());
-        pack_conv_weights(L.w.data(), L.ks, L.cin, L.cout, c.mb, c.kc, pk.data());
+        pack_conv_weights(L.w.data(), L.ks, L.cin, L.cout, c.mb, c.kc, c.wm * c.cb, pk.data());
         int rc = upload(h, key, pk);
         if (rc) return rc;
     }

@@ -43,8 +43,8 @@ const ConvConfig &conv_config(int id);
 hipError_t launch_conv(int cfg_id, const ConvArgs &a, hipStream_t s);
 
 // Host-side: pack folded weights W[ks][ks][Cin][Cout] into A-fragment order
-// for tiling (mb, kc).  Returns floats written (= ks*ks*Cin*Cout).
-size_t pack_conv_weights(const float *w, int ks, int cin, int cout, int mb, int kc, float *dst);
+// for tiling (mb, kc) and workgroups of ncbl = wm*cb Cout blocks.  Returns floats written.
+size_t pack_conv_weights(const float *w, int ks, int cin, int cout, int mb, int kc, int ncbl, float *dst);
 
 // ---------------------------------------------------------------------------
 // First layer: conv3x3, C_in = 1 (network.py:186 with l = 0), direct stencil.

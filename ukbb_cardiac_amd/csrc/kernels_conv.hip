@@ -53,6 +53,23 @@ __host__ __device__ constexpr int plane_pad(int hp) {
     return p;
 }
 
+__host__ __device__ constexpr int conv_lds_bytes(int ks, int s, int mb, int th, int tw, int kc, int wm, int cb) {
+    const int xs = kc * plane_pad(((th - 1) * s + ks) * ((tw - 1) * s + ks));
+    const int xs_al = xs + ((4 - xs % 4) % 4);
+    return (xs_al + wm * cb * ks * ks * 64 * (kc / (mb == 32 ? 2 : 4))) * 4;
+}
+
+__host__ __device__ constexpr int conv_min_waves(int ks, int s, int mb, int th, int tw, int kc, int wm, int wn, int cb) {
+    // Waves per SIMD to ask of the register allocator: 2 (two resident workgroups per CU)
+    // unless the accumulators + staging registers clearly do not fit 256 VGPRs.
+    const int pb = mb, npb = (th * tw + pb - 1) / pb, pbw = (npb + wn - 1) / wn;
+    const int hp = ((th - 1) * s + ks) * ((tw - 1) * s + ks), c4 = kc / 4;
+    const int nit = (hp * c4 + 255) / 256;
+    const int nwt = (wm * cb * ks * ks * 64 * (kc / (mb == 32 ? 2 : 4)) / 4 + 255) / 256;
+    const int est = cb * pbw * (mb == 32 ? 16 : 4) + 4 * (nit + nwt) + pbw + nit + 2 * pbw + 48;
+    return est <= 170 ? 2 : 1;
+}
+
 template <int N> struct VecLoad;
 template <> struct VecLoad<2> {
     static __device__ __forceinline__ void ld(const float *p, float *d) {
@@ -68,17 +85,26 @@ template <> struct VecLoad<8> {
 };
 
 template <int KS, int STRIDE, int MB, int TH, int TW, int KC, int WM, int WN, int CB>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM, WN, CB)) void conv_mfma_kernel(const ConvArgs a) {
     using M = Mfma<MB>;
     using Acc = typename M::Acc;
     constexpr int KK = M::KK, KSTEPS = KC / KK, PB = MB;
     constexpr int NPIX = TH * TW, NPB = (NPIX + PB - 1) / PB, PBW = (NPB + WN - 1) / WN;
     constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
     constexpr int HP = IH * IW, PLANE = plane_pad(HP), C4 = KC / 4, KS2 = KS * KS;
+    constexpr int NCBL = WM * CB;                       // Cout blocks per workgroup
+    constexpr int SLAB = KS2 * 64 * KSTEPS;             // packed weights of one Cout block, one chunk
+    constexpr int NIT = (HP * C4 + 255) / 256;          // activation float4 per thread per chunk
+    constexpr int WF4 = NCBL * SLAB / 4;                // weight float4 per workgroup per chunk
+    constexpr int NWT = (WF4 + 255) / 256;
+    constexpr int PSTEP = 256 / C4;                     // halo pixels advanced per staging iteration
     static_assert(WM * WN == 4, "4 waves per workgroup");
-    static_assert(KC % 4 == 0 && KC % KK == 0, "KC");
+    static_assert(KC % 4 == 0 && KC % KK == 0 && 256 % C4 == 0, "KC");
+    static_assert(KSTEPS == 2 || KSTEPS == 4 || KSTEPS == 8, "KSTEPS");
 
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // [KC][PLANE]
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *xs = lds;                                     // [KC][PLANE]   activations, planar
+    float *ws = lds + KC * PLANE + ((4 - (KC * PLANE) % 4) % 4);   // [NCBL][KS2][64][KSTEPS], 16-B aligned
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -89,7 +115,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     const int ty = bid % a.tiles_y;
     const int n = bid / a.tiles_y;
     const int oy0 = ty * TH, ox0 = tx * TW;
-    const int cbg = blockIdx.y * (WM * CB) + wm * CB;     // first Cout block of this wave
+    const int cbg = blockIdx.y * NCBL + wm * CB;         // first Cout block of this wave
 
     int lbase[PBW];
 #pragma unroll
@@ -110,39 +136,65 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 
     const int nchunk = (a.C0 + a.C1) / KC;
     const int iy0 = oy0 * STRIDE - a.pad_y, ix0 = ox0 * STRIDE - a.pad_x;
+    const int c4 = tid % C4, pix0 = tid / C4;           // this thread's channel quad / first halo pixel
+    const float *wsrc = a.wpk + (size_t)blockIdx.y * nchunk * (NCBL * SLAB);
 
+    // Per-iteration global offsets of this thread's halo pixels (chunk independent), -1 = zero padding.
+    int goff[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int pix = pix0 + it * PSTEP;
+        const int iy = pix / IW, ix = pix % IW;
+        const int gy = iy0 + iy, gx = ix0 + ix;
+        const bool ok = pix < HP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        goff[it] = ok ? ((n * a.H + gy) * a.W + gx) : -1;
+    }
+
+    f32x4 xr[NIT], wr[NWT];
+#define UKBB_PREFETCH(CH)                                                                          \
+    {                                                                                              \
+        const int ch_ = (CH);                                                                      \
+        const float *src_; int cs_;                                                                \
+        if (ch_ * KC < a.C0) { src_ = a.in0 + ch_ * KC; cs_ = a.C0; }                              \
+        else                 { src_ = a.in1 + (ch_ * KC - a.C0); cs_ = a.C1; }                     \
+        src_ += 4 * c4;                                                                            \
+        _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                       \
+            f32x4 v_ = {0.f, 0.f, 0.f, 0.f};                                                       \
+            if (goff[it] >= 0) v_ = *reinterpret_cast<const f32x4 *>(src_ + (size_t)goff[it] * cs_);  \
+            xr[it] = v_;                                                                           \
+        }                                                                                          \
+        const float *wp_ = wsrc + (size_t)ch_ * (NCBL * SLAB);                                     \
+        _Pragma("unroll") for (int it = 0; it < NWT; ++it)                                         \
+            wr[it] = *reinterpret_cast<const f32x4 *>((it * 256 + tid < WF4) ? wp_ + 4 * (it * 256 + tid) : a.wpk); \
+    }
+
+    UKBB_PREFETCH(0)
     for (int ch = 0; ch < nchunk; ++ch) {
-        const float *src; int cs, coff;
-        if (ch * KC < a.C0) { src = a.in0; cs = a.C0; coff = ch * KC; }
-        else                { src = a.in1; cs = a.C1; coff = ch * KC - a.C0; }
-        if (ch > 0) __syncthreads();
-        // ---- stage halo tile: NHWC global -> planar LDS ----------------------
-        for (int idx = tid; idx < HP * C4; idx += 256) {
-            const int pix = idx / C4, c4 = idx % C4;
-            const int iy = pix / IW, ix = pix % IW;
-            const int gy = iy0 + iy, gx = ix0 + ix;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
-                v = *reinterpret_cast<const float4 *>(
-                    src + ((size_t)(n * a.H + gy) * a.W + gx) * cs + coff + 4 * c4);
-            float *d = lds + (4 * c4) * PLANE + pix;
-            d[0] = v.x; d[PLANE] = v.y; d[2 * PLANE] = v.z; d[3 * PLANE] = v.w;
+        if (ch > 0) __syncthreads();                    // all waves done reading the previous chunk
+        // ---- registers -> LDS (activations transposed to planar, weights linear) ----
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int pix = pix0 + it * PSTEP;
+            if (pix < HP) {
+                float *d = xs + (4 * c4) * PLANE + pix;
+                d[0] = xr[it][0]; d[PLANE] = xr[it][1]; d[2 * PLANE] = xr[it][2]; d[3 * PLANE] = xr[it][3];
+            }
         }
+#pragma unroll
+        for (int it = 0; it < NWT; ++it)
+            if (it * 256 + tid < WF4) *reinterpret_cast<f32x4 *>(ws + it * 1024 + 4 * tid) = wr[it];
         __syncthreads();
-        // ---- MFMA over the taps ---------------------------------------------
-        // kh is a real loop (keeps the live A fragments to one kernel row),
-        // kw / k-steps / pixel blocks are unrolled so every LDS address is
-        // lane_base + kh*IW + immediate.
+        if (ch + 1 < nchunk) UKBB_PREFETCH(ch + 1)      // in flight during the MFMA phase below
+        // ---- MFMA over the taps: A and B both from LDS ---------------------------------
 #pragma unroll 1
         for (int kh = 0; kh < KS; ++kh) {
-            const float *wrow = a.wpk + ((((size_t)cbg * nchunk + ch) * KS2 + kh * KS) * 64 + lane) * KSTEPS;
-            const float *lrow = lds + kh * IW;
+            const float *wrow = ws + ((wm * CB) * KS2 + kh * KS) * 64 * KSTEPS + lane * KSTEPS;
+            const float *lrow = xs + kh * IW;
 #pragma unroll
             for (int kw = 0; kw < KS; ++kw) {
                 float av[CB][KSTEPS];
 #pragma unroll
-                for (int cb = 0; cb < CB; ++cb)
-                    VecLoad<KSTEPS>::ld(wrow + ((size_t)cb * nchunk * KS2 + kw) * 64 * KSTEPS, av[cb]);
+                for (int cb = 0; cb < CB; ++cb) VecLoad<KSTEPS>::ld(wrow + (cb * KS2 + kw) * 64 * KSTEPS, av[cb]);
 #pragma unroll
                 for (int s = 0; s < KSTEPS; ++s) {
 #pragma unroll
@@ -194,6 +246,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 #define UKBB_CONV_CONFIGS(X)                         \
     /* 3x3 stride 1 */                               \
     X(0, 3, 1, 16, 16, 52, 16, 1, 4, 1)              \
+    X(10, 3, 1, 16, 8, 52, 16, 1, 4, 1)              \
     X(1, 3, 1, 16, 8, 26, 16, 2, 2, 1)               \
     X(2, 3, 1, 32, 24, 26, 16, 1, 4, 1)              \
     X(3, 3, 1, 16, 12, 26, 16, 2, 2, 1)              \
@@ -218,7 +271,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 
 #define UKBB_CFG_ENTRY(ID, KS, S, MB, TH, TW, KC, WM, WN, CB)                                   \
     {ID, KS, S, MB, TH, TW, KC, WM, WN, CB,                                                     \
-     KC * plane_pad(((TH - 1) * S + KS) * ((TW - 1) * S + KS)) * 4,                             \
+     conv_lds_bytes(KS, S, MB, TH, TW, KC, WM, CB),                                             \
      "conv" #KS "x" #KS "s" #S "_mb" #MB "_t" #TH "x" #TW "_kc" #KC "_w" #WM "x" #WN "_cb" #CB},
 
 static const ConvConfig g_cfgs[] = {UKBB_CONV_CONFIGS(UKBB_CFG_ENTRY)};
@@ -254,22 +307,24 @@ hipError_t launch_conv(int cfg_id, const ConvArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
-size_t pack_conv_weights(const float *w, int ks, int cin, int cout, int mb, int kc, float *dst) {
-    // dst[cb][chunk][tap][lane][s] = W[tap][ci][co]
+size_t pack_conv_weights(const float *w, int ks, int cin, int cout, int mb, int kc, int ncbl, float *dst) {
+    // dst[group][chunk][cbl][tap][lane][s] = W[tap][ci][co],  cb = group*ncbl + cbl
     //   mb = 32: lane = (g<<5)|m, ci = chunk*kc + 2*s + g, co = cb*32 + m
     //   mb = 16: lane = (g<<4)|m, ci = chunk*kc + 4*s + g, co = cb*16 + m
+    // One workgroup (= one group of ncbl Cout blocks) reads, per chunk, one contiguous slab.
     const int kk = (mb == 32) ? 2 : 4, ksteps = kc / kk, ks2 = ks * ks, nchunk = cin / kc;
     size_t o = 0;
-    for (int cb = 0; cb < cout / mb; ++cb)
+    for (int grp = 0; grp < cout / (mb * ncbl); ++grp)
         for (int ch = 0; ch < nchunk; ++ch)
-            for (int tap = 0; tap < ks2; ++tap)
-                for (int lane = 0; lane < 64; ++lane) {
-                    const int m = lane % mb, g = lane / mb;
-                    for (int s = 0; s < ksteps; ++s) {
-                        const int ci = ch * kc + kk * s + g, co = cb * mb + m;
-                        dst[o++] = w[((size_t)tap * cin + ci) * cout + co];
+            for (int cbl = 0; cbl < ncbl; ++cbl)
+                for (int tap = 0; tap < ks2; ++tap)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int m = lane % mb, g = lane / mb;
+                        for (int s = 0; s < ksteps; ++s) {
+                            const int ci = ch * kc + kk * s + g, co = (grp * ncbl + cbl) * mb + m;
+                            dst[o++] = w[((size_t)tap * cin + ci) * cout + co];
+                        }
                     }
-                }
     return o;
 }
 
