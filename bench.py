@@ -100,12 +100,23 @@ def main():
         if world > 1:
             dist.barrier()
 
+    use_events = not args.no_kernel_events
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    use_events = not args.no_kernel_events
+    warm_avg = None
     if use_events:
+        # untimed survey pass with every kernel bracketed: finds the dominant kernel and
+        # fills roofline_detail; the timed region below brackets ONLY the dominant kernel
+        # (2 event records per step), which does not perturb it measurably.
         eng.set_timing(True)
+        eng.kernel_times(reset=True)
+        for _ in range(max(3, args.warmup)):
+            step()
+        ms, cnt = eng.kernel_times(reset=True)
+        warm_avg = [m / max(c, 1) for m, c in zip(ms, cnt)]
+        dom = max(range(len(warm_avg)), key=lambda i: warm_avg[i])
+        eng.set_timing_kernel(dom)
         eng.kernel_times(reset=True)
 
     barrier()
@@ -129,19 +140,20 @@ def main():
         ms, cnt = eng.kernel_times(reset=True)
         eng.set_timing(False)
         names, macs = eng.kernel_names(), eng.kernel_macs()
-        avg = [m / max(c, 1) for m, c in zip(ms, cnt)]
-        dom = max(range(len(avg)), key=lambda i: avg[i])
+        dom_avg = ms[dom] / max(cnt[dom], 1)          # measured inside the timed region
+        avg = list(warm_avg)
         tf = lambda mac, t_ms: 2.0 * mac / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0
-        ach = tf(macs[dom], avg[dom])
+        ach = tf(macs[dom], dom_avg)
         roofline = {'bound': 'mfma', 'kernel': names[dom], 'achieved': round(ach, 2),
                     'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-                    'traffic': None, 'avg_launch_us': round(avg[dom] * 1e3, 2),
+                    'traffic': None, 'avg_launch_us': round(dom_avg * 1e3, 2), 'launches_timed': int(cnt[dom]),
                     'algorithmic_flop_per_launch': 2.0 * macs[dom]}
         is3 = [nm.startswith('conv') and nm != 'conv0_0' for nm in names]
         t3 = sum(a for a, f in zip(avg, is3) if f)
         mac3 = sum(m for m, f in zip(macs, is3) if f)
         tall = sum(avg)
         detail = {
+            'note': 'per-kernel survey from an untimed pass with all kernels bracketed by HIP events',
             'conv3x3_mfma_stack': {'tflops': round(tf(mac3, t3), 2), 'frac': round(tf(mac3, t3) / PEAK_FP32_MFMA_TFLOPS, 4),
                                    'us_per_step': round(t3 * 1e3, 1)},
             'all_kernels': {'tflops': round(tf(sum(macs), tall), 2),

@@ -108,11 +108,20 @@ const char *ukbb_fcn_kernel_name(const ukbb_fcn_handle *h, int i);
 /* Algorithmic MACs kernel i performs for the LAST forward's shape. */
 double ukbb_fcn_kernel_macs(const ukbb_fcn_handle *h, int i);
 
+/* Tiling id the plan chose for kernel i (conv kernels; -1 for the others) and
+ * its descriptive name; used by tools/tune_convs.py.  The environment variable
+ * UKBB_CONV_CFG="layer:id,layer:id" overrides the choice at plan time. */
+int ukbb_fcn_kernel_config(const ukbb_fcn_handle *h, int i);
+const char *ukbb_fcn_conv_config_name(int id);
+
 /* When enabled, every launch of forward() is bracketed by hipEvents recorded
  * on the forward's own stream; ukbb_fcn_kernel_times() then synchronises and
  * returns, per kernel, the summed duration in ms and the number of timed
  * launches since the last reset. */
 int ukbb_fcn_set_timing(ukbb_fcn_handle *h, int enable);
+/* Time only kernel `kernel` (index in launch order; < 0 = all): two event records per
+ * forward instead of two per launch, so the timed region is not perturbed. */
+int ukbb_fcn_set_timing_kernel(ukbb_fcn_handle *h, int kernel);
 int ukbb_fcn_kernel_times(ukbb_fcn_handle *h, double *sum_ms, int64_t *count, int n, int reset);
 
 /* Copy an intermediate activation of the LAST forward to host (tests only).

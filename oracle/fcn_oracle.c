@@ -29,6 +29,38 @@
 #define BN_EPS 1e-3f
 #define MAXC 512
 
+/* Scratch buffers are recycled between calls: a forward touches ~100 MB per
+ * slice of intermediates, and mmap/munmap + first-touch page faults on every
+ * call would otherwise dominate the timing on many-core hosts (the
+ * cpu_baseline leg calls forward repeatedly).  Calls are serial. */
+#define POOL_N 64
+static struct { void *p; size_t n; int used; } g_pool[POOL_N];
+
+static void *oalloc(size_t bytes) {
+    int free_slot = -1, best = -1;
+    for (int i = 0; i < POOL_N; ++i) {
+        if (g_pool[i].p && !g_pool[i].used && g_pool[i].n >= bytes &&
+            (best < 0 || g_pool[i].n < g_pool[best].n)) best = i;
+        if (!g_pool[i].p && free_slot < 0) free_slot = i;
+    }
+    if (best >= 0 && g_pool[best].n <= bytes + bytes / 4 + 4096) { g_pool[best].used = 1; return g_pool[best].p; }
+    if (free_slot < 0) {                     /* pool full: drop an idle block */
+        for (int i = 0; i < POOL_N; ++i)
+            if (!g_pool[i].used) { free(g_pool[i].p); g_pool[i].p = 0; free_slot = i; break; }
+        if (free_slot < 0) return 0;
+    }
+    void *p = malloc(bytes);
+    if (!p) return 0;
+    g_pool[free_slot].p = p; g_pool[free_slot].n = bytes; g_pool[free_slot].used = 1;
+    return p;
+}
+
+static void ofree(const void *p) {
+    if (!p) return;
+    for (int i = 0; i < POOL_N; ++i)
+        if (g_pool[i].p == p) { g_pool[i].used = 0; return; }
+}
+
 static void same_pads(int n_in, int k, int s, int *n_out, int *before) {
     int o = (n_in + s - 1) / s;
     int tot = (o - 1) * s + k - n_in;
@@ -200,43 +232,43 @@ int oracle_fcn_forward(const oracle_arch *a, const float *weights, const float *
         for (int i = 0; i < a->n_block[l]; ++i) {
             const int stride = (l > 0 && i == 0) ? 2 : 1;
             const int ho = (h + stride - 1) / stride, wo = (w + stride - 1) / stride;
-            float *out = (float *)malloc(sizeof(float) * (size_t)N * ho * wo * a->n_filter[l]);
+            float *out = (float *)oalloc(sizeof(float) * (size_t)N * ho * wo * a->n_filter[l]);
             if (!out) return -1;
             unit(x, N, h, w, cin, 3, stride, a->n_filter[l], &wp, out);
-            if (i > 0) free((void *)x);          /* level outputs (i == 0 inputs) are kept */
+            if (i > 0) ofree(x);          /* level outputs (i == 0 inputs) are kept */
             x = out; cin = a->n_filter[l]; h = ho; w = wo;
         }
         feat[l] = (float *)x; fh[l] = h; fw[l] = w;
     }
     const int SD = a->same_dim, CT = SD * L;
-    float *concat = (float *)malloc(sizeof(float) * (size_t)N * H * W * CT);
+    float *concat = (float *)oalloc(sizeof(float) * (size_t)N * H * W * CT);
     if (!concat) return -1;
     for (int l = 0; l < L; ++l) {
-        float *sq = (float *)malloc(sizeof(float) * (size_t)N * fh[l] * fw[l] * SD);
+        float *sq = (float *)oalloc(sizeof(float) * (size_t)N * fh[l] * fw[l] * SD);
         if (!sq) return -1;
         unit(feat[l], N, fh[l], fw[l], a->n_filter[l], 1, 1, SD, &wp, sq);
         if (l == 0) copy_channels(sq, (size_t)N * H * W, SD, concat, CT, 0);
         else upsample_bilinear(sq, N, fh[l], fw[l], SD, 1 << l, concat, CT, SD * l);
-        free(sq);
-        free(feat[l]);
+        ofree(sq);
+        ofree(feat[l]);
     }
-    float *o0 = (float *)malloc(sizeof(float) * (size_t)N * H * W * a->fc);
-    float *o1 = (float *)malloc(sizeof(float) * (size_t)N * H * W * a->fc);
-    float *lg = logits_out ? logits_out : (float *)malloc(sizeof(float) * (size_t)N * H * W * a->n_class);
+    float *o0 = (float *)oalloc(sizeof(float) * (size_t)N * H * W * a->fc);
+    float *o1 = (float *)oalloc(sizeof(float) * (size_t)N * H * W * a->fc);
+    float *lg = logits_out ? logits_out : (float *)oalloc(sizeof(float) * (size_t)N * H * W * a->n_class);
     if (!o0 || !o1 || !lg) return -1;
     unit(concat, N, H, W, CT, 1, 1, a->fc, &wp, o0);
-    free(concat);
+    ofree(concat);
     unit(o0, N, H, W, a->fc, 1, 1, a->fc, &wp, o1);
-    free(o0);
+    ofree(o0);
     conv2d_same(o1, N, H, W, a->fc, wp, 1, 1, a->n_class, lg);
     const float *bias = wp + (size_t)a->fc * a->n_class;
     const size_t npix = (size_t)N * H * W;
 #pragma omp parallel for schedule(static)
     for (size_t i = 0; i < npix; ++i)
         for (int c = 0; c < a->n_class; ++c) lg[i * a->n_class + c] += bias[c];
-    free(o1);
+    ofree(o1);
     softmax_argmax(lg, npix, a->n_class, prob_out, pred_out);
-    if (!logits_out) free(lg);
+    if (!logits_out) ofree(lg);
     return 0;
 }
 
@@ -254,10 +286,10 @@ int oracle_unet_forward(const oracle_arch *a, const float *weights, const float 
         for (int i = 0; i < a->n_block[l]; ++i) {
             const int stride = (l > 0 && i == 0) ? 2 : 1;
             const int ho = (h + stride - 1) / stride, wo = (w + stride - 1) / stride;
-            float *out = (float *)malloc(sizeof(float) * (size_t)N * ho * wo * a->n_filter[l]);
+            float *out = (float *)oalloc(sizeof(float) * (size_t)N * ho * wo * a->n_filter[l]);
             if (!out) return -1;
             unit(x, N, h, w, cin, 3, stride, a->n_filter[l], &wp, out);
-            if (i > 0) free((void *)x);
+            if (i > 0) ofree(x);
             x = out; cin = a->n_filter[l]; h = ho; w = wo;
         }
         feat[l] = (float *)x; fh[l] = h; fw[l] = w;
@@ -266,8 +298,8 @@ int oracle_unet_forward(const oracle_arch *a, const float *weights, const float 
     for (int l = L - 2; l >= 0; --l) {
         const int nf = a->n_filter[l], nfu = a->n_filter[l + 1];
         const size_t npix = (size_t)N * fh[l] * fw[l];
-        float *t = (float *)malloc(sizeof(float) * npix * nf);
-        float *cat = (float *)malloc(sizeof(float) * npix * 2 * nf);
+        float *t = (float *)oalloc(sizeof(float) * npix * nf);
+        float *cat = (float *)oalloc(sizeof(float) * npix * 2 * nf);
         if (!t || !cat) return -1;
         conv2d_transpose_same(up, N, fh[l + 1], fw[l + 1], nfu, wp, 3, 2, nf, t);
         const float *bn = wp + (size_t)9 * nf * nfu;
@@ -275,28 +307,28 @@ int oracle_unet_forward(const oracle_arch *a, const float *weights, const float 
         wp = bn + 4 * (size_t)nf;
         copy_channels(feat[l], npix, nf, cat, 2 * nf, 0);      /* skip first (network_ao.py:51) */
         copy_channels(t, npix, nf, cat, 2 * nf, nf);
-        free(t); free(up); free(feat[l]);
+        ofree(t); ofree(up); ofree(feat[l]);
         const float *y = cat; int c = 2 * nf;
         for (int i = 0; i < a->n_block[l]; ++i) {
-            float *out = (float *)malloc(sizeof(float) * npix * nf);
+            float *out = (float *)oalloc(sizeof(float) * npix * nf);
             if (!out) return -1;
             unit(y, N, fh[l], fw[l], c, 3, 1, nf, &wp, out);
-            free((void *)y);
+            ofree(y);
             y = out; c = nf;
         }
         up = (float *)y;
     }
     const size_t npix = (size_t)N * H * W;
-    float *lg = logits_out ? logits_out : (float *)malloc(sizeof(float) * npix * a->n_class);
+    float *lg = logits_out ? logits_out : (float *)oalloc(sizeof(float) * npix * a->n_class);
     if (!lg) return -1;
     conv2d_same(up, N, H, W, a->n_filter[0], wp, 1, 1, a->n_class, lg);
     const float *bias = wp + (size_t)a->n_filter[0] * a->n_class;
 #pragma omp parallel for schedule(static)
     for (size_t i = 0; i < npix; ++i)
         for (int c = 0; c < a->n_class; ++c) lg[i * a->n_class + c] += bias[c];
-    free(up);
+    ofree(up);
     softmax_argmax(lg, npix, a->n_class, prob_out, pred_out);
-    if (!logits_out) free(lg);
+    if (!logits_out) ofree(lg);
     return 0;
 }
 

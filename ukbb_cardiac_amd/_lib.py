@@ -20,7 +20,8 @@ EXPORTS = [
     'ukbb_fcn_abi_version', 'ukbb_fcn_last_error', 'ukbb_fcn_weight_count', 'ukbb_fcn_create',
     'ukbb_fcn_destroy', 'ukbb_fcn_reserve', 'ukbb_fcn_forward', 'ukbb_fcn_forward_host',
     'ukbb_fcn_num_kernels', 'ukbb_fcn_kernel_name', 'ukbb_fcn_kernel_macs', 'ukbb_fcn_set_timing',
-    'ukbb_fcn_kernel_times', 'ukbb_fcn_get_activation',
+    'ukbb_fcn_kernel_times', 'ukbb_fcn_get_activation', 'ukbb_fcn_kernel_config', 'ukbb_fcn_conv_config_name',
+    'ukbb_fcn_set_timing_kernel',
 ]
 
 
@@ -45,6 +46,14 @@ def _load():
         raise ImportError(
             'ukbb_cardiac_amd: %s is missing. Build the gfx950 HIP library first '
             '(python -c "import __graft_entry__ as g; g.build()"). There is no CPU fallback.' % LIB_PATH)
+    # torch bundles its own libamdhip64; when both it and this library live in one
+    # process the HIP runtime must be loaded once, by whoever comes first.  Loading
+    # ours first and torch later left the second copy without a visible device on
+    # the GPU boxes, so let torch (when installed) bring the runtime in first.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, f32p, i32p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)
     lib.ukbb_fcn_abi_version.restype = C.c_int
@@ -63,7 +72,11 @@ def _load():
     lib.ukbb_fcn_kernel_name.argtypes = [vp, C.c_int]
     lib.ukbb_fcn_kernel_macs.restype = C.c_double
     lib.ukbb_fcn_kernel_macs.argtypes = [vp, C.c_int]
+    lib.ukbb_fcn_kernel_config.argtypes = [vp, C.c_int]
+    lib.ukbb_fcn_conv_config_name.restype = C.c_char_p
+    lib.ukbb_fcn_conv_config_name.argtypes = [C.c_int]
     lib.ukbb_fcn_set_timing.argtypes = [vp, C.c_int]
+    lib.ukbb_fcn_set_timing_kernel.argtypes = [vp, C.c_int]
     lib.ukbb_fcn_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int, C.c_int]
     lib.ukbb_fcn_get_activation.restype = C.c_int64
     lib.ukbb_fcn_get_activation.argtypes = [vp, C.c_char_p, f32p, C.c_int64]

@@ -108,6 +108,7 @@ struct ukbb_fcn_handle {
 
     // timing
     bool timing = false;
+    int timing_only = -1;                     // -1: every kernel; else only this op index
     std::vector<hipEvent_t> ev;               // 2 per op
     std::vector<double> t_sum;
     std::vector<int64_t> t_cnt;
@@ -212,25 +213,54 @@ int override_cfg(const std::string &layer) {
     return -1;
 }
 
+// Tilings measured best on MI355X for the BASELINE workload (N=64, 192x208; tools/tune_convs.py,
+// profiles/r01_tune_convs.txt): {ks, stride, cin, cout, Ho, Wo, cfg}.
+struct Tuned { int ks, stride, cin, cout, ho, wo, cfg; };
+const Tuned g_tuned[] = {
+    {3, 1, 16, 16, 192, 208, 11}, {3, 2, 16, 32, 96, 104, 29},  {3, 1, 32, 32, 96, 104, 5},
+    {3, 2, 32, 64, 48, 52, 31},   {3, 1, 64, 64, 48, 52, 18},   {3, 2, 64, 128, 24, 26, 31},
+    {3, 1, 128, 128, 24, 26, 18}, {3, 2, 128, 256, 12, 13, 31}, {3, 1, 256, 256, 12, 13, 5},
+    {1, 1, 32, 32, 96, 104, 46},  {1, 1, 64, 32, 48, 52, 42},   {1, 1, 128, 32, 24, 26, 44},
+    {1, 1, 256, 32, 12, 13, 44},
+};
+// Fallback preference (small tiles / high occupancy won everywhere in the sweep).
+const int g_pref[] = {18, 5, 11, 7, 4, 2, 31, 29, 27, 23, 42, 44, 46};
+
+bool cfg_valid(const ConvConfig &c, int ks, int stride, int c0, int c1, int cout) {
+    if (c.ks != ks || c.stride != stride) return false;
+    const int group = c.mb * c.cb * c.wm;
+    return !(cout % group || c0 % c.kc || c1 % c.kc);
+}
+
 int choose_cfg(const std::string &layer, int ks, int stride, int c0, int c1, int cout, int Ho, int Wo, int N) {
-    int forced = override_cfg(layer);
+    (void)N;
+    const int forced = override_cfg(layer);
+    ConvConfig fc;
+    if (forced >= 0) {
+        for (int i = 0; i < num_conv_configs(); ++i)
+            if (conv_config(i).id == forced && cfg_valid(conv_config(i), ks, stride, c0, c1, cout)) return forced;
+    }
+    (void)fc;
+    for (const Tuned &t : g_tuned)
+        if (t.ks == ks && t.stride == stride && t.cin == c0 + c1 && t.cout == cout && t.ho == Ho && t.wo == Wo)
+            for (int i = 0; i < num_conv_configs(); ++i)
+                if (conv_config(i).id == t.cfg && cfg_valid(conv_config(i), ks, stride, c0, c1, cout)) return t.cfg;
     double best = 1e300;
     int best_id = -1;
     for (int i = 0; i < num_conv_configs(); ++i) {
         const ConvConfig &c = conv_config(i);
-        if (c.ks != ks || c.stride != stride) continue;
+        if (!cfg_valid(c, ks, stride, c0, c1, cout)) continue;
         const int group = c.mb * c.cb * c.wm;
-        if (cout % group || c0 % c.kc || c1 % c.kc) continue;
-        if (c.id == forced) return c.id;
         const int tiles = ((Ho + c.th - 1) / c.th) * ((Wo + c.tw - 1) / c.tw);
         const int npb = (c.th * c.tw + c.mb - 1) / c.mb;
         const int pbw = (npb + c.wn - 1) / c.wn;
+        // matrix-pipe cycles per wave x workgroups = padded work (tile overhang + block rounding)
         const double cyc = (double)pbw * c.cb * (ks * ks * (c0 + c1) / (c.mb == 32 ? 2 : 4)) * (c.mb == 32 ? 64 : 32);
-        const double wgs = (double)tiles * N * (cout / group);
-        // total matrix-pipe time if perfectly spread, with a floor of one full wave of workgroups
-        double cost = std::max(wgs, 256.0) * cyc;
-        // prefer >= 2 resident workgroups per CU (staging of one overlaps MFMA of another)
-        if (c.lds_bytes > 80 * 1024) cost *= 1.15;
+        double cost = (double)tiles * (cout / group) * cyc;
+        int rank = 12;
+        for (int r = 0; r < (int)(sizeof(g_pref) / sizeof(g_pref[0])); ++r)
+            if (g_pref[r] == c.id) { rank = r % 6; break; }
+        cost *= 1.0 + 0.04 * rank;
         if (cost < best) { best = cost; best_id = c.id; }
     }
     return best_id;
@@ -390,8 +420,9 @@ int prepare(ukbb_fcn_handle *h, int n, int H, int W) {
 
 int collect_events(ukbb_fcn_handle *h) {
     if (!h->ev_pending) return UKBB_OK;
-    HIP_TRY(hipEventSynchronize(h->ev.back()), UKBB_EDEVICE);
+    HIP_TRY(hipEventSynchronize(h->ev[h->timing_only >= 0 ? 2 * h->timing_only + 1 : h->ev.size() - 1]), UKBB_EDEVICE);
     for (size_t i = 0; i < h->ops.size(); ++i) {
+        if (h->timing_only >= 0 && (int)i != h->timing_only) continue;
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]), UKBB_EDEVICE);
         h->t_sum[i] += ms;
@@ -415,7 +446,8 @@ int run_plan(ukbb_fcn_handle *h, const float *image, int n, float *logits, float
     }
     for (size_t i = 0; i < h->ops.size(); ++i) {
         const Op &op = h->ops[i];
-        if (h->timing) HIP_TRY(hipEventRecord(h->ev[2 * i], s), UKBB_EDEVICE);
+        const bool timed = h->timing && (h->timing_only < 0 || h->timing_only == (int)i);
+        if (timed) HIP_TRY(hipEventRecord(h->ev[2 * i], s), UKBB_EDEVICE);
         hipError_t e = hipSuccess;
         switch (op.kind) {
             case OP_FIRST: {
@@ -460,7 +492,7 @@ int run_plan(ukbb_fcn_handle *h, const float *image, int n, float *logits, float
                 return UKBB_EARCH;
         }
         if (e != hipSuccess) { set_err("launch of %s failed: %s", op.name.c_str(), hipGetErrorString(e)); return UKBB_EDEVICE; }
-        if (h->timing) HIP_TRY(hipEventRecord(h->ev[2 * i + 1], s), UKBB_EDEVICE);
+        if (timed) HIP_TRY(hipEventRecord(h->ev[2 * i + 1], s), UKBB_EDEVICE);
     }
     if (h->timing) h->ev_pending = true;
     h->last_n = n;
@@ -629,10 +661,33 @@ double ukbb_fcn_kernel_macs(const ukbb_fcn_handle *h, int i) {
     return h->ops[i].macs_per_image * h->last_n;
 }
 
+int ukbb_fcn_kernel_config(const ukbb_fcn_handle *h, int i) {
+    if (!h || i < 0 || i >= (int)h->ops.size() || h->ops[i].kind != OP_CONV) return -1;
+    return h->ops[i].cfg;
+}
+
+const char *ukbb_fcn_conv_config_name(int id) {
+    for (int i = 0; i < num_conv_configs(); ++i)
+        if (conv_config(i).id == id) return conv_config(i).name;
+    return "";
+}
+
 int ukbb_fcn_set_timing(ukbb_fcn_handle *h, int enable) {
     if (!h) { set_err("set_timing: NULL handle"); return UKBB_EINVAL; }
-    if (!enable && h->timing) { int rc = collect_events(h); if (rc) return rc; }
+    int rc = collect_events(h);
+    if (rc) return rc;
     h->timing = enable != 0;
+    h->timing_only = -1;
+    return UKBB_OK;
+}
+
+int ukbb_fcn_set_timing_kernel(ukbb_fcn_handle *h, int kernel) {
+    if (!h) { set_err("set_timing_kernel: NULL handle"); return UKBB_EINVAL; }
+    int rc = collect_events(h);
+    if (rc) return rc;
+    if (kernel >= (int)h->ops.size()) { set_err("set_timing_kernel: index out of range"); return UKBB_EINVAL; }
+    h->timing = true;
+    h->timing_only = kernel < 0 ? -1 : kernel;
     return UKBB_OK;
 }
 

@@ -256,6 +256,15 @@ __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM,
     X(7, 3, 1, 16, 16, 16, 16, 1, 4, 1)              \
     X(8, 3, 1, 16, 16, 16, 16, 2, 2, 1)              \
     X(9, 3, 1, 32, 16, 16, 16, 2, 2, 1)              \
+    X(11, 3, 1, 16, 8, 16, 16, 1, 4, 1)              \
+    X(12, 3, 1, 16, 8, 26, 16, 1, 4, 1)              \
+    X(13, 3, 1, 16, 12, 13, 16, 1, 4, 1)             \
+    X(14, 3, 1, 32, 12, 13, 16, 2, 2, 1)             \
+    X(15, 3, 1, 16, 6, 26, 16, 2, 2, 1)              \
+    X(16, 3, 1, 16, 8, 13, 16, 2, 2, 1)              \
+    X(17, 3, 1, 16, 16, 13, 16, 2, 2, 1)             \
+    X(18, 3, 1, 16, 12, 13, 16, 2, 2, 2)             \
+    X(19, 3, 1, 32, 12, 13, 16, 4, 1, 1)             \
     /* 3x3 stride 2 */                               \
     X(20, 3, 2, 16, 8, 26, 16, 2, 2, 1)              \
     X(21, 3, 2, 16, 12, 26, 8, 2, 2, 1)              \
@@ -263,11 +272,20 @@ __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM,
     X(23, 3, 2, 16, 12, 13, 16, 2, 2, 1)             \
     X(24, 3, 2, 16, 12, 13, 16, 4, 1, 1)             \
     X(25, 3, 2, 16, 8, 16, 16, 2, 2, 1)              \
+    X(26, 3, 2, 16, 6, 13, 16, 2, 2, 1)              \
+    X(27, 3, 2, 16, 12, 13, 8, 2, 2, 1)              \
+    X(28, 3, 2, 32, 12, 13, 8, 2, 2, 1)              \
+    X(29, 3, 2, 16, 8, 8, 16, 2, 2, 1)               \
+    X(30, 3, 2, 16, 8, 13, 16, 2, 2, 1)              \
+    X(31, 3, 2, 16, 12, 13, 16, 2, 2, 2)             \
     /* 1x1 */                                        \
     X(40, 1, 1, 16, 8, 52, 16, 2, 2, 1)              \
     X(41, 1, 1, 16, 12, 26, 16, 2, 2, 1)             \
     X(42, 1, 1, 16, 12, 13, 16, 2, 2, 1)             \
-    X(43, 1, 1, 16, 16, 16, 16, 2, 2, 1)
+    X(43, 1, 1, 16, 16, 16, 16, 2, 2, 1)             \
+    X(44, 1, 1, 16, 6, 13, 16, 2, 2, 1)              \
+    X(45, 1, 1, 16, 4, 13, 16, 2, 2, 1)              \
+    X(46, 1, 1, 16, 8, 16, 16, 2, 2, 1)
 
 #define UKBB_CFG_ENTRY(ID, KS, S, MB, TH, TW, KC, WM, WN, CB)                                   \
     {ID, KS, S, MB, TH, TW, KC, WM, WN, CB,                                                     \

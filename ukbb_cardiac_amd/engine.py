@@ -99,8 +99,15 @@ class Engine:
         n = _lib.lib.ukbb_fcn_num_kernels(self._h)
         return [_lib.lib.ukbb_fcn_kernel_macs(self._h, i) for i in range(n)]
 
+    def kernel_configs(self):
+        n = _lib.lib.ukbb_fcn_num_kernels(self._h)
+        return [_lib.lib.ukbb_fcn_kernel_config(self._h, i) for i in range(n)]
+
     def set_timing(self, enable: bool):
         _lib.check(_lib.lib.ukbb_fcn_set_timing(self._h, int(enable)), 'ukbb_fcn_set_timing')
+
+    def set_timing_kernel(self, index: int):
+        _lib.check(_lib.lib.ukbb_fcn_set_timing_kernel(self._h, int(index)), 'ukbb_fcn_set_timing_kernel')
 
     def kernel_times(self, reset=True):
         n = _lib.lib.ukbb_fcn_num_kernels(self._h)
