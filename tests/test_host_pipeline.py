@@ -1,0 +1,192 @@
+"""CPU tests of the host side: NIfTI I/O, absl-style flags, the deployment loop
+and its file contract, with a stub in place of the device forward."""
+import gzip
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from oracle import fcn_oracle as O
+from ukbb_cardiac_amd import deploy_network as DN, deploy_network_ao as DA, nifti, pipeline
+from ukbb_cardiac_amd.flags import FlagError
+
+
+# ---- NIfTI ------------------------------------------------------------------------
+@pytest.mark.parametrize('dtype', [np.float32, np.float64, np.int32, np.int16, np.uint8])
+def test_nifti_roundtrip(tmp_path, dtype):
+    rng = np.random.default_rng(0)
+    data = (rng.random((7, 5, 3, 4)) * 100).astype(dtype)
+    affine = np.array([[-1.8, 0.1, 0, 90.5], [0.05, 1.8, -0.2, -80], [0, 0.3, 10.0, 12], [0, 0, 0, 1]])
+    pixdim = np.array([1, 1.8, 1.8, 10.0, 0.03125, 0, 0, 0], np.float32)
+    p = str(tmp_path / 'x.nii.gz')
+    nifti.save(data, p, affine, pixdim)
+    im = nifti.load(p)
+    assert im.data.dtype == np.dtype(dtype) and im.data.shape == data.shape
+    assert np.array_equal(im.data, data)
+    assert np.allclose(im.affine, affine, atol=1e-5)
+    assert np.array_equal(im.header['pixdim'], pixdim)
+    raw = gzip.open(p, 'rb').read()
+    assert struct.unpack('<i', raw[:4])[0] == 348 and raw[344:348] == b'n+1\x00'
+    assert struct.unpack('<8h', raw[40:56])[:5] == (4, 7, 5, 3, 4)
+    # Fortran order on disk: x fastest
+    first = np.frombuffer(raw, np.dtype(dtype).newbyteorder('<'), count=7, offset=352)
+    assert np.array_equal(first, data[:, 0, 0, 0])
+
+
+def test_nifti_qform_and_scaling(tmp_path):
+    data = np.arange(24, dtype=np.int16).reshape(2, 3, 4)
+    hdr = bytearray(348)
+    struct.pack_into('>i', hdr, 0, 348)                       # big-endian file
+    struct.pack_into('>8h', hdr, 40, 3, 2, 3, 4, 1, 1, 1, 1)
+    struct.pack_into('>2h', hdr, 70, 4, 16)
+    struct.pack_into('>8f', hdr, 76, 1, 2, 3, 4, 1, 0, 0, 0)
+    struct.pack_into('>3f', hdr, 108, 352, 2.0, 1.0)          # value = raw*2 + 1
+    struct.pack_into('>2h', hdr, 252, 1, 0)                   # qform only
+    struct.pack_into('>6f', hdr, 256, 0, 0, 0, 5, 6, 7)       # identity rotation
+    hdr[344:348] = b'n+1\x00'
+    p = str(tmp_path / 'q.nii')
+    with open(p, 'wb') as f:
+        f.write(bytes(hdr) + b'\0' * 4 + data.astype('>i2').tobytes(order='F'))
+    im = nifti.load(p)
+    assert np.array_equal(im.data, data * 2.0 + 1.0)
+    assert np.allclose(im.affine, [[2, 0, 0, 5], [0, 3, 0, 6], [0, 0, 4, 7], [0, 0, 0, 1]])
+
+
+def test_nifti_rejects_garbage(tmp_path):
+    p = str(tmp_path / 'bad.nii.gz')
+    with gzip.open(p, 'wb') as f:
+        f.write(b'\0' * 400)
+    with pytest.raises(ValueError):
+        nifti.load(p)
+
+
+# ---- flags ------------------------------------------------------------------------
+def test_flags_reference_command_lines():
+    fs = DN.define_flags()
+    F, _ = fs.parse('--seq_name sa --data_dir demo_image --model_path trained_model/FCN_sa'.split())
+    assert (F.seq_name, F.data_dir, F.model_path, F.process_seq, F.save_seg, F.seg4) == \
+        ('sa', 'demo_image', 'trained_model/FCN_sa', True, True, False)
+    F, _ = fs.parse('--seq_name la_4ch --data_dir d --seg4 --model_path m'.split())   # demo_pipeline.py:95-96
+    assert F.seg4 is True and F.seq_name == 'la_4ch'
+    F, _ = fs.parse(['--seq_name=la_2ch', '--noprocess_seq', '--save_seg=false', '-data_dir', 'x'])
+    assert F.seq_name == 'la_2ch' and F.process_seq is False and F.save_seg is False and F.data_dir == 'x'
+    with pytest.raises(FlagError):
+        fs.parse(['--seq_name', 'ao'])                        # not in the enum
+    with pytest.raises(FlagError):
+        fs.parse(['--bogus', '1'])
+    fa = DA.define_flags()
+    F, _ = fa.parse('--seq_name ao --data_dir demo_image --model_path trained_model/UNet-LSTM_ao'.split())
+    assert F.model == 'UNet-LSTM' and F.z_score is True and F.weight_R == 5 and F.weight_r == 0.1
+
+
+# ---- deployment loop ----------------------------------------------------------------
+def stub_forward(batch):
+    """Deterministic stand-in for the network: label = intensity band (0..3);
+    'prob' is a one-hot-ish map over 3 classes."""
+    x = batch[..., 0]
+    pred = np.clip((x * 4).astype(np.int32), 0, 3)
+    prob = np.stack([(x < -0.2), (np.abs(x) <= 0.2), (x > 0.2)], axis=-1).astype(np.float32)
+    return {'pred': pred, 'prob': prob}
+
+
+def make_volume(shape, seed):
+    rng = np.random.default_rng(seed)
+    return (1000.0 * rng.gamma(2.0, 1.0, size=shape)).astype(np.float32)
+
+
+@pytest.mark.parametrize('shape', [(30, 44, 3, 5), (32, 48, 2, 4), (35, 21, 1, 6)])
+def test_segment_sequence_matches_reference_loop(shape):
+    vol = make_volume(shape, 1)
+    a_in, b_in = vol.copy(), vol.copy()
+    pred = pipeline.segment_sequence(a_in, stub_forward, batch_slices=7)
+    ref_pred, ref_img, ed, es = O.deploy_sequence(b_in, lambda x: stub_forward(x)['pred'], 'sa')
+    assert pred.dtype == np.float64 and np.array_equal(pred, ref_pred)
+    assert np.array_equal(a_in, b_in)                         # both clipped the caller's array in place
+    assert pipeline.pick_ed_es(pred, 'sa') == (ed, es)
+
+
+def test_pad_amounts_known_answers():
+    assert pipeline.pad_amounts(162, 204) == (176, 208, 7, 7, 2, 2)
+    assert pipeline.pad_amounts(163, 205) == (176, 208, 6, 7, 1, 2)
+    assert pipeline.pad_amounts(192, 208) == (192, 208, 0, 0, 0, 0)
+    assert pipeline.pad_amounts_fixed(240, 196) == (256, 256, 8, 8, 30, 30)
+    with pytest.raises(ValueError):
+        pipeline.pad_amounts_fixed(260, 100)
+
+
+def _write_subject(root, name, seq, shape, seed):
+    d = root / name
+    d.mkdir()
+    affine = np.diag([1.8, 1.8, 10.0, 1.0]); affine[:3, 3] = [-10, 5, 3]
+    pixdim = np.array([1, 1.8, 1.8, 10.0, 0.03, 0, 0, 0], np.float32)
+    nifti.save(make_volume(shape, seed), str(d / (seq + '.nii.gz')), affine, pixdim)
+    return d, affine, pixdim
+
+
+@pytest.mark.parametrize('seq,seg4,prefix', [('sa', False, 'seg'), ('la_4ch', True, 'seg4'), ('la_2ch', False, 'seg')])
+def test_deploy_file_contract(tmp_path, seq, seg4, prefix):
+    d, affine, pixdim = _write_subject(tmp_path, 'subj1', seq, (30, 44, 2, 5), 3)
+    (tmp_path / 'subj0_no_image').mkdir()
+    argv = ['--seq_name', seq, '--data_dir', str(tmp_path), '--model_path', 'unused'] + (['--seg4'] if seg4 else [])
+    F, _ = DN.define_flags().parse(argv)
+    logs = []
+    done = DN.run(F, stub_forward, log=logs.append)
+    assert done == ['subj1']
+    assert any('does not contain an image' in l for l in logs)          # print-and-continue (:73-76)
+    names = sorted(os.listdir(d))
+    assert names == sorted([seq + '.nii.gz', '%s_%s.nii.gz' % (prefix, seq), seq + '_ED.nii.gz', seq + '_ES.nii.gz',
+                            '%s_%s_ED.nii.gz' % (prefix, seq), '%s_%s_ES.nii.gz' % (prefix, seq)])
+    seg = nifti.load(str(d / ('%s_%s.nii.gz' % (prefix, seq))))
+    assert seg.data.dtype == np.float64 and seg.data.shape == (30, 44, 2, 5)
+    assert np.allclose(seg.affine, affine) and np.array_equal(seg.header['pixdim'], pixdim)
+    vol = make_volume((30, 44, 2, 5), 3)
+    ref_pred, ref_img, ed, es = O.deploy_sequence(vol, lambda x: stub_forward(x)['pred'], seq, seg4)
+    assert np.array_equal(seg.data, ref_pred)
+    es_img = nifti.load(str(d / (seq + '_ES.nii.gz')))
+    assert es_img.data.dtype == np.float32 and np.array_equal(es_img.data, ref_img[:, :, :, es])   # clipped frames
+    es_seg = nifti.load(str(d / ('%s_%s_ES.nii.gz' % (prefix, seq))))
+    assert np.array_equal(es_seg.data, ref_pred[:, :, :, es])
+    # second run: everything already there -> skipped (idempotent, :62-67)
+    assert DN.run(F, stub_forward, log=lambda *_: None) == []
+
+
+def test_deploy_ed_es_mode(tmp_path):
+    d = tmp_path / 's'
+    d.mkdir()
+    aff = np.eye(4)
+    for fr, seed in (('ED', 1), ('ES', 2)):
+        nifti.save(make_volume((20, 24, 3), seed), str(d / ('sa_%s.nii.gz' % fr)), aff)
+    F, _ = DN.define_flags().parse(['--data_dir', str(tmp_path), '--noprocess_seq'])
+    DN.run(F, stub_forward, log=lambda *_: None)
+    seg = nifti.load(str(d / 'seg_sa_ED.nii.gz'))
+    assert seg.data.dtype == np.int32 and seg.data.shape == (20, 24, 3)     # int32 in this mode (App. C.3)
+    v = make_volume((20, 24, 3), 1)
+    assert np.array_equal(seg.data, pipeline.segment_frame(v, stub_forward))
+
+
+def test_aortic_deploy(tmp_path):
+    d, affine, pixdim = _write_subject(tmp_path, 'a1', 'ao', (40, 36, 1, 6), 5)
+    F, _ = DA.define_flags().parse(['--data_dir', str(tmp_path), '--model', 'UNet', '--model_path', 'x'])
+    DA.run(F, stub_forward, log=lambda *_: None)
+    seg = nifti.load(str(d / 'seg_ao.nii.gz'))
+    assert seg.data.dtype == np.int32 and seg.data.shape == (40, 36, 1, 6)
+    assert np.array_equal(seg.header['pixdim'], pixdim)
+    vol = make_volume((40, 36, 1, 6), 5)
+    norm = O.normalise_intensity(vol, 10.0)
+    want = np.argmax(np.stack([(norm < -0.2), (np.abs(norm) <= 0.2), (norm > 0.2)], -1), -1).astype(np.int32)
+    assert np.array_equal(seg.data, want)
+    F2, _ = DA.define_flags().parse(['--data_dir', str(tmp_path)])          # default model UNet-LSTM
+    with pytest.raises(NotImplementedError):
+        DA.run(F2, stub_forward, log=lambda *_: None)
+
+
+def test_product_path_does_not_import_oracle():
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'ukbb_cardiac_amd')
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if f.endswith(('.py', '.cpp', '.hip', '.h')):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, re.M), f
+                assert 'fcn_oracle' not in src.replace('oracle/fcn_oracle.py', ''), f

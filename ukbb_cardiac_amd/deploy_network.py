@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""Drop-in for the reference's ``common/deploy_network.py``: short-axis and
+long-axis cine segmentation, NIfTI in -> label-map NIfTI out, with the network
+evaluated by the MI355X HIP engine instead of a TensorFlow session.
+
+Accepts the reference's command line verbatim (``demo_pipeline.py:63-64,89-96``)::
+
+    python3 ukbb_cardiac_amd/deploy_network.py --seq_name sa --data_dir demo_image \
+        --model_path trained_model/FCN_sa
+    ... --seq_name la_4ch --seg4 ...
+
+and writes the same files (``deploy_network.py:136-151,207-216``):
+``seg_{seq}.nii.gz`` (float64, affine + pixdim of the input), ``{seq}_ED/ES.nii.gz``,
+``seg_{seq}_ED/ES.nii.gz``; prefix ``seg4_`` with ``la_4ch --seg4``.
+``--model_path`` names ``<model_path>.ukbbw``.
+
+Extra flags (not in the reference): ``--device``, ``--batch_slices``,
+``--num_shards`` / ``--shard_index`` (multi-GPU batch split).
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+if __package__ in (None, ''):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from ukbb_cardiac_amd import nifti, pipeline                       # noqa: E402
+from ukbb_cardiac_amd.flags import FlagError, FlagSet              # noqa: E402
+from ukbb_cardiac_amd.shard import shard_from_env, subjects_for_shard   # noqa: E402
+
+
+def define_flags():
+    fs = FlagSet()                                      # reference: deploy_network.py:25-40
+    fs.DEFINE_enum('seq_name', 'sa', ['sa', 'la_2ch', 'la_4ch'], 'Sequence name.')
+    fs.DEFINE_string('data_dir', 'ukbb_cardiac_demo',
+                     'Path to the data set directory, under which images are organised in '
+                     'subdirectories for each subject.')
+    fs.DEFINE_string('model_path', '', 'Path to the saved trained model.')
+    fs.DEFINE_boolean('process_seq', True, 'Process a time sequence of images.')
+    fs.DEFINE_boolean('save_seg', True, 'Save segmentation.')
+    fs.DEFINE_boolean('seg4', False, 'Segment all the 4 chambers in long-axis 4 chamber view.')
+    env_idx, env_cnt = shard_from_env()
+    fs.DEFINE_integer('device', 0, 'HIP device ordinal (after HIP_VISIBLE_DEVICES).')
+    fs.DEFINE_integer('batch_slices', 128, 'Slices per forward call.')
+    fs.DEFINE_integer('num_shards', env_cnt, 'Number of workers sharing data_dir.')
+    fs.DEFINE_integer('shard_index', env_idx, 'This worker: subjects i with i % num_shards == shard_index.')
+    return fs
+
+
+def seg_prefix(FLAGS):
+    return 'seg4' if (FLAGS.seq_name == 'la_4ch' and FLAGS.seg4) else 'seg'
+
+
+def run(FLAGS, forward, log=print):
+    """The subject loop of deploy_network.py:52-225 with ``forward`` standing for sess.run."""
+    start_time = time.time()
+    data_list = subjects_for_shard(sorted(os.listdir(FLAGS.data_dir)), FLAGS.shard_index, FLAGS.num_shards)
+    processed, table_time = [], []
+    seq, pre = FLAGS.seq_name, seg_prefix(FLAGS)
+    for data in data_list:
+        log(data)
+        data_dir = os.path.join(FLAGS.data_dir, data)
+        if not os.path.isdir(data_dir):
+            continue
+        if os.path.exists('{0}/{1}_{2}.nii.gz'.format(data_dir, pre, seq)):
+            continue                                   # already segmented: idempotent / resumable (:62-67)
+        if FLAGS.process_seq:
+            image_name = '{0}/{1}.nii.gz'.format(data_dir, seq)
+            if not os.path.exists(image_name):
+                log('  Directory {0} does not contain an image with file name {1}. Skip.'.format(
+                    data_dir, os.path.basename(image_name)))
+                continue
+            log('  Reading {} ...'.format(image_name))
+            nim = nifti.load(image_name)
+            image = nim.get_data()
+            if image.ndim != 4:
+                log('  {0}: expected a 4-D sequence, found shape {1}. Skip.'.format(image_name, image.shape))
+                continue
+            log('  Segmenting full sequence ...')
+            t0 = time.time()
+            pred = pipeline.segment_sequence(image, forward, FLAGS.batch_slices)   # clips `image` in place
+            seg_time = time.time() - t0
+            log('  Segmentation time = {:3f}s'.format(seg_time))
+            table_time.append(seg_time)
+            processed.append(data)
+            k_ed, k_es = pipeline.pick_ed_es(pred, seq, FLAGS.seg4)
+            log('  ED frame = {:d}, ES frame = {:d}'.format(k_ed, k_es))
+            if FLAGS.save_seg:
+                log('  Saving segmentation ...')
+                pixdim = nim.header['pixdim']
+                nifti.save(pred, '{0}/{1}_{2}.nii.gz'.format(data_dir, pre, seq), nim.affine, pixdim)
+                for fr, k in (('ED', k_ed), ('ES', k_es)):
+                    # the saved frames are the CLIPPED intensities (alias quirk)
+                    nifti.save(image[:, :, :, k], '{0}/{1}_{2}.nii.gz'.format(data_dir, seq, fr), nim.affine)
+                    nifti.save(pred[:, :, :, k], '{0}/{1}_{2}_{3}.nii.gz'.format(data_dir, pre, seq, fr), nim.affine)
+        else:
+            names = {fr: '{0}/{1}_{2}.nii.gz'.format(data_dir, seq, fr) for fr in ('ED', 'ES')}
+            if not all(os.path.exists(p) for p in names.values()):
+                log('  Directory {0} does not contain an image with file name {1} or {2}. Skip.'.format(
+                    data_dir, os.path.basename(names['ED']), os.path.basename(names['ES'])))
+                continue
+            for fr in ('ED', 'ES'):
+                log('  Reading {} ...'.format(names[fr]))
+                nim = nifti.load(names[fr])
+                image = nim.get_data()
+                log('  Segmenting {} frame ...'.format(fr))
+                t0 = time.time()
+                pred = pipeline.segment_frame(image, forward, FLAGS.batch_slices)
+                seg_time = time.time() - t0
+                log('  Segmentation time = {:3f}s'.format(seg_time))
+                table_time.append(seg_time)
+                processed.append(data)
+                if FLAGS.save_seg:
+                    log('  Saving segmentation ...')
+                    nifti.save(pred, '{0}/{1}_{2}_{3}.nii.gz'.format(data_dir, pre, seq, fr), nim.affine,
+                               nim.header['pixdim'])
+    if table_time:
+        log('Average segmentation time = {:.3f}s per {}'.format(float(np.mean(table_time)),
+                                                               'sequence' if FLAGS.process_seq else 'frame'))
+    process_time = time.time() - start_time
+    if processed:
+        log('Including image I/O and device resource allocation, it took {:.3f}s for processing {:d} subjects '
+            '({:.3f}s per subjects).'.format(process_time, len(processed), process_time / len(processed)))
+    return processed
+
+
+def main(argv=None):
+    fs = define_flags()
+    try:
+        FLAGS, rest = fs.parse(sys.argv[1:] if argv is None else argv)
+    except FlagError as e:
+        sys.exit('FATAL Flags parsing error: %s\n%s' % (e, fs.usage()))
+    if 'CUDA_VISIBLE_DEVICES' in os.environ and 'HIP_VISIBLE_DEVICES' not in os.environ:
+        os.environ['HIP_VISIBLE_DEVICES'] = os.environ['CUDA_VISIBLE_DEVICES']   # demo_pipeline.py:25,63
+    from ukbb_cardiac_amd.engine import Session          # raises if the HIP library is missing
+    with Session(FLAGS.model_path, device=FLAGS.device) as sess:
+        print('Start deployment on the data set ...')
+
+        def forward(batch):
+            pred = sess.run('pred:0', feed_dict={'image:0': batch, 'training:0': False})
+            return {'pred': pred}
+        run(FLAGS, forward)
+
+
+if __name__ == '__main__':
+    main()

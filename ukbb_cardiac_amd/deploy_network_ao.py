@@ -1,0 +1,127 @@
+#!/usr/bin/env python3
+"""Drop-in for the reference's ``common/deploy_network_ao.py`` (aortic cine
+segmentation) on the MI355X HIP engine.
+
+Command line as in ``demo_pipeline.py:116-117``.  Implemented: ``--model UNet``
+(frame-wise 2-D U-Net, ``deploy_network_ao.py:111-128``) in sequence and ED/ES
+mode.  The reference's default ``--model UNet-LSTM`` (bidirectional ConvLSTM over
+a 9-frame window, ``:129-183``) is a "next" row and is
+refused with a clear message rather than silently replaced.
+
+Output: ``seg_ao.nii.gz`` int32 with the input's affine and pixdim (``:189-196``).
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+if __package__ in (None, ''):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from ukbb_cardiac_amd import nifti, pipeline                       # noqa: E402
+from ukbb_cardiac_amd.flags import FlagError, FlagSet              # noqa: E402
+from ukbb_cardiac_amd.shard import shard_from_env, subjects_for_shard   # noqa: E402
+
+
+def define_flags():
+    fs = FlagSet()                                      # reference: deploy_network_ao.py:25-49
+    fs.DEFINE_integer('time_step', 1, 'Time step during deployment of LSTM.')
+    fs.DEFINE_enum('seq_name', 'ao', ['ao'], 'Sequence name.')
+    fs.DEFINE_enum('model', 'UNet-LSTM', ['UNet', 'UNet-LSTM', 'Temporal-UNet'], 'Model name.')
+    fs.DEFINE_string('data_dir', 'Biobank_ao/validation',
+                     'Path to the test set directory, under which images are organised in '
+                     'subdirectories for each subject.')
+    fs.DEFINE_string('model_path', '', 'Path to the saved trained model.')
+    fs.DEFINE_boolean('process_seq', True, 'Process a time sequence of images.')
+    fs.DEFINE_boolean('save_seg', True, 'Save segmentation.')
+    fs.DEFINE_boolean('z_score', True, 'Normalise the image intensity to z-score. Otherwise, rescale the intensity.')
+    fs.DEFINE_integer('weight_R', 5, 'Radius of the weighting window.')
+    fs.DEFINE_float('weight_r', 0.1, 'Power of weight for the seq2seq loss. 0: uniform; 1: linear; 2: square.')
+    env_idx, env_cnt = shard_from_env()
+    fs.DEFINE_integer('device', 0, 'HIP device ordinal (after HIP_VISIBLE_DEVICES).')
+    fs.DEFINE_integer('batch_slices', 64, 'Slices per forward call.')
+    fs.DEFINE_integer('num_shards', env_cnt, 'Number of workers sharing data_dir.')
+    fs.DEFINE_integer('shard_index', env_idx, 'This worker: subjects i with i % num_shards == shard_index.')
+    return fs
+
+
+def run(FLAGS, forward, log=print):
+    if FLAGS.model != 'UNet':
+        raise NotImplementedError(
+            "--model %s: the ConvLSTM / temporal heads (common/network_ao.py:67-399) are not built yet; "
+            "only the frame-wise 2-D 'UNet' (--model UNet) is available" % FLAGS.model)
+    start_time = time.time()
+    data_list = subjects_for_shard(sorted(os.listdir(FLAGS.data_dir)), FLAGS.shard_index, FLAGS.num_shards)
+    processed = []
+    seq = FLAGS.seq_name
+    for data in data_list:
+        log(data)
+        data_dir = os.path.join(FLAGS.data_dir, data)
+        if not os.path.isdir(data_dir):
+            continue
+        if FLAGS.process_seq:
+            image_name = '{0}/{1}.nii.gz'.format(data_dir, seq)
+            if not os.path.exists(image_name):
+                log('  Directory {0} does not contain an image with file name {1}. Skip.'.format(
+                    data_dir, os.path.basename(image_name)))
+                continue
+            log('  Reading {} ...'.format(image_name))
+            nim = nifti.load(image_name)
+            image = nim.get_data()
+            log('  Segmenting full sequence ...')
+            t0 = time.time()
+            prob = pipeline.aortic_prob_sequence(image, forward, FLAGS.z_score, FLAGS.batch_slices)
+            pred = np.argmax(prob, axis=-1).astype(np.int32)          # host argmax, as :189
+            if FLAGS.save_seg:
+                log('  Saving segmentation ...')
+                nifti.save(pred, '{0}/seg_{1}.nii.gz'.format(data_dir, seq), nim.affine, nim.header['pixdim'])
+            log('  Segmentation time = {:3f}s'.format(time.time() - t0))
+            processed.append(data)
+        else:
+            names = {fr: '{0}/{1}_{2}.nii.gz'.format(data_dir, seq, fr) for fr in ('ED', 'ES')}
+            if not all(os.path.exists(p) for p in names.values()):
+                log('  Directory {0} does not contain an image with file name {1} or {2}. Skip.'.format(
+                    data_dir, os.path.basename(names['ED']), os.path.basename(names['ES'])))
+                continue
+            for fr in ('ED', 'ES'):
+                log('  Reading {} ...'.format(names[fr]))
+                nim = nifti.load(names[fr])
+                t0 = time.time()
+                pred = pipeline.aortic_segment_frame(nim.get_data(), forward, FLAGS.z_score, FLAGS.batch_slices)
+                log('  Segmentation time = {:3f}s'.format(time.time() - t0))
+                if FLAGS.save_seg:
+                    log('  Saving segmentation ...')
+                    nifti.save(pred, '{0}/seg_{1}_{2}.nii.gz'.format(data_dir, seq, fr), nim.affine,
+                               nim.header['pixdim'])
+            processed.append(data)
+    process_time = time.time() - start_time
+    if processed:
+        log('Including image I/O and device resource allocation, it took {:.3f}s for processing {:d} subjects '
+            '({:.3f}s per subjects).'.format(process_time, len(processed), process_time / len(processed)))
+    return processed
+
+
+def main(argv=None):
+    fs = define_flags()
+    try:
+        FLAGS, rest = fs.parse(sys.argv[1:] if argv is None else argv)
+    except FlagError as e:
+        sys.exit('FATAL Flags parsing error: %s\n%s' % (e, fs.usage()))
+    if 'CUDA_VISIBLE_DEVICES' in os.environ and 'HIP_VISIBLE_DEVICES' not in os.environ:
+        os.environ['HIP_VISIBLE_DEVICES'] = os.environ['CUDA_VISIBLE_DEVICES']
+    if FLAGS.model != 'UNet':
+        sys.exit("Error: --model %s is not available on the HIP engine yet (only --model UNet); "
+                 "see DESIGN.md section 7." % FLAGS.model)
+    from ukbb_cardiac_amd.engine import Session
+    with Session(FLAGS.model_path, device=FLAGS.device) as sess:
+        print('Start evaluating on the test set ...')
+
+        def forward(batch):
+            prob, pred = sess.run(['prob:0', 'pred:0'], feed_dict={'image:0': batch, 'training:0': False})
+            return {'prob': prob, 'pred': pred}
+        run(FLAGS, forward)
+
+
+if __name__ == '__main__':
+    main()

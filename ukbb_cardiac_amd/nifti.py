@@ -1,0 +1,149 @@
+"""Minimal NIfTI-1 (.nii / .nii.gz) reader and writer.
+
+The reference uses nibabel (``nib.load`` / ``nim.get_data()`` / ``nim.affine`` /
+``nim.header['pixdim']`` / ``nib.Nifti1Image(data, affine)`` / ``nib.save``;
+``common/deploy_network.py:80-83,136-151``), which is not installed here and may
+not be on the GPU box.  Only what the deployment and evaluation scripts touch is
+implemented: single-file NIfTI-1, the common scalar datatypes, scl_slope/inter,
+sform/qform affines, pixdim.  Data is returned in (X, Y, Z, T) order, i.e. the
+file's Fortran order, like nibabel.
+"""
+import gzip
+import struct
+
+import numpy as np
+
+_DTYPES = {2: 'u1', 4: 'i2', 8: 'i4', 16: 'f4', 64: 'f8', 256: 'i1', 512: 'u2', 768: 'u4', 1024: 'i8', 1280: 'u8'}
+_CODES = {np.dtype(v).str[1:]: k for k, v in _DTYPES.items()}
+
+
+class NiftiImage:
+    """data [X,Y,(Z,(T))] ndarray, affine 4x4 float64, pixdim float32[8]
+    (pixdim[1:4] voxel size, pixdim[4] frame time: data/biobank_utils.py:59-63)."""
+
+    def __init__(self, data, affine, pixdim=None, header=None):
+        self.data = data
+        self.affine = np.asarray(affine, dtype=np.float64)
+        self.header = dict(header or {})
+        if pixdim is None:
+            pixdim = np.ones(8, np.float32)
+            vox = np.sqrt((self.affine[:3, :3] ** 2).sum(axis=0))
+            pixdim[1:4] = vox
+        self.header['pixdim'] = np.asarray(pixdim, dtype=np.float32).copy()
+
+    @property
+    def shape(self):
+        return self.data.shape
+
+    def get_data(self):
+        return self.data
+
+
+def _open(path, mode):
+    return gzip.open(path, mode) if str(path).endswith('.gz') else open(path, mode)
+
+
+def _quat_affine(b, c, d, qx, qy, qz, pixdim):
+    a2 = 1.0 - (b * b + c * c + d * d)
+    a = np.sqrt(a2) if a2 > 0 else 0.0
+    R = np.array([[a * a + b * b - c * c - d * d, 2 * (b * c - a * d), 2 * (b * d + a * c)],
+                  [2 * (b * c + a * d), a * a + c * c - b * b - d * d, 2 * (c * d - a * b)],
+                  [2 * (b * d - a * c), 2 * (c * d + a * b), a * a + d * d - b * b - c * c]])
+    qfac = -1.0 if pixdim[0] < 0 else 1.0
+    S = np.diag([pixdim[1], pixdim[2], pixdim[3] * qfac])
+    A = np.eye(4)
+    A[:3, :3] = R @ S
+    A[:3, 3] = [qx, qy, qz]
+    return A
+
+
+def load(path) -> NiftiImage:
+    with _open(path, 'rb') as f:
+        raw = f.read()
+    if len(raw) < 348:
+        raise ValueError('%s: too short for a NIfTI-1 header' % path)
+    end = '<'
+    if struct.unpack('<i', raw[:4])[0] != 348:
+        end = '>'
+        if struct.unpack('>i', raw[:4])[0] != 348:
+            raise ValueError('%s: not a NIfTI-1 file (sizeof_hdr != 348)' % path)
+    if raw[344:347] not in (b'n+1', b'ni1'):
+        raise ValueError('%s: bad NIfTI magic %r' % (path, raw[344:348]))
+    if raw[344:347] == b'ni1':
+        raise ValueError('%s: two-file NIfTI (.hdr/.img) is not supported' % path)
+    dim = struct.unpack(end + '8h', raw[40:56])
+    datatype, bitpix = struct.unpack(end + '2h', raw[70:74])
+    pixdim = np.array(struct.unpack(end + '8f', raw[76:108]), dtype=np.float32)
+    vox_offset, slope, inter = struct.unpack(end + '3f', raw[108:120])
+    qform_code, sform_code = struct.unpack(end + '2h', raw[252:256])
+    qb, qc, qd, qx, qy, qz = struct.unpack(end + '6f', raw[256:280])
+    srow = np.array(struct.unpack(end + '12f', raw[280:328]), dtype=np.float64).reshape(3, 4)
+    if datatype not in _DTYPES:
+        raise ValueError('%s: unsupported NIfTI datatype %d' % (path, datatype))
+    ndim = dim[0]
+    if not 1 <= ndim <= 7:
+        raise ValueError('%s: bad dim[0] = %d' % (path, ndim))
+    shape = tuple(int(d) for d in dim[1:1 + ndim])
+    dt = np.dtype(end + _DTYPES[datatype])
+    off = int(vox_offset) if vox_offset >= 352 else 352
+    n = int(np.prod(shape))
+    if len(raw) < off + n * dt.itemsize:
+        raise ValueError('%s: truncated image data' % path)
+    data = np.frombuffer(raw, dtype=dt, count=n, offset=off).reshape(shape, order='F')
+    data = data.astype(dt.newbyteorder('='), copy=True)       # writable, native order
+    if slope != 0 and not (slope == 1 and inter == 0) and np.isfinite(slope):
+        data = data * np.float64(slope) + np.float64(inter)   # nibabel's get_data() applies the scaling
+    while data.ndim > 3 and data.shape[-1] == 1 and data.ndim > len(shape):
+        data = data[..., 0]
+    if sform_code > 0:                                         # nibabel's get_best_affine order
+        affine = np.vstack([srow, [0, 0, 0, 1]])
+    elif qform_code > 0:
+        affine = _quat_affine(qb, qc, qd, qx, qy, qz, pixdim)
+    else:
+        affine = np.diag([pixdim[1], pixdim[2], pixdim[3], 1.0]).astype(np.float64)
+        affine[:3, 3] = -0.5 * (np.array(shape[:3] + (1,) * (3 - min(3, len(shape))))[:3] - 1) * pixdim[1:4]
+    hdr = {'dim': dim, 'datatype': datatype, 'bitpix': bitpix, 'qform_code': qform_code, 'sform_code': sform_code,
+           'xyzt_units': raw[123], 'descrip': raw[148:228].rstrip(b'\x00')}
+    return NiftiImage(data, affine, pixdim, hdr)
+
+
+def save(img_or_data, path, affine=None, pixdim=None):
+    """save(NiftiImage, path) or save(ndarray, path, affine[, pixdim]).  Writes the
+    array's own dtype (the reference relies on that: float64 label volumes in
+    sequence mode, int32 in ED/ES mode), sform = affine
+    (code 2, as nibabel's Nifti1Image(data, affine) does), qform code 0."""
+    if isinstance(img_or_data, NiftiImage):
+        data, affine, pixdim = img_or_data.data, img_or_data.affine, img_or_data.header['pixdim']
+    else:
+        data = img_or_data
+    data = np.asarray(data)
+    if data.dtype == np.bool_:
+        data = data.astype(np.uint8)
+    key = data.dtype.newbyteorder('<').str[1:]
+    if key not in _CODES:
+        raise ValueError('cannot store dtype %s in NIfTI-1' % data.dtype)
+    affine = np.asarray(affine, dtype=np.float64)
+    if affine.shape != (4, 4):
+        raise ValueError('affine must be 4x4')
+    if not 1 <= data.ndim <= 7:
+        raise ValueError('NIfTI-1 stores 1 to 7 dimensions')
+    dim = [data.ndim] + list(data.shape) + [1] * (7 - data.ndim)
+    pd = np.ones(8, np.float32)
+    pd[1:4] = np.sqrt((affine[:3, :3] ** 2).sum(axis=0))
+    if pixdim is not None:
+        pd = np.asarray(pixdim, dtype=np.float32).copy()
+    hdr = bytearray(348)
+    struct.pack_into('<i', hdr, 0, 348)
+    struct.pack_into('<8h', hdr, 40, *dim)
+    struct.pack_into('<2h', hdr, 70, _CODES[key], data.dtype.itemsize * 8)
+    struct.pack_into('<8f', hdr, 76, *[float(v) for v in pd])
+    struct.pack_into('<3f', hdr, 108, 352.0, 1.0, 0.0)
+    hdr[123] = 10 if data.ndim >= 4 else 2            # mm (+ seconds): informative only
+    struct.pack_into('<2h', hdr, 252, 0, 2)
+    struct.pack_into('<12f', hdr, 280, *[float(v) for v in affine[:3].ravel()])
+    hdr[344:348] = b'n+1\x00'
+    payload = np.asfortranarray(data.astype(data.dtype.newbyteorder('<'), copy=False)).tobytes(order='F')
+    with _open(path, 'wb') as f:
+        f.write(bytes(hdr))
+        f.write(b'\x00\x00\x00\x00')
+        f.write(payload)
