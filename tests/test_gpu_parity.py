@@ -151,3 +151,74 @@ def test_session_mirror(engines):
             sess.run(['nope:0'], feed_dict={'image:0': img})
         with pytest.raises(ValueError):
             sess.run(['pred:0'], feed_dict={'image:0': img, 'training:0': True})
+
+
+# ---- aortic U-Net (network_ao.py:18-64, BASELINE config 5 fp32 leg) -------------------
+def test_unet_golden(engines):
+    g = np.load(os.path.join(GOLD, 'unet_ao_2x64x96.npz'))
+    out = engines('UNet_ao').run(g['image'], want_logits=True)
+    ref = g['logits64']
+    assert np.abs(out['logits'] - ref).max() <= LOGIT_RTOL * np.abs(ref).max()
+    assert np.array_equal(out['pred'], g['pred64'])
+    assert np.abs(out['prob'] - g['prob64']).max() <= 1e-4
+
+
+def test_unet_256_decoder_activations(engines):
+    """Fixed 256x256 aortic input size (deploy_network_ao.py:105); every decoder level
+    (transposed conv + skip concat + convs) against the fp64 oracle."""
+    from oracle import fcn_oracle as O
+    from ukbb_cardiac_amd.arch import MODELS
+    from ukbb_cardiac_amd.phantom import cine_phantom
+    from ukbb_cardiac_amd.weights import synthetic_params
+    arch = MODELS['UNet_ao']
+    img = ((cine_phantom(1, 256, 256, seed=51) - 0.3) / 0.25).astype(np.float32)
+    eng = engines('UNet_ao')
+    out = eng.run(img, want_logits=True)
+    ref, net = O.UNet(img, synthetic_params(arch, 1234), 3, n_block=arch.n_block, dtype=np.float64, return_net=True)
+    for l in (3, 2, 1, 0):
+        a = eng.activation('up%d' % l).reshape(net['conv%d_up' % l].shape)
+        assert np.abs(a - net['conv%d_up' % l]).max() <= 1e-4 * max(1.0, np.abs(net['conv%d_up' % l]).max()), l
+    assert np.abs(out['logits'] - ref).max() <= LOGIT_RTOL * np.abs(ref).max()
+    bad = out['pred'] != O.argmax_pred(ref)
+    assert not np.any(bad & (O.top2_margin(ref) > NEAR_TIE)) and bad.sum() <= 2
+
+
+def test_aortic_pipeline_on_device(engines):
+    """deploy_network_ao.py 'UNet' branch end to end on a (X,Y,1,T) cine, device forward
+    vs the same host loop driven by the C oracle."""
+    from oracle import c_oracle
+    from ukbb_cardiac_amd import pipeline
+    from ukbb_cardiac_amd.arch import MODELS
+    from ukbb_cardiac_amd.weights import pack_flat, synthetic_params
+    arch = MODELS['UNet_ao']
+    flat = pack_flat(arch, synthetic_params(arch, 1234))
+    rng = np.random.default_rng(3)
+    vol = (1000.0 * rng.gamma(2.0, 1.0, size=(200, 180, 1, 4))).astype(np.float32)
+    eng = engines('UNet_ao')
+    dev = pipeline.aortic_prob_sequence(vol.copy(), lambda b: eng.run(b), batch_slices=3)
+
+    def cpu_forward(b):
+        _, pr, pd = c_oracle.forward(arch, flat, b, want_logits=False, want_prob=True)
+        return {'prob': pr, 'pred': pd}
+    ref = pipeline.aortic_prob_sequence(vol.copy(), cpu_forward, batch_slices=4)
+    assert dev.shape == (200, 180, 1, 4, 3) and np.abs(dev - ref).max() <= 1e-4
+    assert (np.argmax(dev, -1) != np.argmax(ref, -1)).mean() < 1e-4
+
+
+def test_sa_pipeline_on_device(engines):
+    """deploy_network.py sequence mode on an un-padded (X,Y,Z,T) volume: device labels
+    == C-oracle labels through the same host loop (pads 7/7 and 2/2: SURVEY 8(c))."""
+    from oracle import c_oracle
+    from ukbb_cardiac_amd import pipeline
+    from ukbb_cardiac_amd.arch import MODELS
+    from ukbb_cardiac_amd.weights import pack_flat, synthetic_params
+    arch = MODELS['FCN_sa']
+    flat = pack_flat(arch, synthetic_params(arch, 1234))
+    rng = np.random.default_rng(4)
+    vol = (1000.0 * rng.gamma(2.0, 1.0, size=(162, 204, 2, 3))).astype(np.float32)
+    eng = engines('FCN_sa')
+    dev = pipeline.segment_sequence(vol.copy(), lambda b: eng.run(b, want_prob=False), batch_slices=4)
+    ref = pipeline.segment_sequence(vol.copy(), lambda b: {'pred': c_oracle.forward(arch, flat, b, want_logits=False)[2]},
+                                    batch_slices=6)
+    assert dev.dtype == np.float64 and dev.shape == vol.shape
+    assert (dev != ref).sum() <= 2          # only fp32 near-ties may differ between two fp32 evaluations

@@ -320,6 +320,39 @@ int add_conv(ukbb_fcn_handle *h, const std::string &lname, int in0, int in1, int
     return UKBB_OK;
 }
 
+// conv2d_transpose 3x3 s2 + BN + ReLU as a 2x2 sub-pixel conv (kernels.h, tconv_as_conv2x2)
+int add_tconv(ukbb_fcn_handle *h, const std::string &lname, int in0, int H, int W, int n_hint, int *out_buf) {
+    const int li = h->layer_index.at(lname);
+    const HostLayer &L = h->layers[li];
+    Op op;
+    op.kind = OP_TCONV; op.name = lname; op.layer = li; op.in0 = in0;
+    op.H = H; op.W = W; op.Ho = H; op.Wo = W; op.stride = 1; op.pad_y = 1; op.pad_x = 1;
+    op.cfg = choose_cfg(lname, 2, 1, L.cin, 0, 4 * L.cout, H, W, n_hint);
+    if (op.cfg < 0) { set_err("no tiling for transposed conv %s", lname.c_str()); return UKBB_EARCH; }
+    ConvConfig c;
+    find_cfg(op.cfg, c);
+    char key[128];
+    snprintf(key, sizeof key, "%s/pk2x2_mb%d_kc%d_g%d", L.name.c_str(), c.mb, c.kc, c.wm * c.cb);
+    if (!dev_ptr(h, key)) {
+        std::vector<float> w2((size_t)4 * L.cin * 4 * L.cout), pk(w2.size());
+        tconv_as_conv2x2(L.w.data(), L.cin, L.cout, w2.data());
+        pack_conv_weights(w2.data(), 2, L.cin, 4 * L.cout, c.mb, c.kc, c.wm * c.cb, pk.data());
+        int rc = upload(h, key, pk);
+        if (rc) return rc;
+        std::vector<float> b4((size_t)4 * L.cout);
+        for (int ph = 0; ph < 4; ++ph) std::copy(L.b.begin(), L.b.end(), b4.begin() + (size_t)ph * L.cout);
+        rc = upload(h, lname + "/bias4", b4);
+        if (rc) return rc;
+    }
+    op.wpk = dev_ptr(h, key);
+    op.bias = dev_ptr(h, lname + "/bias4");
+    op.out = new_act(h, lname, (size_t)4 * H * W * L.cout);
+    op.macs_per_image = (double)H * W * 9 * L.cin * L.cout;
+    h->ops.push_back(op);
+    *out_buf = op.out;
+    return UKBB_OK;
+}
+
 int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
     h->ops.clear();
     h->act.clear(); h->act_per_image.clear(); h->act_name.clear();
@@ -370,8 +403,27 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
         for (int l = 1; l < 5; ++l) op.sq[l - 1] = sq[l];
         h->ops.push_back(op);
     } else {
-        set_err("UNet plan not built yet");
-        return UKBB_EARCH;
+        // decoder (network_ao.py:44-55): transposed conv, concat [skip, up] (two-source conv), convs
+        int up = level_out[a.n_level - 1];
+        for (int l = a.n_level - 2; l >= 0; --l) {
+            snprintf(nm, sizeof nm, "up%d_t", l);
+            int t;
+            int rc = add_tconv(h, nm, up, lh[l + 1], lw[l + 1], n_hint, &t);
+            if (rc) return rc;
+            int x = -1;
+            for (int i = 0; i < a.n_block[l]; ++i) {
+                snprintf(nm, sizeof nm, "up%d_%d", l, i);
+                rc = (i == 0) ? add_conv(h, nm, level_out[l], t, a.n_filter[l], lh[l], lw[l], 1, n_hint, &x)
+                              : add_conv(h, nm, x, -1, 0, lh[l], lw[l], 1, n_hint, &x);
+                if (rc) return rc;
+            }
+            up = x;
+            h->act_name[up] = std::string("up") + std::to_string(l);
+        }
+        Op op; op.kind = OP_LOGITS; op.name = "logits"; op.layer = h->layer_index.at("logits"); op.in0 = up;
+        op.H = op.Ho = H; op.W = op.Wo = W;
+        op.macs_per_image = (double)H * W * a.n_filter[0] * a.n_class;
+        h->ops.push_back(op);
     }
     h->plan_h = H; h->plan_w = W;
     // events
@@ -485,6 +537,29 @@ int run_plan(ukbb_fcn_handle *h, const float *image, int n, float *logits, float
                 ha.logits = logits; ha.prob = prob; ha.pred = pred;
                 ha.N = n; ha.H = op.H; ha.W = op.W; ha.n_class = a.n_class;
                 e = launch_head(ha, s);
+                break;
+            }
+            case OP_TCONV: {
+                const HostLayer &L = h->layers[op.layer];
+                ConvConfig c;
+                find_cfg(op.cfg, c);
+                ConvArgs ca{};
+                ca.in0 = h->act[op.in0]->p; ca.in1 = nullptr; ca.C0 = L.cin; ca.C1 = 0;
+                ca.wpk = op.wpk; ca.bias = op.bias; ca.out = h->act[op.out]->p;
+                ca.N = n; ca.H = op.H; ca.W = op.W; ca.Ho = op.Ho; ca.Wo = op.Wo; ca.Cout = 4 * L.cout;
+                ca.pad_y = 1; ca.pad_x = 1;
+                ca.tiles_y = (op.Ho + c.th - 1) / c.th; ca.tiles_x = (op.Wo + c.tw - 1) / c.tw;
+                ca.relu = 1; ca.up2 = L.cout;
+                e = launch_conv(op.cfg, ca, s);
+                break;
+            }
+            case OP_LOGITS: {
+                const HostLayer &L = h->layers[op.layer];
+                LogitsArgs la{};
+                la.in = h->act[op.in0]->p; la.w = dev_ptr(h, "logits/w"); la.bias = dev_ptr(h, "logits/bias");
+                la.logits = logits; la.prob = prob; la.pred = pred;
+                la.npix = (int64_t)n * op.H * op.W; la.C = L.cin; la.n_class = a.n_class;
+                e = launch_logits(la, s);
                 break;
             }
             default:

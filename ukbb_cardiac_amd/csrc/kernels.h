@@ -23,6 +23,8 @@ struct ConvArgs {
     int pad_y, pad_x;   // TF 'SAME' pad_before (oracle/fcn_oracle.py same_pads)
     int tiles_y, tiles_x;
     int relu;
+    int up2;            // 0: plain conv.  C > 0: the 4*C output channels are the 4 sub-pixel phases of a
+                        // stride-2 transposed conv with C real channels; scatter to out[N,2Ho,2Wo,C]
 };
 
 // One compiled tiling of the conv kernel.
@@ -89,15 +91,13 @@ void pack_head_lg(const float *w /*[64][n_class]*/, int n_class, float *dst /*2*
 // ---------------------------------------------------------------------------
 // U-Net pieces (network_ao.py:48-63)
 // ---------------------------------------------------------------------------
-struct TconvArgs {          // conv2d_transpose 3x3 stride 2 'SAME' + bias + ReLU
-    const float *in;        // [N,h,w,Cin]
-    const float *wpk;       // packed per phase
-    const float *bias;
-    float *out;             // [N,2h,2w,Cout]
-    int N, h, w, Cin, Cout;
-};
-hipError_t launch_tconv(const TconvArgs &a, hipStream_t s);
-size_t pack_tconv_weights(const float *w /*[3][3][Cout][Cin] folded*/, int cin, int cout, float *dst);
+// conv2d_transpose 3x3 stride 2 'SAME' (network.py:28-34 via network_ao.py:49) is run by
+// conv_mfma_kernel as a 2x2-tap stride-1 conv over the INPUT grid with 4*Cout output channels
+// (phase-major: (py,px,co)) and ConvArgs::up2 = Cout.  This builds that dense filter
+// [2][2][Cin][4*Cout] from the folded transposed filter w[3][3][Cin][Cout] (already re-laid
+// out as HWIO by the engine):  out[2m+py] = sum_a x[m+a-1] * w[kh(py,a)],
+//   py = 0: a=0 -> kh=2, a=1 -> kh=0 ;  py = 1: a=1 -> kh=1 (a=0: no tap).
+void tconv_as_conv2x2(const float *w, int cin, int cout, float *dst);
 
 struct LogitsArgs {         // 1x1 conv C -> n_class + bias, softmax / argmax (network_ao.py:63,159-160)
     const float *in;        // [N,H,W,C]

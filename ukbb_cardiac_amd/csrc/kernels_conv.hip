@@ -221,7 +221,13 @@ __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM,
             const int q = (wn + pb * WN) * PB + pl;
             const int oy = oy0 + q / TW, ox = ox0 + q % TW;
             if (q < NPIX && oy < a.Ho && ox < a.Wo) {
-                float *o = a.out + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.Cout + co0;
+                float *o;
+                if (a.up2 == 0) {
+                    o = a.out + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.Cout + co0;
+                } else {                          // sub-pixel scatter of a transposed conv
+                    const int ph = co0 / a.up2, co = co0 % a.up2;   // a 32-channel block never straddles phases
+                    o = a.out + ((size_t)(n * 2 * a.Ho + 2 * oy + (ph >> 1)) * (2 * a.Wo) + 2 * ox + (ph & 1)) * a.up2 + co;
+                }
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     float4 v;
@@ -285,7 +291,12 @@ __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM,
     X(43, 1, 1, 16, 16, 16, 16, 2, 2, 1)             \
     X(44, 1, 1, 16, 6, 13, 16, 2, 2, 1)              \
     X(45, 1, 1, 16, 4, 13, 16, 2, 2, 1)              \
-    X(46, 1, 1, 16, 8, 16, 16, 2, 2, 1)
+    X(46, 1, 1, 16, 8, 16, 16, 2, 2, 1)              \
+    /* 2x2 (transposed conv as sub-pixel conv) */    \
+    X(60, 2, 1, 16, 12, 13, 16, 2, 2, 2)             \
+    X(61, 2, 1, 16, 12, 13, 16, 2, 2, 1)             \
+    X(62, 2, 1, 16, 8, 16, 16, 2, 2, 2)              \
+    X(63, 2, 1, 16, 8, 16, 16, 2, 2, 1)
 
 #define UKBB_CFG_ENTRY(ID, KS, S, MB, TH, TW, KC, WM, WN, CB)                                   \
     {ID, KS, S, MB, TH, TW, KC, WM, WN, CB,                                                     \
