@@ -125,7 +125,8 @@ int ukbb_fcn_set_timing_kernel(ukbb_fcn_handle *h, int kernel);
 int ukbb_fcn_kernel_times(ukbb_fcn_handle *h, double *sum_ms, int64_t *count, int n, int reset);
 
 /* Copy an intermediate activation of the LAST forward to host (tests only).
- * Names: "conv0".."conv4" (level outputs), "sq1".."sq4" (FCN squeezed maps),
+ * Names: "conv0".."conv4" (level outputs), "g1".."g4" (FCN: out0's level-l slice applied to
+ * the squeezed map at low resolution, 64 channels),
  * "up3".."up0" (UNet decoder outputs).  Returns the number of floats, or a
  * negative error; with dst == NULL only the size is returned. */
 int64_t ukbb_fcn_get_activation(ukbb_fcn_handle *h, const char *name, float *dst, int64_t cap);

@@ -67,10 +67,17 @@ def test_intermediate_activations_match_oracle(engines):
     eng = engines('FCN_sa')
     eng.run(img)
     _, net = O.build_FCN(img, synthetic_params(arch, 1234), 4, dtype=np.float64, return_net=True)
-    for dev, ora in [('conv%d' % l, 'conv%d' % l) for l in range(5)] + \
-                    [('sq%d' % l, 'conv%d_same_dim' % l) for l in range(1, 5)]:
-        a = eng.activation(dev).reshape(net[ora].shape)
-        assert np.abs(a - net[ora]).max() <= 1e-4 * max(1.0, np.abs(net[ora]).max()), dev
+    params = synthetic_params(arch, 1234)
+    for l in range(5):
+        a = eng.activation('conv%d' % l).reshape(net['conv%d' % l].shape)
+        assert np.abs(a - net['conv%d' % l]).max() <= 1e-4 * max(1.0, np.abs(net['conv%d' % l]).max()), l
+    # g_l = (out0 weights of level l, BN scale folded) applied to the squeezed map at LOW resolution
+    p0 = params['out0']
+    scale = p0['gamma'].astype(np.float64) / np.sqrt(p0['var'].astype(np.float64) + 1e-3)
+    for l in range(1, 5):
+        ref = net['conv%d_same_dim' % l] @ (p0['kernel'][0, 0, 32 * l:32 * (l + 1), :].astype(np.float64) * scale)
+        a = eng.activation('g%d' % l).reshape(ref.shape)
+        assert np.abs(a - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), l
 
 
 @pytest.mark.parametrize('n', [1, 3, 10])

@@ -25,7 +25,11 @@ if __name__ == '__main__':
     print('kernels:', eng.kernel_names())
     if arch.kind == KIND_FCN:
         ref, net = O.build_FCN(img, params, arch.n_class, dtype=np.float64, return_net=True)
-        names = [('conv%d' % l, 'conv%d' % l) for l in range(5)] + [('sq%d' % l, 'conv%d_same_dim' % l) for l in range(1, 5)]
+        names = [('conv%d' % l, 'conv%d' % l) for l in range(5)] + [('g%d' % l, 'g%d' % l) for l in range(1, 5)]
+        p0 = params['out0']
+        scale = p0['gamma'].astype(np.float64) / np.sqrt(p0['var'].astype(np.float64) + 1e-3)
+        for l in range(1, 5):
+            net['g%d' % l] = net['conv%d_same_dim' % l] @ (p0['kernel'][0, 0, 32 * l:32 * (l + 1), :].astype(np.float64) * scale)
     else:
         ref, net = O.UNet(img, params, arch.n_class, n_block=arch.n_block, dtype=np.float64, return_net=True)
         names = [('conv%d' % l, 'conv%d' % l) for l in range(5)] + [('up%d' % l, 'conv%d_up' % l) for l in range(3, -1, -1)]

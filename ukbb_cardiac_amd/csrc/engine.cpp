@@ -69,7 +69,7 @@ struct DevBuf {
     }
 };
 
-enum OpKind { OP_FIRST, OP_CONV, OP_HEAD, OP_TCONV, OP_LOGITS };
+enum OpKind { OP_FIRST, OP_CONV, OP_HEAD, OP_TCONV, OP_LOGITS, OP_SQG };
 
 struct Op {                    // one kernel launch of the plan
     OpKind kind;
@@ -390,11 +390,15 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
         std::vector<int> sq(a.n_level, -1);
         for (int l = 1; l < a.n_level; ++l) {     // same_dim0 lives inside the head kernel
             snprintf(nm, sizeof nm, "same_dim%d", l);
-            int out;
-            int rc = add_conv(h, nm, level_out[l], -1, 0, lh[l], lw[l], 1, n_hint, &out);
-            if (rc) return rc;
-            sq[l] = out;
-            h->act_name[out] = std::string("sq") + std::to_string(l);
+            Op op; op.kind = OP_SQG; op.name = std::string("sqg") + std::to_string(l);
+            op.layer = h->layer_index.at(nm); op.in0 = level_out[l];
+            op.H = op.Ho = lh[l]; op.W = op.Wo = lw[l]; op.stride = l;
+            op.out = new_act(h, std::string("g") + std::to_string(l), (size_t)lh[l] * lw[l] * a.fc);
+            // algorithmic MACs: the squeeze; the 32->64 projection is out0's work moved to low
+            // resolution and is accounted to the head (so the per-layer sums equal Appendix A)
+            op.macs_per_image = (double)lh[l] * lw[l] * a.n_filter[l] * a.same_dim;
+            h->ops.push_back(op);
+            sq[l] = op.out;
         }
         Op op; op.kind = OP_HEAD; op.name = "head"; op.in0 = level_out[0];
         op.H = op.Ho = H; op.W = op.Wo = W;
@@ -526,10 +530,22 @@ int run_plan(ukbb_fcn_handle *h, const float *image, int n, float *logits, float
                 e = launch_conv(op.cfg, ca, s);
                 break;
             }
+            case OP_SQG: {
+                const HostLayer &L = h->layers[op.layer];
+                const std::string ls = std::to_string(op.stride);
+                SqgArgs sa{};
+                sa.x = h->act[op.in0]->p;
+                sa.w_s = dev_ptr(h, "sqg" + ls + "/w_s"); sa.b_s = dev_ptr(h, L.name + "/bias");
+                sa.w_g = dev_ptr(h, "sqg" + ls + "/w_g");
+                sa.out = h->act[op.out]->p;
+                sa.npix = (long long)n * op.H * op.W; sa.cin = L.cin;
+                e = launch_sqg(sa, s);
+                break;
+            }
             case OP_HEAD: {
                 HeadArgs ha{};
                 ha.conv0 = h->act[op.in0]->p;
-                for (int l = 0; l < 4; ++l) ha.sq[l] = h->act[op.sq[l]]->p;
+                for (int l = 0; l < 4; ++l) ha.G[l] = h->act[op.sq[l]]->p;
                 ha.w_s0 = dev_ptr(h, "head/w_s0"); ha.b_s0 = dev_ptr(h, "same_dim0/bias");
                 ha.w_o0 = dev_ptr(h, "head/w_o0"); ha.b_o0 = dev_ptr(h, "out0/bias");
                 ha.w_o1 = dev_ptr(h, "head/w_o1"); ha.b_o1 = dev_ptr(h, "out1/bias");
@@ -668,14 +684,23 @@ ukbb_fcn_handle *ukbb_fcn_create(const ukbb_fcn_arch *arch, const float *weights
         const HostLayer &o1 = h->layers[h->layer_index.at("out1")];
         const HostLayer &lg = h->layers[h->layer_index.at("logits")];
         std::vector<float> v;
-        v.assign(64 * 8, 0.f);              pack_head_s0(s0.w.data(), v.data());
+        v.assign(16 * 32, 0.f);                 pack_sq(s0.w.data(), 16, v.data());
         if (upload(h.get(), "head/w_s0", v)) return nullptr;
-        v.assign(5 * 2 * 16 * 64, 0.f);     pack_head_o0(o0.w.data(), v.data());
+        v.assign(2 * 4 * 64 * 4, 0.f);          pack_rowmap_32x64(o0.w.data(), 64, v.data());
         if (upload(h.get(), "head/w_o0", v)) return nullptr;
-        v.assign(2 * 2 * 16 * 64, 0.f);     pack_head_o1(o1.w.data(), v.data());
+        v.assign(2 * 2 * 4 * 64 * 4, 0.f);
+        pack_rowmap_32x64(o1.w.data(), 64, v.data());
+        pack_rowmap_32x64(o1.w.data() + 32 * 64, 64, v.data() + 2 * 4 * 64 * 4);
         if (upload(h.get(), "head/w_o1", v)) return nullptr;
-        v.assign(2 * arch->n_class * 32, 0.f); pack_head_lg(lg.w.data(), arch->n_class, v.data());
+        v.assign(2 * arch->n_class * 32, 0.f);  pack_head_lg(lg.w.data(), arch->n_class, v.data());
         if (upload(h.get(), "head/w_lg", v)) return nullptr;
+        for (int l = 1; l < arch->n_level; ++l) {
+            const HostLayer &sl = h->layers[h->layer_index.at("same_dim" + std::to_string(l))];
+            v.assign((size_t)sl.cin * 32, 0.f);  pack_sq(sl.w.data(), sl.cin, v.data());
+            if (upload(h.get(), "sqg" + std::to_string(l) + "/w_s", v)) return nullptr;
+            v.assign(2 * 4 * 64 * 4, 0.f);       pack_rowmap_32x64(o0.w.data() + (size_t)32 * l * 64, 64, v.data());
+            if (upload(h.get(), "sqg" + std::to_string(l) + "/w_g", v)) return nullptr;
+        }
     } else {
         const HostLayer &lg = h->layers[h->layer_index.at("logits")];
         if (upload(h.get(), "logits/w", lg.w)) return nullptr;

@@ -61,20 +61,32 @@ struct FirstArgs {
 hipError_t launch_first(const FirstArgs &a, hipStream_t s);
 
 // ---------------------------------------------------------------------------
-// Fused FCN head (network.py:201-229 + train_network.py:198-199):
-// same_dim0 1x1 -> [gather-upsample of sq1..sq4] -> out0 -> out1 -> logits
-// -> softmax / argmax.  The 160-channel concat is never materialised.
+// FCN head (network.py:201-229 + train_network.py:198-199), see kernels_head.hip.
+// sqg: G_l[px][64] = W0_l * relu(BN(Ws_l * conv_l[px]))   at the resolution of level l = 1..4
+// head: same_dim0 -> out0 (level-0 slice) + sum_l bilinear-gather(G_l) -> out1 -> logits
+//       -> softmax / argmax, at full resolution.
 // ---------------------------------------------------------------------------
+struct SqgArgs {
+    const float *x;          // [npix][cin] level-l features
+    const float *w_s;        // pack_sq(same_dim_l)            [cin/8][64][4]
+    const float *b_s;        // [32]
+    const float *w_g;        // pack_rowmap_32x64(out0 rows 32l..32l+31)
+    float *out;              // [npix][64]
+    long long npix;
+    int cin;
+};
+hipError_t launch_sqg(const SqgArgs &a, hipStream_t s);
+
 struct HeadArgs {
     const float *conv0;      // [N,H,W,16] level-0 features
-    const float *sq[4];      // squeezed maps of levels 1..4: [N,H>>l,W>>l,32]
-    const float *w_s0;       // packed A frags same_dim0   (16 -> 32)
+    const float *G[4];       // projected maps of levels 1..4: [N,H>>l,W>>l,64]
+    const float *w_s0;       // pack_sq(same_dim0, 16)
     const float *b_s0;       // [32]
-    const float *w_o0;       // packed A frags out0        (160 -> 64)
+    const float *w_o0;       // pack_rowmap_32x64(out0 rows 0..31)
     const float *b_o0;       // [64]
-    const float *w_o1;       // packed A frags out1        (64 -> 64)
+    const float *w_o1;       // pack_rowmap_32x64(out1 rows 0..31) ++ pack_rowmap_32x64(out1 rows 32..63)
     const float *b_o1;       // [64]
-    const float *w_lg;       // packed logits weights [2][n_class][32]
+    const float *w_lg;       // pack_head_lg: [2][n_class][32]
     const float *b_lg;       // [n_class]
     float *logits;           // optional [N,H,W,n_class]
     float *prob;             // optional
@@ -82,10 +94,8 @@ struct HeadArgs {
     int N, H, W, n_class;
 };
 hipError_t launch_head(const HeadArgs &a, hipStream_t s);
-// packers for the head's weights (see kernels_head.hip for the k-order)
-void pack_head_s0(const float *w /*[16][32] folded*/, float *dst /*64*8*/);
-void pack_head_o0(const float *w /*[160][64] folded*/, float *dst /*5*2*16*64*/);
-void pack_head_o1(const float *w /*[64][64] folded*/, float *dst /*2*2*16*64*/);
+void pack_sq(const float *w /*[cin][32] folded*/, int cin, float *dst /*cin*32*/);
+void pack_rowmap_32x64(const float *w /*32 rows x 64 cols*/, int ld, float *dst /*2*4*64*4*/);
 void pack_head_lg(const float *w /*[64][n_class]*/, int n_class, float *dst /*2*n_class*32*/);
 
 // ---------------------------------------------------------------------------

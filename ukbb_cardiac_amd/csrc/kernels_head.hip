@@ -1,32 +1,34 @@
-// Fused FCN head for gfx950.  One kernel replaces, for the full-resolution
-// part of build_FCN (reference common/network.py:201-229) and the prob / pred
-// definition (common/train_network.py:198-199):
+// Fused FCN head for gfx950.  Two kernels replace the full-resolution part of
+// build_FCN (reference common/network.py:201-229) and the prob / pred definition
+// (common/train_network.py:198-199):
 //
-//   same_dim0 (1x1, 16->32, BN, ReLU)
-//   transpose_upsample2d x2/x4/x8/x16 of the squeezed maps of levels 1..4
-//   concat -> 160 channels                         (never materialised)
-//   out0 1x1 160->64 BN ReLU, out1 1x1 64->64 BN ReLU, logits 1x1 64->n_class + bias
+//   same_dim_l   1x1 C_l -> 32, BN, ReLU                       (network.py:203-204)
+//   up_l         transpose_upsample2d x2/x4/x8/x16             (network.py:138-167,210-211)
+//   concat       -> 160 channels                               (network.py:218)
+//   out0         1x1 160 -> 64, BN, ReLU ; out1 1x1 64 -> 64, BN, ReLU ; logits 1x1 64 -> n_class + bias
 //   softmax, argmax
 //
-// Mapping: one wave owns 32 consecutive pixels (linear index over N*H*W); the
-// pixel sits on the MFMA N dimension (lane & 31) and channels on M, so every
-// 1x1 layer is D[cout][pixel] = W[cout][k] * X[k][pixel] with
-// v_mfma_f32_32x32x2_f32.  The 32x32 result tile has its column (pixel) on the
-// lane and its rows (channels) in the 16 accumulator registers, so after
-// bias+ReLU the registers ARE the next layer's B operand (k-step r supplies
-// rows rowmap(r,0) on lanes 0-31 and rowmap(r,1) on lanes 32-63); the weights
-// are packed on the host in that k order.  Nothing goes through LDS.
+// Algebra used: out0's pre-activation is  W0 * concat_l(up_l(s_l)) = sum_l up_l(W0_l * s_l),
+// because the bilinear "transposed conv" acts per channel and linearly, and a 1x1 conv acts
+// per pixel and linearly, so they commute (borders included: both sides apply the same,
+// possibly un-normalised, tap weights).  Levels 1..4 are therefore projected to 64
+// channels at LOW resolution by sqg_kernel (G_l = W0_l * relu(BN(Ws_l * x_l))), and the
+// full-resolution kernel only gathers the <= 2x2 taps of G_l and adds them.  This removes
+// 128 of the 160 input channels of out0 at full resolution (-300 M of 603 M MAC per slice)
+// and the 160-channel concat / the four upsampled maps are never materialised.
 //
-// The bilinear "transposed conv" upsampling (network.py:138-167) is evaluated
-// as its <= 2x2 non-zero taps per output pixel, gathered straight from the
-// low-resolution maps (L2 resident), with TF's SAME crop offset and
-// un-normalised borders: out[o] = sum_i x[i] * h[o + pb - i*f], pb = (f-1)/2
-// (oracle/fcn_oracle.py transpose_upsample2d_separable).
+// Common mapping: one wave owns 32 pixels; the pixel sits on the MFMA N dimension
+// (lane & 31), channels on M, so every 1x1 layer is D[cout][px] = W[cout][k] X[k][px] with
+// v_mfma_f32_32x32x2_f32.  The 32x32 result has its column (pixel) on the lane and its rows
+// (channels) in the 16 accumulator registers, so after bias + ReLU the registers ARE the next
+// layer's B operand: k-step r supplies rows rowmap(r,0) on lanes 0-31 and rowmap(r,1) on
+// lanes 32-63, and the weights are packed on the host in that k order.
 #include "kernels.h"
 
 namespace ukbb {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __host__ __device__ __forceinline__ constexpr int rowmap(int r, int g) {
     // row of a 32x32 f32 MFMA result held in register r by lane half g
@@ -35,165 +37,232 @@ __host__ __device__ __forceinline__ constexpr int rowmap(int r, int g) {
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-__device__ __forceinline__ void tap1d(int o, int l, int n_in, int &i0, float &w0, int &i1, float &w1) {
-    const int f = 1 << l;
-    const int t = o + ((f - 1) >> 1);
-    i1 = t >> l;
-    const int j1 = t & (f - 1);
-    const float inv = 1.0f / (float)f;
-    w1 = (float)(j1 + 1) * inv;
-    w0 = (float)(f - 1 - j1) * inv;
-    i0 = i1 - 1;
-    if (i1 >= n_in) { i1 = n_in - 1; w1 = 0.f; }
-    if (i0 < 0) { i0 = 0; w0 = 0.f; }
+__device__ __forceinline__ f32x4 ldg4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+
+// acc[4j+i] = relu(acc[4j+i] + bias[8j + 4g + i])
+__device__ __forceinline__ void bias_relu(f32x16 &acc, const float *bias, int g) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x4 b = ldg4(bias + 8 * j + 4 * g);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[4 * j + i] = fmaxf(acc[4 * j + i] + b[i], 0.f);
+    }
 }
 
-template <int NCLS>
-__global__ __launch_bounds__(256) void fcn_head_kernel(const HeadArgs a) {
+// D0/D1 (two Cout blocks of 32) += W[64][32 rows of X] * X, X given as an accumulator tile.
+// wp: packed [cb][q4][lane][4]
+__device__ __forceinline__ void chain_32to64(const float *wp, int lane, const f32x16 &X, f32x16 &D0, f32x16 &D1) {
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+        const f32x4 wa = ldg4(wp + ((0 * 4 + q4) * 64 + lane) * 4);
+        const f32x4 wb = ldg4(wp + ((1 * 4 + q4) * 64 + lane) * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            D0 = MFMA32(wa[i], X[4 * q4 + i], D0);
+            D1 = MFMA32(wb[i], X[4 * q4 + i], D1);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// sqg_kernel: G[px][64] = W0_l (64x32) * relu(Ws (32xCIN) * x[px] + bs)   at low resolution.
+// One wave per 32 consecutive pixels of the flattened [N*H_l*W_l] map; no LDS.
+// ---------------------------------------------------------------------------
+template <int CIN>
+__global__ __launch_bounds__(256) void sqg_kernel(const SqgArgs a) {
     const int lane = threadIdx.x & 63;
     const int p = lane & 31, g = lane >> 5;
-    const long long nblk = ((long long)a.N * a.H * a.W) >> 5;
-    const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const long long nwave = (long long)gridDim.x * 4;
-
-    for (long long blk = wave0; blk < nblk; blk += nwave) {
+    const long long nblk = (a.npix + 31) >> 5;
+    for (long long blk = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); blk < nblk; blk += (long long)gridDim.x * 4) {
         const long long q = blk * 32 + p;
-        const int hw = a.H * a.W;
-        const int n = (int)(q / hw);
-        const int rem = (int)(q - (long long)n * hw);
-        const int y = rem / a.W, x = rem - y * a.W;
-
-        // ---- same_dim0: S[32][px] = Ws0[32][16] * conv0[16][px] -----------------
+        const bool valid = q < a.npix;
+        const float *xp = a.x + (valid ? q : a.npix - 1) * CIN + 4 * g;
         f32x16 S;
 #pragma unroll
         for (int r = 0; r < 16; ++r) S[r] = 0.f;
-        {
-            const float4 *xp = reinterpret_cast<const float4 *>(a.conv0 + q * 16 + 8 * g);
-            const float4 x0 = xp[0], x1 = xp[1];
-            const float xin[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-            const float4 *wp = reinterpret_cast<const float4 *>(a.w_s0 + lane * 8);
-            const float4 w0 = wp[0], w1 = wp[1];
-            const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        // k-step (j,i) pairs channels 8j+i (lanes 0-31) and 8j+4+i (lanes 32-63)
+#pragma unroll 4
+        for (int j = 0; j < CIN / 8; ++j) {
+            const f32x4 xv = ldg4(xp + 8 * j);
+            const f32x4 wv = ldg4(a.w_s + (j * 64 + lane) * 4);
 #pragma unroll
-            for (int s = 0; s < 8; ++s) S = MFMA32(wv[s], xin[s], S);
+            for (int i = 0; i < 4; ++i) S = MFMA32(wv[i], xv[i], S);
         }
-        // bias + ReLU -> B operand of out0's level-0 slice
+        bias_relu(S, a.b_s, g);
+        f32x16 G0, G1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { G0[r] = 0.f; G1[r] = 0.f; }
+        chain_32to64(a.w_g, lane, S, G0, G1);
+        if (valid) {
+            float *o = a.out + q * 64 + 4 * g;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v0, v1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { v0[i] = G0[4 * j + i]; v1[i] = G1[4 * j + i]; }
+                *reinterpret_cast<f32x4 *>(o + 8 * j) = v0;
+                *reinterpret_cast<f32x4 *>(o + 32 + 8 * j) = v1;
+            }
+        }
+    }
+}
+
+hipError_t launch_sqg(const SqgArgs &a, hipStream_t s) {
+    const long long nblk = (a.npix + 31) / 32;
+    long long wg = (nblk + 3) / 4;
+    if (wg > 256 * 8) wg = 256 * 8;
+    dim3 grid((unsigned)wg), block(256);
+    switch (a.cin) {
+        case 32: hipLaunchKernelGGL(sqg_kernel<32>, grid, block, 0, s, a); break;
+        case 64: hipLaunchKernelGGL(sqg_kernel<64>, grid, block, 0, s, a); break;
+        case 128: hipLaunchKernelGGL(sqg_kernel<128>, grid, block, 0, s, a); break;
+        case 256: hipLaunchKernelGGL(sqg_kernel<256>, grid, block, 0, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// fcn_head_kernel: one workgroup = one 16x16 pixel tile (H, W are multiples of 16) =
+// 8 blocks of 32 pixels (two tile rows each), two blocks per wave.
+//
+// LDS holds the low-resolution windows of G_1..G_4 this tile's bilinear taps touch:
+// for level l (factor f = 2^l, pb = (f-1)/2) output row y reads source rows
+// i1 = (y+pb)>>l and i1-1, so a 16-row tile origin y0 needs rows (y0>>l)-1 .. (y0>>l)+((15+pb)>>l):
+// 9, 6, 4, 3 rows (and columns) for l = 1..4, i.e. 81+36+16+9 = 142 source pixels x 64 ch.
+// Rows/columns outside the map are stored as zeros, which is exactly the reference's
+// un-normalised border (the tap is dropped).  Pixel stride is 68 floats
+// so the ds_read_b128 of 16 lanes with different source pixels hit distinct bank quads.
+// ---------------------------------------------------------------------------
+constexpr int HT = 16;                                 // tile edge
+constexpr int GSTRIDE = 68;                            // floats per staged source pixel
+__host__ __device__ constexpr int win_n(int l) { return l == 1 ? 9 : l == 2 ? 6 : l == 3 ? 4 : 3; }
+__host__ __device__ constexpr int win_base(int l) { return l == 1 ? 0 : l == 2 ? 81 : l == 3 ? 117 : 133; }
+constexpr int GPIX = 142;
+constexpr int HEAD_LDS_FLOATS = GPIX * GSTRIDE;
+
+template <int NCLS>
+__global__ __launch_bounds__(256, 2) void fcn_head_kernel(const HeadArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float gl[];   // [GPIX][GSTRIDE]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = lane & 31, g = lane >> 5;
+    const int tiles_x = a.W / HT, tiles_y = a.H / HT;
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int n = bid / tiles_y;
+    const int y0 = ty * HT, x0 = tx * HT;
+
+    // ---- stage the G windows (global NHWC -> LDS), 16 float4 per source pixel ---------
+    {
+        constexpr int NF4 = GPIX * 16, NIT = (NF4 + 255) / 256;
+        f32x4 v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = it * 256 + tid;
+            const int sp = idx >> 4, c4 = idx & 15;
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            if (sp < GPIX) {
+                const int l = sp < 81 ? 1 : sp < 117 ? 2 : sp < 133 ? 3 : 4;
+                const int wn_ = win_n(l), rel = sp - win_base(l);
+                const int ry = rel / wn_, rx = rel - ry * wn_;
+                const int hl = a.H >> l, wl = a.W >> l;
+                const int sy = (y0 >> l) - 1 + ry, sx = (x0 >> l) - 1 + rx;
+                if ((unsigned)sy < (unsigned)hl && (unsigned)sx < (unsigned)wl)
+                    t = ldg4(a.G[l - 1] + (((size_t)n * hl + sy) * wl + sx) * 64 + 4 * c4);
+            }
+            v[it] = t;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = it * 256 + tid;
+            const int sp = idx >> 4, c4 = idx & 15;
+            if (sp < GPIX) *reinterpret_cast<f32x4 *>(gl + sp * GSTRIDE + 4 * c4) = v[it];
+        }
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int bb = 0; bb < 2; ++bb) {
+        const int blk = wave * 2 + bb;                        // tile rows 2*blk, 2*blk+1
+        const int yl = 2 * blk + (p >> 4), xl = p & 15;
+        const int y = y0 + yl, x = x0 + xl;
+        const size_t q = ((size_t)n * a.H + y) * a.W + x;
+
+        // ---- same_dim0: S[32][px] = Ws0[32][16] * conv0[16][px] -----------------------------
+        f32x16 S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const f32x4 xv = ldg4(a.conv0 + q * 16 + 8 * j + 4 * g);
+            const f32x4 wv = ldg4(a.w_s0 + (j * 64 + lane) * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) S = MFMA32(wv[i], xv[i], S);
+        }
+        bias_relu(S, a.b_s0, g);
+        // ---- out0, level-0 slice: P[64][px] = W0_0[64][32] * S ---------------------------------
         f32x16 P0, P1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { P0[r] = 0.f; P1[r] = 0.f; }
-        {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float4 b = *reinterpret_cast<const float4 *>(a.b_s0 + 8 * j + 4 * g);
-                S[4 * j + 0] = fmaxf(S[4 * j + 0] + b.x, 0.f);
-                S[4 * j + 1] = fmaxf(S[4 * j + 1] + b.y, 0.f);
-                S[4 * j + 2] = fmaxf(S[4 * j + 2] + b.z, 0.f);
-                S[4 * j + 3] = fmaxf(S[4 * j + 3] + b.w, 0.f);
-            }
-            // w_o0 layout: [level][cb][quad q4][lane][4]  (k-steps 4*q4 .. 4*q4+3)
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const float4 wa = *reinterpret_cast<const float4 *>(a.w_o0 + (((0 * 2 + 0) * 4 + q4) * 64 + lane) * 4);
-                const float4 wb = *reinterpret_cast<const float4 *>(a.w_o0 + (((0 * 2 + 1) * 4 + q4) * 64 + lane) * 4);
-                P0 = MFMA32(wa.x, S[4 * q4 + 0], P0); P1 = MFMA32(wb.x, S[4 * q4 + 0], P1);
-                P0 = MFMA32(wa.y, S[4 * q4 + 1], P0); P1 = MFMA32(wb.y, S[4 * q4 + 1], P1);
-                P0 = MFMA32(wa.z, S[4 * q4 + 2], P0); P1 = MFMA32(wb.z, S[4 * q4 + 2], P1);
-                P0 = MFMA32(wa.w, S[4 * q4 + 3], P0); P1 = MFMA32(wb.w, S[4 * q4 + 3], P1);
-            }
-        }
-        // ---- levels 1..4: gather-upsample 32 channels, feed out0 ---------------
+        chain_32to64(a.w_o0, lane, S, P0, P1);
+        // ---- + sum_l up_l(G_l): <= 2x2 taps per level from LDS ------------------------------------
 #pragma unroll
         for (int l = 1; l <= 4; ++l) {
-            const int hl = a.H >> l, wl = a.W >> l;
-            int y0, y1, x0, x1; float wy0, wy1, wx0, wx1;
-            tap1d(y, l, hl, y0, wy0, y1, wy1);
-            tap1d(x, l, wl, x0, wx0, x1, wx1);
-            const float *base = a.sq[l - 1] + (size_t)n * hl * wl * 32 + 16 * g;
-            const float4 *t00 = reinterpret_cast<const float4 *>(base + ((size_t)y0 * wl + x0) * 32);
-            const float4 *t01 = reinterpret_cast<const float4 *>(base + ((size_t)y0 * wl + x1) * 32);
-            const float4 *t10 = reinterpret_cast<const float4 *>(base + ((size_t)y1 * wl + x0) * 32);
-            const float4 *t11 = reinterpret_cast<const float4 *>(base + ((size_t)y1 * wl + x1) * 32);
+            const int f = 1 << l, pb = (f - 1) >> 1;
+            const float inv = 1.0f / (float)f;
+            const int tyy = yl + pb, txx = xl + pb;           // tile-relative: (y0 >> l) cancels
+            const int ry1 = (tyy >> l) + 1, rx1 = (txx >> l) + 1;   // window index (row 0 = source row (y0>>l)-1)
+            const int jy = tyy & (f - 1), jx = txx & (f - 1);
+            const float wy1 = (float)(jy + 1) * inv, wy0 = (float)(f - 1 - jy) * inv;
+            const float wx1 = (float)(jx + 1) * inv, wx0 = (float)(f - 1 - jx) * inv;
+            const int wn_ = win_n(l);
+            const float *b11 = gl + (win_base(l) + ry1 * wn_ + rx1) * GSTRIDE + 4 * g;
+            const float *b10 = b11 - GSTRIDE, *b01 = b11 - wn_ * GSTRIDE, *b00 = b01 - GSTRIDE;
             const float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
-            float f[16];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float4 v00 = t00[j], v01 = t01[j], v10 = t10[j], v11 = t11[j];
-                f[4 * j + 0] = w00 * v00.x + w01 * v01.x + w10 * v10.x + w11 * v11.x;
-                f[4 * j + 1] = w00 * v00.y + w01 * v01.y + w10 * v10.y + w11 * v11.y;
-                f[4 * j + 2] = w00 * v00.z + w01 * v01.z + w10 * v10.z + w11 * v11.z;
-                f[4 * j + 3] = w00 * v00.w + w01 * v01.w + w10 * v10.w + w11 * v11.w;
-            }
+                const f32x4 a00 = *reinterpret_cast<const f32x4 *>(b00 + 8 * j), a01 = *reinterpret_cast<const f32x4 *>(b01 + 8 * j);
+                const f32x4 a10 = *reinterpret_cast<const f32x4 *>(b10 + 8 * j), a11 = *reinterpret_cast<const f32x4 *>(b11 + 8 * j);
+                const f32x4 c00 = *reinterpret_cast<const f32x4 *>(b00 + 32 + 8 * j), c01 = *reinterpret_cast<const f32x4 *>(b01 + 32 + 8 * j);
+                const f32x4 c10 = *reinterpret_cast<const f32x4 *>(b10 + 32 + 8 * j), c11 = *reinterpret_cast<const f32x4 *>(b11 + 32 + 8 * j);
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const float4 wa = *reinterpret_cast<const float4 *>(a.w_o0 + (((l * 2 + 0) * 4 + q4) * 64 + lane) * 4);
-                const float4 wb = *reinterpret_cast<const float4 *>(a.w_o0 + (((l * 2 + 1) * 4 + q4) * 64 + lane) * 4);
-                P0 = MFMA32(wa.x, f[4 * q4 + 0], P0); P1 = MFMA32(wb.x, f[4 * q4 + 0], P1);
-                P0 = MFMA32(wa.y, f[4 * q4 + 1], P0); P1 = MFMA32(wb.y, f[4 * q4 + 1], P1);
-                P0 = MFMA32(wa.z, f[4 * q4 + 2], P0); P1 = MFMA32(wb.z, f[4 * q4 + 2], P1);
-                P0 = MFMA32(wa.w, f[4 * q4 + 3], P0); P1 = MFMA32(wb.w, f[4 * q4 + 3], P1);
+                for (int i = 0; i < 4; ++i) {
+                    P0[4 * j + i] += w00 * a00[i] + w01 * a01[i] + w10 * a10[i] + w11 * a11[i];
+                    P1[4 * j + i] += w00 * c00[i] + w01 * c01[i] + w10 * c10[i] + w11 * c11[i];
+                }
             }
         }
-        // ---- out0 bias + ReLU ; out1: Q[64][px] = W1[64][64] * X[64][px] ----------
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float4 b0 = *reinterpret_cast<const float4 *>(a.b_o0 + 8 * j + 4 * g);
-            const float4 b1 = *reinterpret_cast<const float4 *>(a.b_o0 + 32 + 8 * j + 4 * g);
-            P0[4 * j + 0] = fmaxf(P0[4 * j + 0] + b0.x, 0.f); P1[4 * j + 0] = fmaxf(P1[4 * j + 0] + b1.x, 0.f);
-            P0[4 * j + 1] = fmaxf(P0[4 * j + 1] + b0.y, 0.f); P1[4 * j + 1] = fmaxf(P1[4 * j + 1] + b1.y, 0.f);
-            P0[4 * j + 2] = fmaxf(P0[4 * j + 2] + b0.z, 0.f); P1[4 * j + 2] = fmaxf(P1[4 * j + 2] + b1.z, 0.f);
-            P0[4 * j + 3] = fmaxf(P0[4 * j + 3] + b0.w, 0.f); P1[4 * j + 3] = fmaxf(P1[4 * j + 3] + b1.w, 0.f);
-        }
+        // ---- out0 bias + ReLU ; out1: Q[64][px] = W1[64][64] * X[64][px] ------------------------------
+        bias_relu(P0, a.b_o0, g);
+        bias_relu(P1, a.b_o0 + 32, g);
         f32x16 Q0, Q1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { Q0[r] = 0.f; Q1[r] = 0.f; }
-        // w_o1 layout: [kb][cb][q4][lane][4]
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            const float4 wa = *reinterpret_cast<const float4 *>(a.w_o1 + (((0 * 2 + 0) * 4 + q4) * 64 + lane) * 4);
-            const float4 wb = *reinterpret_cast<const float4 *>(a.w_o1 + (((0 * 2 + 1) * 4 + q4) * 64 + lane) * 4);
-            Q0 = MFMA32(wa.x, P0[4 * q4 + 0], Q0); Q1 = MFMA32(wb.x, P0[4 * q4 + 0], Q1);
-            Q0 = MFMA32(wa.y, P0[4 * q4 + 1], Q0); Q1 = MFMA32(wb.y, P0[4 * q4 + 1], Q1);
-            Q0 = MFMA32(wa.z, P0[4 * q4 + 2], Q0); Q1 = MFMA32(wb.z, P0[4 * q4 + 2], Q1);
-            Q0 = MFMA32(wa.w, P0[4 * q4 + 3], Q0); Q1 = MFMA32(wb.w, P0[4 * q4 + 3], Q1);
-        }
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            const float4 wa = *reinterpret_cast<const float4 *>(a.w_o1 + (((1 * 2 + 0) * 4 + q4) * 64 + lane) * 4);
-            const float4 wb = *reinterpret_cast<const float4 *>(a.w_o1 + (((1 * 2 + 1) * 4 + q4) * 64 + lane) * 4);
-            Q0 = MFMA32(wa.x, P1[4 * q4 + 0], Q0); Q1 = MFMA32(wb.x, P1[4 * q4 + 0], Q1);
-            Q0 = MFMA32(wa.y, P1[4 * q4 + 1], Q0); Q1 = MFMA32(wb.y, P1[4 * q4 + 1], Q1);
-            Q0 = MFMA32(wa.z, P1[4 * q4 + 2], Q0); Q1 = MFMA32(wb.z, P1[4 * q4 + 2], Q1);
-            Q0 = MFMA32(wa.w, P1[4 * q4 + 3], Q0); Q1 = MFMA32(wb.w, P1[4 * q4 + 3], Q1);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float4 b0 = *reinterpret_cast<const float4 *>(a.b_o1 + 8 * j + 4 * g);
-            const float4 b1 = *reinterpret_cast<const float4 *>(a.b_o1 + 32 + 8 * j + 4 * g);
-            Q0[4 * j + 0] = fmaxf(Q0[4 * j + 0] + b0.x, 0.f); Q1[4 * j + 0] = fmaxf(Q1[4 * j + 0] + b1.x, 0.f);
-            Q0[4 * j + 1] = fmaxf(Q0[4 * j + 1] + b0.y, 0.f); Q1[4 * j + 1] = fmaxf(Q1[4 * j + 1] + b1.y, 0.f);
-            Q0[4 * j + 2] = fmaxf(Q0[4 * j + 2] + b0.z, 0.f); Q1[4 * j + 2] = fmaxf(Q1[4 * j + 2] + b1.z, 0.f);
-            Q0[4 * j + 3] = fmaxf(Q0[4 * j + 3] + b0.w, 0.f); Q1[4 * j + 3] = fmaxf(Q1[4 * j + 3] + b1.w, 0.f);
-        }
-        // ---- logits on the vector ALU: each lane holds 32 of the 64 channels ------
+        chain_32to64(a.w_o1, lane, P0, Q0, Q1);               // k rows 0..31
+        chain_32to64(a.w_o1 + 2 * 4 * 64 * 4, lane, P1, Q0, Q1);   // k rows 32..63
+        bias_relu(Q0, a.b_o1, g);
+        bias_relu(Q1, a.b_o1 + 32, g);
+        // ---- logits on the vector ALU: each lane holds 32 of the 64 channels --------------------------
         // w_lg layout: [g][c][32] with index cb*16 + r  <->  channel cb*32 + rowmap(r, g)
         float lg[NCLS];
 #pragma unroll
         for (int c = 0; c < NCLS; ++c) {
-            const float4 *wp = reinterpret_cast<const float4 *>(a.w_lg + (g * NCLS + c) * 32);
+            const float *wp = a.w_lg + (g * NCLS + c) * 32;
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float4 w = wp[j];
-                s = fmaf(w.x, Q0[4 * j + 0], s); s = fmaf(w.y, Q0[4 * j + 1], s);
-                s = fmaf(w.z, Q0[4 * j + 2], s); s = fmaf(w.w, Q0[4 * j + 3], s);
+                const f32x4 w = ldg4(wp + 4 * j);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s = fmaf(w[i], Q0[4 * j + i], s);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float4 w = wp[4 + j];
-                s = fmaf(w.x, Q1[4 * j + 0], s); s = fmaf(w.y, Q1[4 * j + 1], s);
-                s = fmaf(w.z, Q1[4 * j + 2], s); s = fmaf(w.w, Q1[4 * j + 3], s);
+                const f32x4 w = ldg4(wp + 16 + 4 * j);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s = fmaf(w[i], Q1[4 * j + i], s);
             }
-            // both halves compute (lower + upper) in the SAME order -> identical bits
+            // both halves form (lower + upper) in the SAME order -> identical bits
             const float other = __shfl_xor(s, 32);
             lg[c] = (g == 0 ? s + other : other + s) + a.b_lg[c];
         }
@@ -219,55 +288,39 @@ __global__ __launch_bounds__(256) void fcn_head_kernel(const HeadArgs a) {
 }
 
 hipError_t launch_head(const HeadArgs &a, hipStream_t s) {
-    const long long npix = (long long)a.N * a.H * a.W;
-    if (npix % 32) return hipErrorInvalidValue;
-    const long long nblk = npix / 32;
-    long long wg = (nblk + 3) / 4;
-    if (wg > 256 * 8) wg = 256 * 8;
-    dim3 grid((unsigned)wg), block(256);
+    if ((a.H % HT) || (a.W % HT)) return hipErrorInvalidValue;
+    dim3 grid((unsigned)(a.N * (a.H / HT) * (a.W / HT))), block(256);
+    const size_t lds = HEAD_LDS_FLOATS * sizeof(float);
     switch (a.n_class) {
-        case 2: hipLaunchKernelGGL(fcn_head_kernel<2>, grid, block, 0, s, a); break;
-        case 3: hipLaunchKernelGGL(fcn_head_kernel<3>, grid, block, 0, s, a); break;
-        case 4: hipLaunchKernelGGL(fcn_head_kernel<4>, grid, block, 0, s, a); break;
-        case 5: hipLaunchKernelGGL(fcn_head_kernel<5>, grid, block, 0, s, a); break;
-        case 6: hipLaunchKernelGGL(fcn_head_kernel<6>, grid, block, 0, s, a); break;
+        case 2: hipLaunchKernelGGL(fcn_head_kernel<2>, grid, block, lds, s, a); break;
+        case 3: hipLaunchKernelGGL(fcn_head_kernel<3>, grid, block, lds, s, a); break;
+        case 4: hipLaunchKernelGGL(fcn_head_kernel<4>, grid, block, lds, s, a); break;
+        case 5: hipLaunchKernelGGL(fcn_head_kernel<5>, grid, block, lds, s, a); break;
+        case 6: hipLaunchKernelGGL(fcn_head_kernel<6>, grid, block, lds, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
 // ---- host-side weight packers (k order documented at the top) ---------------
-void pack_head_s0(const float *w, float *dst) {
-    // dst[lane][s] = W[ci = 8*g + s][co = m],  lane = (g<<5)|m, W is [16][32]
-    for (int lane = 0; lane < 64; ++lane)
-        for (int s = 0; s < 8; ++s) dst[lane * 8 + s] = w[(8 * (lane >> 5) + s) * 32 + (lane & 31)];
+void pack_sq(const float *w, int cin, float *dst) {
+    // W is [cin][32].  dst[j][lane][i] = W[ci = 8j + 4g + i][co = m],  lane = (g<<5)|m
+    for (int j = 0; j < cin / 8; ++j)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int i = 0; i < 4; ++i)
+                dst[(j * 64 + lane) * 4 + i] = w[(8 * j + 4 * (lane >> 5) + i) * 32 + (lane & 31)];
 }
 
-void pack_head_o0(const float *w, float *dst) {
-    // W is [160][64].  dst[level][cb][q4][lane][i], k-step s = 4*q4 + i:
-    //   level 0 : ci = rowmap(s, g)              (B operand = same_dim0 accumulator)
-    //   level l : ci = 32*l + 16*g + s            (B operand = gathered f[s])
-    for (int l = 0; l < 5; ++l)
-        for (int cb = 0; cb < 2; ++cb)
-            for (int q4 = 0; q4 < 4; ++q4)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int i = 0; i < 4; ++i) {
-                        const int s = 4 * q4 + i, g = lane >> 5, m = lane & 31;
-                        const int ci = (l == 0) ? rowmap(s, g) : 32 * l + 16 * g + s;
-                        dst[((((l * 2 + cb) * 4 + q4) * 64 + lane) * 4) + i] = w[ci * 64 + cb * 32 + m];
-                    }
-}
-
-void pack_head_o1(const float *w, float *dst) {
-    // W is [64][64].  dst[kb][cb][q4][lane][i]: ci = 32*kb + rowmap(4*q4+i, g), co = 32*cb + m
-    for (int kb = 0; kb < 2; ++kb)
-        for (int cb = 0; cb < 2; ++cb)
-            for (int q4 = 0; q4 < 4; ++q4)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int i = 0; i < 4; ++i) {
-                        const int s = 4 * q4 + i, g = lane >> 5, m = lane & 31;
-                        dst[((((kb * 2 + cb) * 4 + q4) * 64 + lane) * 4) + i] = w[(32 * kb + rowmap(s, g)) * 64 + cb * 32 + m];
-                    }
+void pack_rowmap_32x64(const float *w, int ld, float *dst) {
+    // W is 32 rows (k) x 64 cols (cout), row stride ld.  dst[cb][q4][lane][i]:
+    //   k = rowmap(4*q4 + i, g), co = 32*cb + m   (B operand = a 32-row accumulator tile)
+    for (int cb = 0; cb < 2; ++cb)
+        for (int q4 = 0; q4 < 4; ++q4)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 4; ++i) {
+                    const int g = lane >> 5, m = lane & 31;
+                    dst[(((cb * 4 + q4) * 64 + lane) * 4) + i] = w[rowmap(4 * q4 + i, g) * ld + cb * 32 + m];
+                }
 }
 
 void pack_head_lg(const float *w, int n_class, float *dst) {
