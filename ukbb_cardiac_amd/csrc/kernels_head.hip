@@ -25,6 +25,8 @@
 // lanes 32-63, and the weights are packed on the host in that k order.
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace ukbb {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -39,14 +41,22 @@ __host__ __device__ __forceinline__ constexpr int rowmap(int r, int g) {
 
 __device__ __forceinline__ f32x4 ldg4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 
-// acc[4j+i] = relu(acc[4j+i] + bias[8j + 4g + i])
-__device__ __forceinline__ void bias_relu(f32x16 &acc, const float *bias, int g) {
+// Accumulator tile pre-loaded with the bias of its 16 rows: acc[4j+i] = bias[8j + 4g + i].
+// Used as the C operand of the first MFMA of a chain, so the bias add costs no VALU op.
+__device__ __forceinline__ f32x16 bias_tile(const float *bias, int g) {
+    f32x16 acc;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const f32x4 b = ldg4(bias + 8 * j + 4 * g);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[4 * j + i] = fmaxf(acc[4 * j + i] + b[i], 0.f);
+        for (int i = 0; i < 4; ++i) acc[4 * j + i] = b[i];
     }
+    return acc;
+}
+
+__device__ __forceinline__ void relu16(f32x16 &acc) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);
 }
 
 // D0/D1 (two Cout blocks of 32) += W[64][32 rows of X] * X, X given as an accumulator tile.
@@ -64,6 +74,16 @@ __device__ __forceinline__ void chain_32to64(const float *wp, int lane, const f3
     }
 }
 
+// D (one Cout block of 32) += W[32 couts][32 rows of X] * X.  wp: packed [q4][lane][4] of that block.
+__device__ __forceinline__ void chain_32to32(const float *wp, int lane, const f32x16 &X, f32x16 &D) {
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+        const f32x4 w = ldg4(wp + (q4 * 64 + lane) * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) D = MFMA32(w[i], X[4 * q4 + i], D);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // sqg_kernel: G[px][64] = W0_l (64x32) * relu(Ws (32xCIN) * x[px] + bs)   at low resolution.
 // One wave per 32 consecutive pixels of the flattened [N*H_l*W_l] map; no LDS.
@@ -77,9 +97,7 @@ __global__ __launch_bounds__(256) void sqg_kernel(const SqgArgs a) {
         const long long q = blk * 32 + p;
         const bool valid = q < a.npix;
         const float *xp = a.x + (valid ? q : a.npix - 1) * CIN + 4 * g;
-        f32x16 S;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) S[r] = 0.f;
+        f32x16 S = bias_tile(a.b_s, g);
         // k-step (j,i) pairs channels 8j+i (lanes 0-31) and 8j+4+i (lanes 32-63)
 #pragma unroll 4
         for (int j = 0; j < CIN / 8; ++j) {
@@ -88,7 +106,7 @@ __global__ __launch_bounds__(256) void sqg_kernel(const SqgArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) S = MFMA32(wv[i], xv[i], S);
         }
-        bias_relu(S, a.b_s, g);
+        relu16(S);
         f32x16 G0, G1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { G0[r] = 0.f; G1[r] = 0.f; }
@@ -141,8 +159,8 @@ __host__ __device__ constexpr int win_base(int l) { return l == 1 ? 0 : l == 2 ?
 constexpr int GPIX = 142;
 constexpr int HEAD_LDS_FLOATS = GPIX * GSTRIDE;
 
-template <int NCLS>
-__global__ __launch_bounds__(256, 2) void fcn_head_kernel(const HeadArgs a) {
+template <int NCLS, int OCC>
+__global__ __launch_bounds__(256, OCC) void fcn_head_kernel(const HeadArgs a) {
     extern __shared__ __attribute__((aligned(16))) float gl[];   // [GPIX][GSTRIDE]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int p = lane & 31, g = lane >> 5;
@@ -189,24 +207,8 @@ __global__ __launch_bounds__(256, 2) void fcn_head_kernel(const HeadArgs a) {
         const int y = y0 + yl, x = x0 + xl;
         const size_t q = ((size_t)n * a.H + y) * a.W + x;
 
-        // ---- same_dim0: S[32][px] = Ws0[32][16] * conv0[16][px] -----------------------------
-        f32x16 S;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) S[r] = 0.f;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const f32x4 xv = ldg4(a.conv0 + q * 16 + 8 * j + 4 * g);
-            const f32x4 wv = ldg4(a.w_s0 + (j * 64 + lane) * 4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) S = MFMA32(wv[i], xv[i], S);
-        }
-        bias_relu(S, a.b_s0, g);
-        // ---- out0, level-0 slice: P[64][px] = W0_0[64][32] * S ---------------------------------
-        f32x16 P0, P1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { P0[r] = 0.f; P1[r] = 0.f; }
-        chain_32to64(a.w_o0, lane, S, P0, P1);
-        // ---- + sum_l up_l(G_l): <= 2x2 taps per level from LDS ------------------------------------
+        // ---- out0 = bias + sum_l up_l(G_l) [<= 2x2 taps per level, from LDS] + W0_0[64][32] * S -------
+        f32x16 P0 = bias_tile(a.b_o0, g), P1 = bias_tile(a.b_o0 + 32, g);
 #pragma unroll
         for (int l = 1; l <= 4; ++l) {
             const int f = 1 << l, pb = (f - 1) >> 1;
@@ -228,21 +230,30 @@ __global__ __launch_bounds__(256, 2) void fcn_head_kernel(const HeadArgs a) {
                 const f32x4 c10 = *reinterpret_cast<const f32x4 *>(b10 + 32 + 8 * j), c11 = *reinterpret_cast<const f32x4 *>(b11 + 32 + 8 * j);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    P0[4 * j + i] += w00 * a00[i] + w01 * a01[i] + w10 * a10[i] + w11 * a11[i];
-                    P1[4 * j + i] += w00 * c00[i] + w01 * c01[i] + w10 * c10[i] + w11 * c11[i];
+                    P0[4 * j + i] = fmaf(w00, a00[i], fmaf(w01, a01[i], fmaf(w10, a10[i], fmaf(w11, a11[i], P0[4 * j + i]))));
+                    P1[4 * j + i] = fmaf(w00, c00[i], fmaf(w01, c01[i], fmaf(w10, c10[i], fmaf(w11, c11[i], P1[4 * j + i]))));
                 }
             }
         }
-        // ---- out0 bias + ReLU ; out1: Q[64][px] = W1[64][64] * X[64][px] ------------------------------
-        bias_relu(P0, a.b_o0, g);
-        bias_relu(P1, a.b_o0 + 32, g);
-        f32x16 Q0, Q1;
+        // ---- same_dim0: S[32][px] = Ws0[32][16] * conv0[16][px] -----------------------------
+        f32x16 S = bias_tile(a.b_s0, g);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { Q0[r] = 0.f; Q1[r] = 0.f; }
+        for (int j = 0; j < 2; ++j) {
+            const f32x4 xv = ldg4(a.conv0 + q * 16 + 8 * j + 4 * g);
+            const f32x4 wv = ldg4(a.w_s0 + (j * 64 + lane) * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) S = MFMA32(wv[i], xv[i], S);
+        }
+        relu16(S);
+        chain_32to64(a.w_o0, lane, S, P0, P1);
+        relu16(P0);
+        relu16(P1);
+        // ---- out1: Q[64][px] = b1 + W1[64][64] * X[64][px] ------------------------------------------------
+        f32x16 Q0 = bias_tile(a.b_o1, g), Q1 = bias_tile(a.b_o1 + 32, g);
         chain_32to64(a.w_o1, lane, P0, Q0, Q1);               // k rows 0..31
         chain_32to64(a.w_o1 + 2 * 4 * 64 * 4, lane, P1, Q0, Q1);   // k rows 32..63
-        bias_relu(Q0, a.b_o1, g);
-        bias_relu(Q1, a.b_o1 + 32, g);
+        relu16(Q0);
+        relu16(Q1);
         // ---- logits on the vector ALU: each lane holds 32 of the 64 channels --------------------------
         // w_lg layout: [g][c][32] with index cb*16 + r  <->  channel cb*32 + rowmap(r, g)
         float lg[NCLS];
@@ -287,19 +298,28 @@ __global__ __launch_bounds__(256, 2) void fcn_head_kernel(const HeadArgs a) {
     }
 }
 
-hipError_t launch_head(const HeadArgs &a, hipStream_t s) {
-    if ((a.H % HT) || (a.W % HT)) return hipErrorInvalidValue;
+template <int OCC>
+static hipError_t launch_head_occ(const HeadArgs &a, hipStream_t s) {
     dim3 grid((unsigned)(a.N * (a.H / HT) * (a.W / HT))), block(256);
     const size_t lds = HEAD_LDS_FLOATS * sizeof(float);
     switch (a.n_class) {
-        case 2: hipLaunchKernelGGL(fcn_head_kernel<2>, grid, block, lds, s, a); break;
-        case 3: hipLaunchKernelGGL(fcn_head_kernel<3>, grid, block, lds, s, a); break;
-        case 4: hipLaunchKernelGGL(fcn_head_kernel<4>, grid, block, lds, s, a); break;
-        case 5: hipLaunchKernelGGL(fcn_head_kernel<5>, grid, block, lds, s, a); break;
-        case 6: hipLaunchKernelGGL(fcn_head_kernel<6>, grid, block, lds, s, a); break;
+        case 2: hipLaunchKernelGGL((fcn_head_kernel<2, OCC>), grid, block, lds, s, a); break;
+        case 3: hipLaunchKernelGGL((fcn_head_kernel<3, OCC>), grid, block, lds, s, a); break;
+        case 4: hipLaunchKernelGGL((fcn_head_kernel<4, OCC>), grid, block, lds, s, a); break;
+        case 5: hipLaunchKernelGGL((fcn_head_kernel<5, OCC>), grid, block, lds, s, a); break;
+        case 6: hipLaunchKernelGGL((fcn_head_kernel<6, OCC>), grid, block, lds, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
+}
+
+hipError_t launch_head(const HeadArgs &a, hipStream_t s) {
+    if ((a.H % HT) || (a.W % HT)) return hipErrorInvalidValue;
+    const HeadArgs &b = a;
+    static const int occ = [] { const char *e = getenv("UKBB_HEAD_OCC"); return e ? atoi(e) : 3; }();   // tuning knob
+    if (occ == 2) return launch_head_occ<2>(b, s);
+    if (occ == 4) return launch_head_occ<4>(b, s);
+    return launch_head_occ<3>(b, s);
 }
 
 // ---- host-side weight packers (k order documented at the top) ---------------
