@@ -8,18 +8,18 @@
 //   per lane, 4 consecutive output channels of ONE pixel: NHWC float4 stores.
 //
 // Data movement per workgroup (256 threads = 4 waves):
-//   * the input halo tile of KC channels is staged once into LDS in PLANAR
-//     form lds[ci][halo pixel] (transposed on the fly from NHWC float4 loads);
-//     every one of the 9 taps then re-reads it with plain ds_read_b32 whose
-//     address is lane_base + compile-time immediate (tap shift, channel plane),
-//     conflict-free because the 16/32 pixel lanes of a fragment are adjacent.
+//   * the input halo tile of KC channels is staged once into LDS as
+//     xs[halo pixel][KC + 4 pad] (straight float4 copies of the NHWC rows); every one
+//     of the 9 taps then re-reads it with ONE ds_read_b128/b64 per pixel block that
+//     returns the lane's B operands for KC/NG consecutive k-steps (the k order is
+//     permuted so that lane group g owns channels g*KC/NG ...; the weights are packed
+//     to match).  Address = lane_base + compile-time immediate (tap shift).
 //   * weights are pre-packed on the host in A-fragment order, so a lane reads
 //     its KC/KK k-steps of one tap as one 16/32-byte global load (L1/L2 hits:
 //     every workgroup of a layer streams the same few KB).
-// The f32 MFMA rate equals the vector rate (64 FLOP/clk/SIMD) and one
-// 32x32x2 issue takes 64 cycles, so one LDS read + 1/8 global load per MFMA
-// leaves the matrix pipe as the only bound; there is nothing to gain from
-// wider LDS reads here (MI355X_MICROARCH.md, "Matrix cores").
+// The f32 MFMA rate equals the vector rate (64 FLOP/clk/SIMD); with one LDS read per
+// 4-8 MFMAs the matrix pipe is the only bound (r01 PMC: the earlier planar/ds_read_b32
+// layout spent 44 % of its LDS cycles in bank conflicts, profiles/r01_pmc_summary_head2.csv).
 #include "kernels.h"
 
 namespace ukbb {
@@ -45,18 +45,15 @@ template <> struct Mfma<16> {
     }
 };
 
-__host__ __device__ constexpr int plane_pad(int hp) {
-    // plane stride == 2 (mod 8): the 4 transposing ds_write_b32 of a staging
-    // float4 then land on distinct bank octets (at worst a free 2-way conflict).
-    int p = hp;
-    while ((p & 7) != 2) ++p;
-    return p;
+__host__ __device__ constexpr int xs_stride(int kc) {
+    // floats per staged halo pixel: KC channels + 4 pad, so the 16-byte reads of the 16 lanes
+    // of a ds_read_b128 group (consecutive pixels) fall on distinct bank quads (5p mod 16).
+    return kc + 4;
 }
 
 __host__ __device__ constexpr int conv_lds_bytes(int ks, int s, int mb, int th, int tw, int kc, int wm, int cb) {
-    const int xs = kc * plane_pad(((th - 1) * s + ks) * ((tw - 1) * s + ks));
-    const int xs_al = xs + ((4 - xs % 4) % 4);
-    return (xs_al + wm * cb * ks * ks * 64 * (kc / (mb == 32 ? 2 : 4))) * 4;
+    const int xs = xs_stride(kc) * ((th - 1) * s + ks) * ((tw - 1) * s + ks);
+    return (xs + wm * cb * ks * ks * 64 * (kc / (mb == 32 ? 2 : 4))) * 4;
 }
 
 __host__ __device__ constexpr int conv_min_waves(int ks, int s, int mb, int th, int tw, int kc, int wm, int wn, int cb) {
@@ -91,7 +88,7 @@ __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM,
     constexpr int KK = M::KK, KSTEPS = KC / KK, PB = MB;
     constexpr int NPIX = TH * TW, NPB = (NPIX + PB - 1) / PB, PBW = (NPB + WN - 1) / WN;
     constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
-    constexpr int HP = IH * IW, PLANE = plane_pad(HP), C4 = KC / 4, KS2 = KS * KS;
+    constexpr int HP = IH * IW, XS = xs_stride(KC), C4 = KC / 4, KS2 = KS * KS;
     constexpr int NCBL = WM * CB;                       // Cout blocks per workgroup
     constexpr int SLAB = KS2 * 64 * KSTEPS;             // packed weights of one Cout block, one chunk
     constexpr int NIT = (HP * C4 + 255) / 256;          // activation float4 per thread per chunk
@@ -103,8 +100,8 @@ __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM,
     static_assert(KSTEPS == 2 || KSTEPS == 4 || KSTEPS == 8, "KSTEPS");
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *xs = lds;                                     // [KC][PLANE]   activations, planar
-    float *ws = lds + KC * PLANE + ((4 - (KC * PLANE) % 4) % 4);   // [NCBL][KS2][64][KSTEPS], 16-B aligned
+    float *xs = lds;                                     // [HP][XS]  halo pixels x (KC channels + pad)
+    float *ws = lds + HP * XS;                           // [NCBL][KS2][64][KSTEPS]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -123,7 +120,7 @@ __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM,
         int q = (wn + pb * WN) * PB + pl;
         if (q >= NPIX) q = 0;
         const int oy = q / TW, ox = q % TW;
-        lbase[pb] = g * PLANE + (oy * STRIDE) * IW + ox * STRIDE;
+        lbase[pb] = ((oy * STRIDE) * IW + ox * STRIDE) * XS + KSTEPS * g;   // lane group g owns channels g*KSTEPS..
     }
 
     Acc acc[CB][PBW];
@@ -171,14 +168,11 @@ __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM,
     UKBB_PREFETCH(0)
     for (int ch = 0; ch < nchunk; ++ch) {
         if (ch > 0) __syncthreads();                    // all waves done reading the previous chunk
-        // ---- registers -> LDS (activations transposed to planar, weights linear) ----
+        // ---- registers -> LDS (straight 16-byte copies) ----
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int pix = pix0 + it * PSTEP;
-            if (pix < HP) {
-                float *d = xs + (4 * c4) * PLANE + pix;
-                d[0] = xr[it][0]; d[PLANE] = xr[it][1]; d[2 * PLANE] = xr[it][2]; d[3 * PLANE] = xr[it][3];
-            }
+            if (pix < HP) *reinterpret_cast<f32x4 *>(xs + pix * XS + 4 * c4) = xr[it];
         }
 #pragma unroll
         for (int it = 0; it < NWT; ++it)
@@ -189,20 +183,20 @@ __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM,
 #pragma unroll 1
         for (int kh = 0; kh < KS; ++kh) {
             const float *wrow = ws + ((wm * CB) * KS2 + kh * KS) * 64 * KSTEPS + lane * KSTEPS;
-            const float *lrow = xs + kh * IW;
+            const float *lrow = xs + kh * IW * XS;
 #pragma unroll
             for (int kw = 0; kw < KS; ++kw) {
                 float av[CB][KSTEPS];
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb) VecLoad<KSTEPS>::ld(wrow + (cb * KS2 + kw) * 64 * KSTEPS, av[cb]);
 #pragma unroll
-                for (int s = 0; s < KSTEPS; ++s) {
+                for (int pb = 0; pb < PBW; ++pb) {
+                    float bv[KSTEPS];                    // B operands of this lane for all k-steps of the tap
+                    VecLoad<KSTEPS>::ld(lrow + lbase[pb] + kw * XS, bv);
 #pragma unroll
-                    for (int pb = 0; pb < PBW; ++pb) {
-                        const float b = lrow[lbase[pb] + kw + s * KK * PLANE];
+                    for (int s = 0; s < KSTEPS; ++s)
 #pragma unroll
-                        for (int cb = 0; cb < CB; ++cb) acc[cb][pb] = M::run(av[cb][s], b, acc[cb][pb]);
-                    }
+                        for (int cb = 0; cb < CB; ++cb) acc[cb][pb] = M::run(av[cb][s], bv[s], acc[cb][pb]);
                 }
             }
         }
@@ -338,8 +332,9 @@ hipError_t launch_conv(int cfg_id, const ConvArgs &a, hipStream_t s) {
 
 size_t pack_conv_weights(const float *w, int ks, int cin, int cout, int mb, int kc, int ncbl, float *dst) {
     // dst[group][chunk][cbl][tap][lane][s] = W[tap][ci][co],  cb = group*ncbl + cbl
-    //   mb = 32: lane = (g<<5)|m, ci = chunk*kc + 2*s + g, co = cb*32 + m
-    //   mb = 16: lane = (g<<4)|m, ci = chunk*kc + 4*s + g, co = cb*16 + m
+    //   k-step s of lane group g uses channel ci = chunk*kc + g*ksteps + s  (so the B operands
+    //   of a lane for all k-steps of a tap are ksteps CONSECUTIVE channels = one LDS vector read)
+    //   mb = 32: lane = (g<<5)|m (g < 2), co = cb*32 + m ;  mb = 16: lane = (g<<4)|m (g < 4), co = cb*16 + m
     // One workgroup (= one group of ncbl Cout blocks) reads, per chunk, one contiguous slab.
     const int kk = (mb == 32) ? 2 : 4, ksteps = kc / kk, ks2 = ks * ks, nchunk = cin / kc;
     size_t o = 0;
@@ -350,7 +345,7 @@ size_t pack_conv_weights(const float *w, int ks, int cin, int cout, int mb, int 
                     for (int lane = 0; lane < 64; ++lane) {
                         const int m = lane % mb, g = lane / mb;
                         for (int s = 0; s < ksteps; ++s) {
-                            const int ci = ch * kc + kk * s + g, co = (grp * ncbl + cbl) * mb + m;
+                            const int ci = ch * kc + g * ksteps + s, co = (grp * ncbl + cbl) * mb + m;
                             dst[o++] = w[((size_t)tap * cin + ci) * cout + co];
                         }
                     }
