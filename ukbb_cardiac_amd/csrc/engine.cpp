@@ -226,6 +226,7 @@ const int g_pref[] = {4, 5, 18, 3, 11, 7, 31, 23, 22, 29, 27, 26};
 
 bool cfg_valid(const ConvConfig &c, int ks, int stride, int c0, int c1, int cout) {
     if (c.ks != ks || c.stride != stride) return false;
+    if (c.lds_bytes > 160 * 1024) return false;      // LDS per CU on gfx950
     const int group = c.mb * c.cb * c.wm;
     return !(cout % group || c0 % c.kc || c1 % c.kc);
 }

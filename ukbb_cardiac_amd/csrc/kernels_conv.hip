@@ -22,6 +22,8 @@
 // layout spent 44 % of its LDS cycles in bank conflicts, profiles/r01_pmc_summary_head2.csv).
 #include "kernels.h"
 
+#include <type_traits>
+
 namespace ukbb {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -80,6 +82,15 @@ template <> struct VecLoad<8> {
     static __device__ __forceinline__ void ld(const float *p, float *d) {
         VecLoad<4>::ld(p, d); VecLoad<4>::ld(p + 4, d + 4); }
 };
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void unroll_taps(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        unroll_taps<N, I + 1>(f);
+    }
+}
 
 template <int KS, int STRIDE, int MB, int TH, int TW, int KC, int WM, int WN, int CB>
 __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM, WN, CB)) void conv_mfma_kernel(const ConvArgs a) {
@@ -144,7 +155,7 @@ __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM,
         const int iy = pix / IW, ix = pix % IW;
         const int gy = iy0 + iy, gx = ix0 + ix;
         const bool ok = pix < HP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-        goff[it] = ok ? ((n * a.H + gy) * a.W + gx) : -1;
+        goff[it] = ok ? ((n * a.H + gy) * a.W + gx) : -1;      // -1: zero padding / outside the tile
     }
 
     f32x4 xr[NIT], wr[NWT];
@@ -156,9 +167,10 @@ __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM,
         else                 { src_ = a.in1 + (ch_ * KC - a.C0); cs_ = a.C1; }                     \
         src_ += 4 * c4;                                                                            \
         _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                       \
-            f32x4 v_ = {0.f, 0.f, 0.f, 0.f};                                                       \
-            if (goff[it] >= 0) v_ = *reinterpret_cast<const f32x4 *>(src_ + (size_t)goff[it] * cs_);  \
-            xr[it] = v_;                                                                           \
+            /* unconditional load from a clamped address: a branch around the load makes hipcc  */ \
+            /* wait for it at the join, which would serialise the prefetch with the MFMA phase; */ \
+            /* padding pixels are zeroed when the registers are written to LDS instead.          */ \
+            xr[it] = *reinterpret_cast<const f32x4 *>(src_ + (size_t)(goff[it] < 0 ? 0 : goff[it]) * cs_); \
         }                                                                                          \
         const float *wp_ = wsrc + (size_t)ch_ * (NCBL * SLAB);                                     \
         _Pragma("unroll") for (int it = 0; it < NWT; ++it)                                         \
@@ -172,33 +184,47 @@ __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM,
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int pix = pix0 + it * PSTEP;
-            if (pix < HP) *reinterpret_cast<f32x4 *>(xs + pix * XS + 4 * c4) = xr[it];
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            if (pix < HP) *reinterpret_cast<f32x4 *>(xs + pix * XS + 4 * c4) = goff[it] < 0 ? zero4 : xr[it];
         }
 #pragma unroll
         for (int it = 0; it < NWT; ++it)
             if (it * 256 + tid < WF4) *reinterpret_cast<f32x4 *>(ws + it * 1024 + 4 * tid) = wr[it];
         __syncthreads();
         if (ch + 1 < nchunk) UKBB_PREFETCH(ch + 1)      // in flight during the MFMA phase below
-        // ---- MFMA over the taps: A and B both from LDS ---------------------------------
-#pragma unroll 1
-        for (int kh = 0; kh < KS; ++kh) {
-            const float *wrow = ws + ((wm * CB) * KS2 + kh * KS) * 64 * KSTEPS + lane * KSTEPS;
-            const float *lrow = xs + kh * IW * XS;
-#pragma unroll
-            for (int kw = 0; kw < KS; ++kw) {
-                float av[CB][KSTEPS];
-#pragma unroll
-                for (int cb = 0; cb < CB; ++cb) VecLoad<KSTEPS>::ld(wrow + (cb * KS2 + kw) * 64 * KSTEPS, av[cb]);
-#pragma unroll
-                for (int pb = 0; pb < PBW; ++pb) {
-                    float bv[KSTEPS];                    // B operands of this lane for all k-steps of the tap
-                    VecLoad<KSTEPS>::ld(lrow + lbase[pb] + kw * XS, bv);
-#pragma unroll
-                    for (int s = 0; s < KSTEPS; ++s)
-#pragma unroll
-                        for (int cb = 0; cb < CB; ++cb) acc[cb][pb] = M::run(av[cb][s], bv[s], acc[cb][pb]);
-                }
+        // ---- MFMA over the taps: A and B both from LDS, software-pipelined by one tap:
+        //      the LDS reads of tap t+1 are issued before the MFMAs of tap t (two register sets,
+        //      statically indexed because the tap loop is fully unrolled).
+        {
+            const float *wbase = ws + (wm * CB) * KS2 * 64 * KSTEPS + lane * KSTEPS;
+            float av[2][CB][KSTEPS], bv[2][PBW][KSTEPS];
+#define UKBB_LOAD_TAP(T, SET)                                                                       \
+            {                                                                                      \
+                constexpr int kh_ = (T) / KS, kw_ = (T) % KS;                                      \
+                _Pragma("unroll") for (int cb = 0; cb < CB; ++cb)                                  \
+                    VecLoad<KSTEPS>::ld(wbase + (cb * KS2 + (T)) * 64 * KSTEPS, av[SET][cb]);      \
+                _Pragma("unroll") for (int pb = 0; pb < PBW; ++pb)                                 \
+                    VecLoad<KSTEPS>::ld(xs + lbase[pb] + (kh_ * IW + kw_) * XS, bv[SET][pb]);      \
             }
+            UKBB_LOAD_TAP(0, 0)
+            unroll_taps<KS2>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                if constexpr (t + 1 < KS2) UKBB_LOAD_TAP(t + 1, (t + 1) & 1)
+                // Pin the software pipeline: without the barriers hipcc sinks the reads of tap
+                // t+1 down to their first use (exposing the LDS latency before every MFMA group).
+                __builtin_amdgcn_sched_barrier(0);
+                // k-step outer / pixel block inner: consecutive MFMAs write different accumulators
+                // (a 16x16x4 f32 MFMA has 40 cycles dependent latency but issues every 32).
+#pragma unroll
+                for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+                    for (int pb = 0; pb < PBW; ++pb)
+#pragma unroll
+                        for (int cb = 0; cb < CB; ++cb)
+                            acc[cb][pb] = M::run(av[t & 1][cb][s], bv[t & 1][pb][s], acc[cb][pb]);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+#undef UKBB_LOAD_TAP
         }
     }
 
