@@ -36,6 +36,7 @@ struct ConvConfig {
     int kc;             // input channels staged in LDS per pass
     int wm, wn, cb;     // waves along Cout / along pixels; Cout blocks per wave
     int lds_bytes;
+    int pc;             // 1: producer/consumer persistent kernel (512 threads), 0: single-role kernel
     const char *name;
 };
 

@@ -267,6 +267,201 @@ __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM,
 }
 
 // ---------------------------------------------------------------------------
+// Producer/consumer variant (512 threads, persistent over work items):
+//   waves 0-3  "consumers": only ds_read + MFMA (+ the epilogue stores of finished items);
+//   waves 4-7  "producers": all global loads and LDS writes, one stage (= one KC-channel chunk
+//              of one item) ahead, into a double-buffered LDS.
+// One barrier per stage is the only synchronisation: at barrier #s buffer s&1 holds stage s and
+// buffer (s+1)&1 has been fully read (stage s-1), so producers may overwrite it.  The MFMA waves
+// never wait on global memory, never issue an LDS write and never compute a staging address
+// (r01 stamps: those phases cost the single-role kernel ~15 % of every workgroup's lifetime and
+// co-resident workgroups did not hide them).  A work item is (Cout group, image, tile); items
+// are walked group-major so concurrently running workgroups stream the same weight slab from L2.
+// ---------------------------------------------------------------------------
+template <int KS, int STRIDE, int MB, int TH, int TW, int KC, int WM, int WN, int CB>
+__global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
+    using M = Mfma<MB>;
+    using Acc = typename M::Acc;
+    constexpr int KK = M::KK, KSTEPS = KC / KK, PB = MB;
+    constexpr int NPIX = TH * TW, NPB = (NPIX + PB - 1) / PB, PBW = (NPB + WN - 1) / WN;
+    constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
+    constexpr int HP = IH * IW, XS = xs_stride(KC), C4 = KC / 4, KS2 = KS * KS;
+    constexpr int NCBL = WM * CB, SLAB = KS2 * 64 * KSTEPS;
+    constexpr int NIT = (HP * C4 + 255) / 256, WF4 = NCBL * SLAB / 4, NWT = (WF4 + 255) / 256;
+    constexpr int PSTEP = 256 / C4;
+    constexpr int BUF = HP * XS + NCBL * SLAB;
+    static_assert(WM * WN == 4, "4 consumer waves");
+
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 x BUF
+
+    const int nchunk = (a.C0 + a.C1) / KC;
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int per_group = a.N * tiles;
+    const int nitems = per_group * (a.Cout / (MB * NCBL));
+    const int my_items = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nstages = my_items * nchunk;
+    const bool producer = __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256;
+
+    if (producer) {
+        // ===================== producers: global -> registers -> LDS =====================
+        const int tid = threadIdx.x - 256;
+        const int c4 = tid % C4, pix0 = tid / C4;
+        int item = blockIdx.x, ch = 0;
+        int goff[NIT];
+        f32x4 xr[NIT], wr[NWT];
+        const float *wsrc = nullptr;
+        auto decode = [&]() {
+            const int grp = item / per_group, rest = item - grp * per_group;
+            const int n = rest / tiles, t = rest - n * tiles;
+            const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+            const int iy0 = ty * TH * STRIDE - a.pad_y, ix0 = tx * TW * STRIDE - a.pad_x;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int pix = pix0 + it * PSTEP;
+                const int iy = pix / IW, ix = pix % IW;
+                const int gy = iy0 + iy, gx = ix0 + ix;
+                const bool ok = pix < HP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+                goff[it] = ok ? ((n * a.H + gy) * a.W + gx) : -1;
+            }
+            wsrc = a.wpk + (size_t)grp * nchunk * (NCBL * SLAB);
+        };
+        auto load = [&]() {
+            const float *src; int cs;
+            if (ch * KC < a.C0) { src = a.in0 + ch * KC; cs = a.C0; }
+            else                { src = a.in1 + (ch * KC - a.C0); cs = a.C1; }
+            src += 4 * c4;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)     // unconditional, clamped address (no branch -> stays asynchronous)
+                xr[it] = *reinterpret_cast<const f32x4 *>(src + (size_t)(goff[it] < 0 ? 0 : goff[it]) * cs);
+            const float *wp = wsrc + (size_t)ch * (NCBL * SLAB);
+#pragma unroll
+            for (int it = 0; it < NWT; ++it)
+                wr[it] = *reinterpret_cast<const f32x4 *>((it * 256 + tid < WF4) ? wp + 4 * (it * 256 + tid) : a.wpk);
+        };
+        auto store = [&](int b) {
+            float *xs = lds + b * BUF, *ws = xs + HP * XS;
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int pix = pix0 + it * PSTEP;
+                if (pix < HP) *reinterpret_cast<f32x4 *>(xs + pix * XS + 4 * c4) = goff[it] < 0 ? zero4 : xr[it];
+            }
+#pragma unroll
+            for (int it = 0; it < NWT; ++it)
+                if (it * 256 + tid < WF4) *reinterpret_cast<f32x4 *>(ws + it * 1024 + 4 * tid) = wr[it];
+        };
+        auto advance = [&]() {
+            if (++ch == nchunk) { ch = 0; item += gridDim.x; if (item < nitems) decode(); }
+        };
+        if (nstages > 0) {
+            decode();
+            load();
+            store(0);                          // stage 0
+            if (nstages > 1) { advance(); load(); }   // stage 1 in flight
+        }
+        for (int s = 0; s < nstages; ++s) {
+            __syncthreads();                   // barrier #s
+            if (s + 1 < nstages) {
+                store((s + 1) & 1);            // registers hold stage s+1 (requested one stage ago)
+                if (s + 2 < nstages) { advance(); load(); }
+            }
+        }
+    } else {
+        // ===================== consumers: LDS -> MFMA -> global =====================
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int wm = wave / WN, wn = wave % WN;
+        const int g = lane / PB, pl = lane % PB;
+        int lbase[PBW];
+#pragma unroll
+        for (int pb = 0; pb < PBW; ++pb) {
+            int q = (wn + pb * WN) * PB + pl;
+            if (q >= NPIX) q = 0;
+            lbase[pb] = (((q / TW) * STRIDE) * IW + (q % TW) * STRIDE) * XS + KSTEPS * g;
+        }
+        int s = 0;
+        for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+            Acc acc[CB][PBW];
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int pb = 0; pb < PBW; ++pb)
+#pragma unroll
+                    for (int r = 0; r < M::NACC; ++r) acc[cb][pb][r] = 0.f;
+            for (int ch = 0; ch < nchunk; ++ch, ++s) {
+                __syncthreads();               // barrier #s: buffer s&1 holds this stage
+                const float *xs = lds + (s & 1) * BUF;
+                const float *wbase = xs + HP * XS + (wm * CB) * KS2 * 64 * KSTEPS + lane * KSTEPS;
+                float av[2][CB][KSTEPS], bv[2][PBW][KSTEPS];
+#define UKBB_LOAD_TAP(T, SET)                                                                       \
+                {                                                                                  \
+                    constexpr int kh_ = (T) / KS, kw_ = (T) % KS;                                  \
+                    _Pragma("unroll") for (int cb = 0; cb < CB; ++cb)                              \
+                        VecLoad<KSTEPS>::ld(wbase + (cb * KS2 + (T)) * 64 * KSTEPS, av[SET][cb]);  \
+                    _Pragma("unroll") for (int pb = 0; pb < PBW; ++pb)                             \
+                        VecLoad<KSTEPS>::ld(xs + lbase[pb] + (kh_ * IW + kw_) * XS, bv[SET][pb]);  \
+                }
+                UKBB_LOAD_TAP(0, 0)
+                unroll_taps<KS2>([&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+                    if constexpr (t + 1 < KS2) UKBB_LOAD_TAP(t + 1, (t + 1) & 1)
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int ks_ = 0; ks_ < KSTEPS; ++ks_)
+#pragma unroll
+                        for (int pb = 0; pb < PBW; ++pb)
+#pragma unroll
+                            for (int cb = 0; cb < CB; ++cb)
+                                acc[cb][pb] = M::run(av[t & 1][cb][ks_], bv[t & 1][pb][ks_], acc[cb][pb]);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+#undef UKBB_LOAD_TAP
+            }
+            // ---- epilogue of this item ----
+            const int grp = item / per_group, rest = item - grp * per_group;
+            const int n = rest / tiles, t = rest - n * tiles;
+            const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+            const int oy0 = ty * TH, ox0 = tx * TW;
+            const int cbg = grp * NCBL + wm * CB;
+            constexpr int NJ = M::NACC / 4;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                const int co0 = (cbg + cb) * MB + 4 * g;
+                float4 bi[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) bi[j] = *reinterpret_cast<const float4 *>(a.bias + co0 + 8 * j);
+#pragma unroll
+                for (int pb = 0; pb < PBW; ++pb) {
+                    const int q = (wn + pb * WN) * PB + pl;
+                    const int oy = oy0 + q / TW, ox = ox0 + q % TW;
+                    if (q < NPIX && oy < a.Ho && ox < a.Wo) {
+                        float *o;
+                        if (a.up2 == 0) {
+                            o = a.out + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.Cout + co0;
+                        } else {
+                            const int ph = co0 / a.up2, co = co0 % a.up2;
+                            o = a.out + ((size_t)(n * 2 * a.Ho + 2 * oy + (ph >> 1)) * (2 * a.Wo) + 2 * ox + (ph & 1)) * a.up2 + co;
+                        }
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) {
+                            float4 v;
+                            v.x = acc[cb][pb][4 * j + 0] + bi[j].x;
+                            v.y = acc[cb][pb][4 * j + 1] + bi[j].y;
+                            v.z = acc[cb][pb][4 * j + 2] + bi[j].z;
+                            v.w = acc[cb][pb][4 * j + 3] + bi[j].w;
+                            if (a.relu) {
+                                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+                                v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                            }
+                            *reinterpret_cast<float4 *>(o + 8 * j) = v;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Compiled tilings.  X(id, KS, STRIDE, MB, TH, TW, KC, WM, WN, CB)
 // ---------------------------------------------------------------------------
 #define UKBB_CONV_CONFIGS(X)                         \
@@ -320,10 +515,31 @@ __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM,
 
 #define UKBB_CFG_ENTRY(ID, KS, S, MB, TH, TW, KC, WM, WN, CB)                                   \
     {ID, KS, S, MB, TH, TW, KC, WM, WN, CB,                                                     \
-     conv_lds_bytes(KS, S, MB, TH, TW, KC, WM, CB),                                             \
+     conv_lds_bytes(KS, S, MB, TH, TW, KC, WM, CB), 0,                                          \
      "conv" #KS "x" #KS "s" #S "_mb" #MB "_t" #TH "x" #TW "_kc" #KC "_w" #WM "x" #WN "_cb" #CB},
+#define UKBB_PC_ENTRY(ID, KS, S, MB, TH, TW, KC, WM, WN, CB)                                    \
+    {ID, KS, S, MB, TH, TW, KC, WM, WN, CB,                                                     \
+     2 * conv_lds_bytes(KS, S, MB, TH, TW, KC, WM, CB), 1,                                      \
+     "convPC" #KS "x" #KS "s" #S "_mb" #MB "_t" #TH "x" #TW "_kc" #KC "_w" #WM "x" #WN "_cb" #CB},
 
-static const ConvConfig g_cfgs[] = {UKBB_CONV_CONFIGS(UKBB_CFG_ENTRY)};
+// Producer/consumer tilings.  Y(id, KS, STRIDE, MB, TH, TW, KC, WM, WN, CB)
+#define UKBB_PC_CONFIGS(Y)                           \
+    Y(100, 3, 1, 32, 12, 26, 16, 2, 2, 1)            \
+    Y(101, 3, 1, 16, 12, 13, 16, 4, 1, 1)            \
+    Y(102, 3, 1, 32, 12, 13, 8, 4, 1, 1)             \
+    Y(103, 3, 1, 16, 12, 26, 16, 2, 2, 1)            \
+    Y(104, 3, 1, 16, 16, 16, 16, 1, 4, 1)            \
+    Y(105, 3, 1, 16, 16, 26, 16, 1, 4, 1)            \
+    Y(106, 3, 1, 32, 12, 26, 16, 1, 4, 1)            \
+    Y(107, 3, 1, 16, 12, 13, 16, 2, 2, 2)            \
+    Y(120, 3, 2, 16, 12, 13, 16, 2, 2, 1)            \
+    Y(121, 3, 2, 16, 12, 13, 16, 4, 1, 1)            \
+    Y(122, 3, 2, 32, 12, 26, 8, 2, 2, 1)             \
+    Y(123, 3, 2, 16, 8, 16, 16, 2, 2, 1)             \
+    Y(124, 3, 2, 16, 12, 13, 8, 2, 2, 2)             \
+    Y(125, 3, 2, 16, 8, 26, 16, 2, 2, 1)
+
+static const ConvConfig g_cfgs[] = {UKBB_CONV_CONFIGS(UKBB_CFG_ENTRY) UKBB_PC_CONFIGS(UKBB_PC_ENTRY)};
 
 int num_conv_configs() { return (int)(sizeof(g_cfgs) / sizeof(g_cfgs[0])); }
 const ConvConfig &conv_config(int i) { return g_cfgs[i]; }
@@ -335,6 +551,10 @@ hipError_t launch_conv(int cfg_id, const ConvArgs &a, hipStream_t s) {
     const int group = c->mb * c->cb * c->wm;
     if (a.Cout % group || (a.C0 + a.C1) % c->kc || a.C0 % c->kc) return hipErrorInvalidValue;
     dim3 grid((unsigned)(a.N * a.tiles_y * a.tiles_x), (unsigned)(a.Cout / group), 1);
+    const long long nitems = (long long)a.N * a.tiles_y * a.tiles_x * (a.Cout / group);
+    static const int n_cu = [] { int v = 256; hipDeviceProp_t p; int d = 0;
+                                 if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) v = p.multiProcessorCount;
+                                 return v; }();
     switch (cfg_id) {
 #define UKBB_CFG_CASE(ID, KS, S, MB, TH, TW, KC, WM, WN, CB)                                    \
     case ID: {                                                                                  \
@@ -351,6 +571,24 @@ hipError_t launch_conv(int cfg_id, const ConvArgs &a, hipStream_t s) {
         break;                                                                                  \
     }
         UKBB_CONV_CONFIGS(UKBB_CFG_CASE)
+#define UKBB_PC_CASE(ID, KS, S, MB, TH, TW, KC, WM, WN, CB)                                     \
+    case ID: {                                                                                  \
+        auto k = conv_pc_kernel<KS, S, MB, TH, TW, KC, WM, WN, CB>;                             \
+        static bool attr_done = false;                                                          \
+        if (!attr_done) {                                                                       \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),               \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                               c->lds_bytes);                                   \
+            if (e != hipSuccess) return e;                                                      \
+            attr_done = true;                                                                   \
+        }                                                                                       \
+        const int per_cu = c->lds_bytes * 2 <= 160 * 1024 ? 2 : 1;                              \
+        const long long cap = (long long)n_cu * per_cu;                                         \
+        dim3 pgrid((unsigned)(nitems < cap ? nitems : cap), 1, 1);                              \
+        hipLaunchKernelGGL(k, pgrid, dim3(512), c->lds_bytes, s, a);                            \
+        break;                                                                                  \
+    }
+        UKBB_PC_CONFIGS(UKBB_PC_CASE)
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
