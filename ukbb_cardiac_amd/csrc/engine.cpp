@@ -79,6 +79,7 @@ struct Op {                    // one kernel launch of the plan
     int in0 = -1, in1 = -1;    // activation buffer ids (-1: network input / none)
     int out = -1;
     int sq[4] = {-1, -1, -1, -1};   // OP_HEAD: squeezed maps of levels 1..4
+    bool fused_first = false;       // OP_CONV: conv0_0 (C_in = 1) evaluated by this kernel's producers
     int H = 0, W = 0, Ho = 0, Wo = 0, stride = 1, pad_y = 0, pad_x = 0;
     double macs_per_image = 0; // algorithmic
     const float *wpk = nullptr, *bias = nullptr;
@@ -224,22 +225,26 @@ const Tuned g_tuned[] = {
 // Fallback preference (small tiles / high occupancy won everywhere in the sweep).
 const int g_pref[] = {4, 5, 18, 3, 11, 7, 31, 23, 22, 29, 27, 26};
 
-bool cfg_valid(const ConvConfig &c, int ks, int stride, int c0, int c1, int cout) {
+bool cfg_valid(const ConvConfig &c, int ks, int stride, int c0, int c1, int cout, bool fused_first = false) {
     if (c.ks != ks || c.stride != stride) return false;
+    if ((c.pc == 2) != fused_first) return false;
+    if (c.pc == 2 && cout != c.mb * c.cb * c.wm) return false;   // fused kernel stages its weights once: one Cout group
     if (c.lds_bytes > 160 * 1024) return false;      // LDS per CU on gfx950
     const int group = c.mb * c.cb * c.wm;
     return !(cout % group || c0 % c.kc || c1 % c.kc);
 }
 
-int choose_cfg(const std::string &layer, int ks, int stride, int c0, int c1, int cout, int Ho, int Wo, int N) {
+int choose_cfg(const std::string &layer, int ks, int stride, int c0, int c1, int cout, int Ho, int Wo, int N,
+               bool fused_first = false) {
     (void)N;
     const int forced = override_cfg(layer);
     ConvConfig fc;
     if (forced >= 0) {
         for (int i = 0; i < num_conv_configs(); ++i)
-            if (conv_config(i).id == forced && cfg_valid(conv_config(i), ks, stride, c0, c1, cout)) return forced;
+            if (conv_config(i).id == forced && cfg_valid(conv_config(i), ks, stride, c0, c1, cout, fused_first)) return forced;
     }
     (void)fc;
+    if (!fused_first)
     for (const Tuned &t : g_tuned)
         if (t.ks == ks && t.stride == stride && t.cin == c0 + c1 && t.cout == cout && t.ho == Ho && t.wo == Wo)
             for (int i = 0; i < num_conv_configs(); ++i)
@@ -248,7 +253,7 @@ int choose_cfg(const std::string &layer, int ks, int stride, int c0, int c1, int
     int best_id = -1;
     for (int i = 0; i < num_conv_configs(); ++i) {
         const ConvConfig &c = conv_config(i);
-        if (!cfg_valid(c, ks, stride, c0, c1, cout)) continue;
+        if (!cfg_valid(c, ks, stride, c0, c1, cout, fused_first)) continue;
         const int group = c.mb * c.cb * c.wm;
         const int tiles = ((Ho + c.th - 1) / c.th) * ((Wo + c.tw - 1) / c.tw);
         const int npb = (c.th * c.tw + c.mb - 1) / c.mb;
@@ -294,7 +299,7 @@ int ensure_packed(ukbb_fcn_handle *h, int layer, const ConvConfig &c, const floa
 }
 
 int add_conv(ukbb_fcn_handle *h, const std::string &lname, int in0, int in1, int c1, int H, int W, int stride,
-             int n_hint, int *out_buf) {
+             int n_hint, int *out_buf, bool fused_first = false) {
     const int li = h->layer_index.at(lname);
     const HostLayer &L = h->layers[li];
     Op op;
@@ -305,7 +310,8 @@ int add_conv(ukbb_fcn_handle *h, const std::string &lname, int in0, int in1, int
     op.pad_y = std::max((op.Ho - 1) * stride + L.ks - H, 0) / 2;
     op.pad_x = std::max((op.Wo - 1) * stride + L.ks - W, 0) / 2;
     const int c0 = L.cin - c1;
-    op.cfg = choose_cfg(lname, L.ks, stride, c0, c1, L.cout, op.Ho, op.Wo, n_hint);
+    op.fused_first = fused_first;
+    op.cfg = choose_cfg(lname, L.ks, stride, c0, c1, L.cout, op.Ho, op.Wo, n_hint, fused_first);
     if (op.cfg < 0) { set_err("no conv tiling for layer %s (ks %d stride %d cin %d+%d cout %d)", lname.c_str(), L.ks, stride, c0, c1, L.cout); return UKBB_EARCH; }
     ConvConfig c;
     find_cfg(op.cfg, c);
@@ -366,7 +372,10 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
         for (int i = 0; i < a.n_block[l]; ++i) {
             snprintf(nm, sizeof nm, "conv%d_%d", l, i);
             const int stride = (l > 0 && i == 0) ? 2 : 1;
+            static const bool no_fuse = getenv("UKBB_NO_FUSE_FIRST") != nullptr;    // A/B knob
+            const bool can_fuse = !no_fuse && a.n_block[0] >= 2 && a.n_filter[0] == 16;
             if (l == 0 && i == 0) {
+                if (can_fuse) continue;              // evaluated inside conv0_1's producers
                 Op op; op.kind = OP_FIRST; op.name = nm; op.layer = h->layer_index.at(nm);
                 op.H = op.Ho = H; op.W = op.Wo = W;
                 op.out = new_act(h, nm, (size_t)H * W * a.n_filter[0]);
@@ -375,8 +384,13 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
                 cur = op.out;
             } else {
                 int out;
-                int rc = add_conv(h, nm, cur, -1, 0, hh, ww, stride, n_hint, &out);
+                const bool fused = (l == 0 && i == 1 && can_fuse);
+                int rc = add_conv(h, nm, cur, -1, 0, hh, ww, stride, n_hint, &out, fused);
                 if (rc) return rc;
+                if (fused) {
+                    h->ops.back().name = "conv0_0+conv0_1";
+                    h->ops.back().macs_per_image += (double)H * W * 9 * a.n_filter[0];
+                }
                 cur = out;
                 if (stride == 2) { hh = (hh + 1) / 2; ww = (ww + 1) / 2; }
             }
@@ -517,7 +531,8 @@ int run_plan(ukbb_fcn_handle *h, const float *image, int n, float *logits, float
                 ConvConfig c;
                 find_cfg(op.cfg, c);
                 ConvArgs ca{};
-                ca.in0 = h->act[op.in0]->p;
+                ca.in0 = op.fused_first ? image : h->act[op.in0]->p;
+                if (op.fused_first) { ca.first_w = dev_ptr(h, "conv0_0/w"); ca.first_b = dev_ptr(h, "conv0_0/bias"); }
                 ca.in1 = op.in1 >= 0 ? h->act[op.in1]->p : nullptr;
                 ca.C1 = op.in1 >= 0 ? (int)(h->act_per_image[op.in1] / ((size_t)op.H * op.W)) : 0;
                 ca.C0 = L.cin - ca.C1;

@@ -23,6 +23,8 @@ struct ConvArgs {
     int pad_y, pad_x;   // TF 'SAME' pad_before (oracle/fcn_oracle.py same_pads)
     int tiles_y, tiles_x;
     int relu;
+    const float *first_w;   // fused first layer (conv_pc_kernel<..., FIRST>): folded conv0_0 weights [9][KC]
+    const float *first_b;   //   and bias [KC]; in0 is then the 1-channel network input [N,H,W]
     int up2;            // 0: plain conv.  C > 0: the 4*C output channels are the 4 sub-pixel phases of a
                         // stride-2 transposed conv with C real channels; scatter to out[N,2Ho,2Wo,C]
 };
@@ -36,7 +38,8 @@ struct ConvConfig {
     int kc;             // input channels staged in LDS per pass
     int wm, wn, cb;     // waves along Cout / along pixels; Cout blocks per wave
     int lds_bytes;
-    int pc;             // 1: producer/consumer persistent kernel (512 threads), 0: single-role kernel
+    int pc;             // 0: single-role kernel; 1: producer/consumer persistent kernel (512 threads);
+                        // 2: producer/consumer with the C_in = 1 first layer fused into the producers
     const char *name;
 };
 

@@ -278,7 +278,12 @@ __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM,
 // co-resident workgroups did not hide them).  A work item is (Cout group, image, tile); items
 // are walked group-major so concurrently running workgroups stream the same weight slab from L2.
 // ---------------------------------------------------------------------------
-template <int KS, int STRIDE, int MB, int TH, int TW, int KC, int WM, int WN, int CB>
+// FIRST = true fuses the network's first layer (conv3x3, C_in = 1, BN, ReLU; reference
+// common/network.py:186 with l = 0) into this conv: the producers evaluate it for every halo
+// pixel directly from the 1-channel image (9 taps x KC channels on the vector ALU, same fma
+// order as conv_first_kernel) and write the KC-channel tile to LDS, so that layer's output
+// never exists in HBM.  Halo pixels outside the image are this conv's zero padding.
+template <int KS, int STRIDE, int MB, int TH, int TW, int KC, int WM, int WN, int CB, bool FIRST = false>
 __global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
     using M = Mfma<MB>;
     using Acc = typename M::Acc;
@@ -290,11 +295,12 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
     constexpr int NIT = (HP * C4 + 255) / 256, WF4 = NCBL * SLAB / 4, NWT = (WF4 + 255) / 256;
     constexpr int PSTEP = 256 / C4;
     constexpr int BUF = HP * XS + NCBL * SLAB;
+    constexpr int RH = IH + 2, RW = IW + 2, RP = RH * RW, NRAW = (RP + 255) / 256;   // FIRST: raw image tile
     static_assert(WM * WN == 4, "4 consumer waves");
 
     extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 x BUF
 
-    const int nchunk = (a.C0 + a.C1) / KC;
+    const int nchunk = FIRST ? 1 : (a.C0 + a.C1) / KC;
     const int tiles = a.tiles_x * a.tiles_y;
     const int per_group = a.N * tiles;
     const int nitems = per_group * (a.Cout / (MB * NCBL));
@@ -325,45 +331,138 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
             }
             wsrc = a.wpk + (size_t)grp * nchunk * (NCBL * SLAB);
         };
-        auto load = [&]() {
-            const float *src; int cs;
-            if (ch * KC < a.C0) { src = a.in0 + ch * KC; cs = a.C0; }
-            else                { src = a.in1 + (ch * KC - a.C0); cs = a.C1; }
-            src += 4 * c4;
-#pragma unroll
-            for (int it = 0; it < NIT; ++it)     // unconditional, clamped address (no branch -> stays asynchronous)
-                xr[it] = *reinterpret_cast<const f32x4 *>(src + (size_t)(goff[it] < 0 ? 0 : goff[it]) * cs);
+        auto load_w = [&]() {
             const float *wp = wsrc + (size_t)ch * (NCBL * SLAB);
 #pragma unroll
             for (int it = 0; it < NWT; ++it)
                 wr[it] = *reinterpret_cast<const f32x4 *>((it * 256 + tid < WF4) ? wp + 4 * (it * 256 + tid) : a.wpk);
         };
-        auto store = [&](int b) {
-            float *xs = lds + b * BUF, *ws = xs + HP * XS;
+        auto store_w = [&](int b) {
+            float *ws = lds + b * BUF + HP * XS;
+#pragma unroll
+            for (int it = 0; it < NWT; ++it)
+                if (it * 256 + tid < WF4) *reinterpret_cast<f32x4 *>(ws + it * 1024 + 4 * tid) = wr[it];
+        };
+        auto store_x = [&](int b) {
+            float *xs = lds + b * BUF;
             const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int pix = pix0 + it * PSTEP;
                 if (pix < HP) *reinterpret_cast<f32x4 *>(xs + pix * XS + 4 * c4) = goff[it] < 0 ? zero4 : xr[it];
             }
+        };
+
+        if constexpr (FIRST) {
+            // ---- fused first layer: raw 1-channel tile (halo of the halo) -> LDS -> conv0_0 -> xs ----
+            // Stage k == item k of this workgroup (one chunk).  In the iteration after barrier #s the
+            // producers (a) turn raw tile s+1 (LDS) into the KC-channel halo tile of stage s+1,
+            // (b) park raw tile s+2 (registers, loaded one iteration ago) in LDS, (c) request raw tile s+3.
+            float *raw = lds + 2 * BUF;                        // [2][RP]
+            float w0q[9][4], b0q[4];
 #pragma unroll
-            for (int it = 0; it < NWT; ++it)
-                if (it * 256 + tid < WF4) *reinterpret_cast<f32x4 *>(ws + it * 1024 + 4 * tid) = wr[it];
-        };
-        auto advance = [&]() {
-            if (++ch == nchunk) { ch = 0; item += gridDim.x; if (item < nitems) decode(); }
-        };
-        if (nstages > 0) {
-            decode();
-            load();
-            store(0);                          // stage 0
-            if (nstages > 1) { advance(); load(); }   // stage 1 in flight
-        }
-        for (int s = 0; s < nstages; ++s) {
-            __syncthreads();                   // barrier #s
-            if (s + 1 < nstages) {
-                store((s + 1) & 1);            // registers hold stage s+1 (requested one stage ago)
-                if (s + 2 < nstages) { advance(); load(); }
+            for (int t = 0; t < 9; ++t) {
+                const f32x4 w = *reinterpret_cast<const f32x4 *>(a.first_w + t * KC + 4 * c4);
+                w0q[t][0] = w[0]; w0q[t][1] = w[1]; w0q[t][2] = w[2]; w0q[t][3] = w[3];
+            }
+            {
+                const f32x4 b = *reinterpret_cast<const f32x4 *>(a.first_b + 4 * c4);
+                b0q[0] = b[0]; b0q[1] = b[1]; b0q[2] = b[2]; b0q[3] = b[3];
+            }
+            float rr[NRAW];
+            bool rok[NRAW];
+            auto raw_load = [&](int it_item) {              // global -> registers (unconditional, clamped)
+                const int rest = it_item % per_group;
+                const int n = rest / tiles, t = rest - n * tiles;
+                const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+                const int ry0 = ty * TH - a.pad_y - 1, rx0 = tx * TW - a.pad_x - 1;
+#pragma unroll
+                for (int k = 0; k < NRAW; ++k) {
+                    const int idx = tid + 256 * k;
+                    const int ry = idx / RW, rx = idx - ry * RW;
+                    const int gy = ry0 + ry, gx = rx0 + rx;
+                    rok[k] = idx < RP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+                    rr[k] = a.in0[rok[k] ? ((size_t)(n * a.H + gy) * a.W + gx) : 0];
+                }
+            };
+            auto raw_store = [&](int b) {
+#pragma unroll
+                for (int k = 0; k < NRAW; ++k) {
+                    const int idx = tid + 256 * k;
+                    if (idx < RP) raw[b * RP + idx] = rok[k] ? rr[k] : 0.f;
+                }
+            };
+            auto first_layer = [&](int braw) {              // raw tile (LDS) -> xr[] = relu(conv0_0 + b)
+                const float *rt = raw + braw * RP;
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int pix = pix0 + it * PSTEP;
+                    const int iy = pix / IW, ix = pix % IW;
+                    const float *rp = rt + (pix < HP ? iy * RW + ix : 0);
+                    float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const float v = rp[(t / 3) * RW + (t % 3)];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc4[j] = fmaf(v, w0q[t][j], acc4[j]);
+                    }
+                    f32x4 r;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) r[j] = fmaxf(acc4[j] + b0q[j], 0.f);
+                    xr[it] = r;
+                }
+            };
+            const int step = gridDim.x;
+            if (nstages > 0) {
+                raw_load(item);
+                raw_store(0);                                  // R(0)
+                if (nstages > 1) raw_load(item + step);        // R(1) in registers
+            }
+            // single Cout group (enforced by the launcher): this conv's weights are the same for every
+            // item, so they are staged ONCE into both buffers instead of once per stage
+            decode(); load_w(); store_w(0); store_w(1);
+            __syncthreads();                                   // extra barrier: R(0) visible to all producers
+            if (nstages > 0) {
+                first_layer(0); store_x(0);                    // stage 0 complete
+                if (nstages > 1) raw_store(1);
+                if (nstages > 2) raw_load(item + 2 * step);
+            }
+            for (int s = 0; s < nstages; ++s) {
+                __syncthreads();                               // barrier #s
+                if (s + 1 < nstages) {
+                    item += step; decode();
+                    first_layer((s + 1) & 1); store_x((s + 1) & 1);
+                    if (s + 2 < nstages) raw_store(s & 1);     // R(s+2) replaces R(s)
+                    if (s + 3 < nstages) raw_load(item + 2 * step);
+                }
+            }
+        } else {
+            auto load = [&]() {
+                const float *src; int cs;
+                if (ch * KC < a.C0) { src = a.in0 + ch * KC; cs = a.C0; }
+                else                { src = a.in1 + (ch * KC - a.C0); cs = a.C1; }
+                src += 4 * c4;
+#pragma unroll
+                for (int it = 0; it < NIT; ++it)     // unconditional, clamped address (no branch -> stays asynchronous)
+                    xr[it] = *reinterpret_cast<const f32x4 *>(src + (size_t)(goff[it] < 0 ? 0 : goff[it]) * cs);
+                load_w();
+            };
+            auto store = [&](int b) { store_x(b); store_w(b); };
+            auto advance = [&]() {
+                if (++ch == nchunk) { ch = 0; item += gridDim.x; if (item < nitems) decode(); }
+            };
+            if (nstages > 0) {
+                decode();
+                load();
+                store(0);                          // stage 0
+                if (nstages > 1) { advance(); load(); }   // stage 1 in flight
+            }
+            for (int s = 0; s < nstages; ++s) {
+                __syncthreads();                   // barrier #s
+                if (s + 1 < nstages) {
+                    store((s + 1) & 1);            // registers hold stage s+1 (requested one stage ago)
+                    if (s + 2 < nstages) { advance(); load(); }
+                }
             }
         }
     } else {
@@ -379,6 +478,7 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
             lbase[pb] = (((q / TW) * STRIDE) * IW + (q % TW) * STRIDE) * XS + KSTEPS * g;
         }
         int s = 0;
+        if constexpr (FIRST) __syncthreads();          // matches the producers' raw-tile barrier
         for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
             Acc acc[CB][PBW];
 #pragma unroll
@@ -539,7 +639,20 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
     Y(124, 3, 2, 16, 12, 13, 8, 2, 2, 2)             \
     Y(125, 3, 2, 16, 8, 26, 16, 2, 2, 1)
 
-static const ConvConfig g_cfgs[] = {UKBB_CONV_CONFIGS(UKBB_CFG_ENTRY) UKBB_PC_CONFIGS(UKBB_PC_ENTRY)};
+// Producer/consumer tilings with the fused first layer (C_in = 1 -> KC, then this conv).
+#define UKBB_PCF_CONFIGS(Z)                          \
+    Z(130, 3, 1, 16, 16, 16, 16, 1, 4, 1)            \
+    Z(131, 3, 1, 16, 8, 16, 16, 1, 4, 1)             \
+    Z(132, 3, 1, 16, 16, 26, 16, 1, 4, 1)            \
+    Z(133, 3, 1, 16, 12, 16, 16, 1, 4, 1)
+
+#define UKBB_PCF_ENTRY(ID, KS, S, MB, TH, TW, KC, WM, WN, CB)                                   \
+    {ID, KS, S, MB, TH, TW, KC, WM, WN, CB,                                                     \
+     2 * conv_lds_bytes(KS, S, MB, TH, TW, KC, WM, CB) + 2 * 4 * (((TH - 1) * S + KS + 2) * ((TW - 1) * S + KS + 2)), 2, \
+     "convPCfirst" #KS "x" #KS "s" #S "_mb" #MB "_t" #TH "x" #TW "_kc" #KC "_w" #WM "x" #WN "_cb" #CB},
+
+static const ConvConfig g_cfgs[] = {UKBB_CONV_CONFIGS(UKBB_CFG_ENTRY) UKBB_PC_CONFIGS(UKBB_PC_ENTRY)
+                                    UKBB_PCF_CONFIGS(UKBB_PCF_ENTRY)};
 
 int num_conv_configs() { return (int)(sizeof(g_cfgs) / sizeof(g_cfgs[0])); }
 const ConvConfig &conv_config(int i) { return g_cfgs[i]; }
@@ -549,7 +662,11 @@ hipError_t launch_conv(int cfg_id, const ConvArgs &a, hipStream_t s) {
     for (const auto &e : g_cfgs) if (e.id == cfg_id) c = &e;
     if (!c) return hipErrorInvalidValue;
     const int group = c->mb * c->cb * c->wm;
-    if (a.Cout % group || (a.C0 + a.C1) % c->kc || a.C0 % c->kc) return hipErrorInvalidValue;
+    if (c->pc == 2) {
+        if (!a.first_w || !a.first_b || a.Cout != group) return hipErrorInvalidValue;
+    } else if (a.Cout % group || (a.C0 + a.C1) % c->kc || a.C0 % c->kc) {
+        return hipErrorInvalidValue;
+    }
     dim3 grid((unsigned)(a.N * a.tiles_y * a.tiles_x), (unsigned)(a.Cout / group), 1);
     const long long nitems = (long long)a.N * a.tiles_y * a.tiles_x * (a.Cout / group);
     static const int n_cu = [] { int v = 256; hipDeviceProp_t p; int d = 0;
@@ -589,6 +706,24 @@ hipError_t launch_conv(int cfg_id, const ConvArgs &a, hipStream_t s) {
         break;                                                                                  \
     }
         UKBB_PC_CONFIGS(UKBB_PC_CASE)
+#define UKBB_PCF_CASE(ID, KS, S, MB, TH, TW, KC, WM, WN, CB)                                    \
+    case ID: {                                                                                  \
+        auto k = conv_pc_kernel<KS, S, MB, TH, TW, KC, WM, WN, CB, true>;                       \
+        static bool attr_done = false;                                                          \
+        if (!attr_done) {                                                                       \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),               \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                               c->lds_bytes);                                   \
+            if (e != hipSuccess) return e;                                                      \
+            attr_done = true;                                                                   \
+        }                                                                                       \
+        const int per_cu = c->lds_bytes * 2 <= 160 * 1024 ? 2 : 1;                              \
+        const long long cap = (long long)n_cu * per_cu;                                         \
+        dim3 pgrid((unsigned)(nitems < cap ? nitems : cap), 1, 1);                              \
+        hipLaunchKernelGGL(k, pgrid, dim3(512), c->lds_bytes, s, a);                            \
+        break;                                                                                  \
+    }
+        UKBB_PCF_CONFIGS(UKBB_PCF_CASE)
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
