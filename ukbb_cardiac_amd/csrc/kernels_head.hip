@@ -26,6 +26,7 @@
 #include "kernels.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace ukbb {
 
@@ -298,6 +299,322 @@ __global__ __launch_bounds__(256, OCC) void fcn_head_kernel(const HeadArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Producer/consumer head (768 threads, persistent over 16x16 tiles, one workgroup per CU):
+//   waves 4-11 "producers": stage the G windows of upcoming tiles (global -> registers -> LDS,
+//       double buffered per tile) and evaluate, for the 32-pixel block their partner wave will
+//       process next, out0's pre-activation  b0 + sum_l up_l(G_l)  (all VALU + LDS work), which
+//       they hand over through LDS as a ready accumulator tile (8 float4 per lane, laid out
+//       [slot][lane] so both sides touch consecutive 16-byte words);
+//   waves 0-3 "consumers": same_dim0 (8 MFMA) -> out0 level-0 slice accumulated ONTO the handed
+//       tile (32 MFMA) -> ReLU -> out1 (64 MFMA) -> ReLU -> logits / softmax / argmax.
+// A stage = one block per consumer wave (2 stages per tile); one barrier per stage.
+// r01 measurements behind this split: in the single-role kernel the gather (VALU+LDS), the G
+// staging and the MFMA chains simply added up (ablation: 76 + 63 + 40%..) because every wave
+// ran them back to back and at most 3 waves fit per SIMD.
+// ---------------------------------------------------------------------------
+constexpr int PX_WAVE = 8 * 64 * 4;                    // floats of one handed-over tile (64 ch x 32 px)
+// LDS map of fcn_head_pc_kernel (floats)
+constexpr int L_GW = 0;                                // [2][GPIX][GSTRIDE]  G windows, double buffered per tile
+constexpr int L_PX = L_GW + 2 * GPIX * GSTRIDE;        // [4][PX_WAVE]        hand-over tiles (single buffered)
+constexpr int L_WS0 = L_PX + 4 * PX_WAVE;              // pack_sq(same_dim0)           512
+constexpr int L_WO0 = L_WS0 + 512;                     // pack_rowmap(out0 rows 0..31) 2048
+constexpr int L_WO1 = L_WO0 + 2048;                    // pack_rowmap(out1) x2         4096
+constexpr int L_BS0 = L_WO1 + 4096;                    // 32
+constexpr int L_BO0 = L_BS0 + 32;                      // 64
+constexpr int L_BO1 = L_BO0 + 64;                      // 64
+constexpr int L_WLG = L_BO1 + 64;                      // [2][NCLS][32] <= 384
+constexpr int L_BLG = L_WLG + 384;                     // <= 8
+constexpr int HEADPC_LDS_FLOATS = L_BLG + 8;
+
+__device__ __forceinline__ f32x4 lds4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void unroll_n(F &&f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); unroll_n<N, I + 1>(f); }
+}
+
+__device__ __forceinline__ f32x16 bias_tile_lds(const float *bias, int g) {
+    f32x16 acc;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x4 b = lds4(bias + 8 * j + 4 * g);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[4 * j + i] = b[i];
+    }
+    return acc;
+}
+
+__device__ __forceinline__ void chain_32to64_lds(const float *wp, int lane, const f32x16 &X, f32x16 &D0, f32x16 &D1) {
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+        const f32x4 wa = lds4(wp + ((0 * 4 + q4) * 64 + lane) * 4);
+        const f32x4 wb = lds4(wp + ((1 * 4 + q4) * 64 + lane) * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            D0 = MFMA32(wa[i], X[4 * q4 + i], D0);
+            D1 = MFMA32(wb[i], X[4 * q4 + i], D1);
+        }
+    }
+}
+
+template <int NCLS>
+__global__ __launch_bounds__(768) void fcn_head_pc_kernel(const HeadArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *gw = lds + L_GW;
+    float *px = lds + L_PX;
+    const int tiles_x = a.W / HT, tiles_y = a.H / HT;
+    const int ntiles = a.N * tiles_y * tiles_x;
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nstages = 2 * my_tiles;
+    const bool producer = __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256;
+    const int lane = threadIdx.x & 63, p = lane & 31, g = lane >> 5;
+
+    // ---- every weight / bias of the head lives in LDS for the lifetime of the workgroup ----
+    {
+        const int t = threadIdx.x;
+        auto copy = [&](int dst, const float *src, int nfloat) {
+            for (int i = t; i < nfloat; i += 768) lds[dst + i] = src[i];
+        };
+        copy(L_WS0, a.w_s0, 512); copy(L_WO0, a.w_o0, 2048); copy(L_WO1, a.w_o1, 4096);
+        copy(L_BS0, a.b_s0, 32);  copy(L_BO0, a.b_o0, 64);   copy(L_BO1, a.b_o1, 64);
+        copy(L_WLG, a.w_lg, 2 * NCLS * 32); copy(L_BLG, a.b_lg, NCLS);
+    }
+
+    if (producer) {
+        // 8 producer waves: waves 4-7 build channels 0..31 of the hand-over tile of consumer wave pw,
+        // waves 8-11 channels 32..63 (the gather is the longest per-stage job; halving it per wave keeps
+        // the producers ahead of the MFMA waves).  All 512 producer threads share the window staging.
+        const int tid = threadIdx.x - 256, pw = (tid >> 6) & 3, half = tid >> 8;
+        // Staging index space: every iteration (512 threads = 32 source pixels x 16 float4) belongs to ONE
+        // level, so level, window width and the row/column split are compile-time per iteration:
+        // l=1: 81 px -> 3 iterations, l=2: 36 -> 2, l=3: 16 -> 1, l=4: 9 -> 1.
+        constexpr int NIT = 7;
+        f32x4 gv[NIT];
+        const int sp32 = tid >> 4, c4 = tid & 15;
+        auto g_load = [&](int k) {                      // G windows of this workgroup's k-th tile -> registers
+            int bid = blockIdx.x + k * gridDim.x;
+            const int tx = bid % tiles_x; bid /= tiles_x;
+            const int ty = bid % tiles_y;
+            const int n = bid / tiles_y;
+            const int y0 = ty * HT, x0 = tx * HT;
+            unroll_n<NIT>([&](auto ic) {
+                constexpr int it = decltype(ic)::value;
+                constexpr int l = it < 3 ? 1 : it < 5 ? 2 : it < 6 ? 3 : 4;
+                constexpr int it0 = l == 1 ? 0 : l == 2 ? 3 : l == 3 ? 5 : 6;
+                constexpr int wn_ = win_n(l);
+                const int rel = (it - it0) * 32 + sp32;
+                const int ry = rel / wn_, rx = rel - ry * wn_;
+                const int hl = a.H >> l, wl = a.W >> l;
+                const int sy = (y0 >> l) - 1 + ry, sx = (x0 >> l) - 1 + rx;
+                const bool ok = rel < wn_ * wn_ && (unsigned)sy < (unsigned)hl && (unsigned)sx < (unsigned)wl;
+                // unconditional load from a clamped address (keeps the prefetch asynchronous);
+                // out-of-map taps become zeros (border taps are dropped)
+                const f32x4 t = ldg4(a.G[l - 1] + (ok ? (((size_t)n * hl + sy) * wl + sx) * 64 + 4 * c4 : 0));
+                gv[it] = ok ? t : f32x4{0.f, 0.f, 0.f, 0.f};
+            });
+        };
+        auto g_store = [&](int b) {
+            float *dst = gw + b * GPIX * GSTRIDE;
+            unroll_n<NIT>([&](auto ic) {
+                constexpr int it = decltype(ic)::value;
+                constexpr int l = it < 3 ? 1 : it < 5 ? 2 : it < 6 ? 3 : 4;
+                constexpr int it0 = l == 1 ? 0 : l == 2 ? 3 : l == 3 ? 5 : 6;
+                const int rel = (it - it0) * 32 + sp32;
+                if (rel < win_n(l) * win_n(l))
+                    *reinterpret_cast<f32x4 *>(dst + (win_base(l) + rel) * GSTRIDE + 4 * c4) = gv[it];
+            });
+        };
+        f32x16 P;
+        auto gather = [&](int s) {                      // stage s: tile k = s>>1, block 2*pw + (s&1)  -> P (32 channels)
+            const float *gl = gw + ((s >> 1) & 1) * GPIX * GSTRIDE + 32 * half;
+            const int blk = pw * 2 + (s & 1);
+            const int yl = 2 * blk + (p >> 4), xl = p & 15;
+            P = bias_tile_lds(lds + L_BO0 + 32 * half, g);
+#pragma unroll
+            for (int l = 1; l <= 4; ++l) {
+                const int f = 1 << l, pb = (f - 1) >> 1;
+                const float inv = 1.0f / (float)f;
+                const int tyy = yl + pb, txx = xl + pb;
+                const int ry1 = (tyy >> l) + 1, rx1 = (txx >> l) + 1;
+                const int jy = tyy & (f - 1), jx = txx & (f - 1);
+                const float wy1 = (float)(jy + 1) * inv, wy0 = (float)(f - 1 - jy) * inv;
+                const float wx1 = (float)(jx + 1) * inv, wx0 = (float)(f - 1 - jx) * inv;
+                const int wn_ = win_n(l);
+                const float *b11 = gl + (win_base(l) + ry1 * wn_ + rx1) * GSTRIDE + 4 * g;
+                const float *b10 = b11 - GSTRIDE, *b01 = b11 - wn_ * GSTRIDE, *b00 = b01 - GSTRIDE;
+                const float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 a00 = lds4(b00 + 8 * j), a01 = lds4(b01 + 8 * j), a10 = lds4(b10 + 8 * j), a11 = lds4(b11 + 8 * j);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        P[4 * j + i] = fmaf(w00, a00[i], fmaf(w01, a01[i], fmaf(w10, a10[i], fmaf(w11, a11[i], P[4 * j + i]))));
+                }
+            }
+        };
+        auto hand_over = [&]() {                        // P -> px[pw]  ([slot][lane] float4 image)
+            float *dst = px + pw * PX_WAVE + (4 * half) * 256 + lane * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = P[4 * j + i];
+                *reinterpret_cast<f32x4 *>(dst + j * 256) = v;
+            }
+        };
+        // prologue: windows of tiles 0 and 1 into LDS, tile 2 stays in registers until GW[0] is free
+#pragma unroll 1
+        for (int k = 0; k < 3; ++k) {
+            if (k < my_tiles) {
+                g_load(k);
+                if (k < 2) g_store(k);
+            }
+        }
+        __syncthreads();                                // barrier X: weights, GW[0], GW[1] visible
+#pragma unroll 1
+        for (int s = 0; s < nstages; ++s) {
+            gather(s);                                  // LDS windows -> registers (consumers still busy with s-1)
+            hand_over();                                // px was released at barrier B of stage s-1
+            __syncthreads();                            // barrier A_s: px ready
+            __syncthreads();                            // barrier B_s: px consumed
+            if (s & 1) {                                // tile k = s>>1 fully gathered: its window buffer is free
+                const int k = s >> 1;
+                if (k + 2 < my_tiles) g_store(k & 1);   // G(k+2), requested two stages ago
+                if (k + 3 < my_tiles) g_load(k + 3);
+            }
+        }
+    } else {
+        const int wave = threadIdx.x >> 6;
+        const float *w_s0 = lds + L_WS0, *w_o0 = lds + L_WO0, *w_o1 = lds + L_WO1, *w_lg = lds + L_WLG;
+        auto pixel_of = [&](int s) -> size_t {
+            int bid = blockIdx.x + (s >> 1) * gridDim.x;
+            const int tx = bid % tiles_x; bid /= tiles_x;
+            const int ty = bid % tiles_y;
+            const int n = bid / tiles_y;
+            const int blk = wave * 2 + (s & 1);
+            const int y = ty * HT + 2 * blk + (p >> 4), x = tx * HT + (p & 15);
+            return ((size_t)n * a.H + y) * a.W + x;
+        };
+        f32x4 xv0 = {0.f, 0.f, 0.f, 0.f}, xv1 = xv0;      // conv0 features of the NEXT block, prefetched
+        if (nstages > 0) {
+            const size_t q0 = pixel_of(0);
+            xv0 = ldg4(a.conv0 + q0 * 16 + 4 * g);
+            xv1 = ldg4(a.conv0 + q0 * 16 + 8 + 4 * g);
+        }
+        __syncthreads();                                // barrier X
+#pragma unroll 1
+        for (int s = 0; s < nstages; ++s) {
+            const size_t q = pixel_of(s);
+            const f32x4 x0 = xv0, x1 = xv1;
+            __syncthreads();                            // barrier A_s: px[wave] ready
+            f32x16 P0, P1;
+            {
+                const float *src = px + wave * PX_WAVE + lane * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 v0 = lds4(src + j * 256);
+                    const f32x4 v1 = lds4(src + (4 + j) * 256);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { P0[4 * j + i] = v0[i]; P1[4 * j + i] = v1[i]; }
+                }
+            }
+            __syncthreads();                            // barrier B_s: px may be overwritten
+            if (s + 1 < nstages) {                      // features of the next block: a whole stage to arrive
+                const size_t qn = pixel_of(s + 1);
+                xv0 = ldg4(a.conv0 + qn * 16 + 4 * g);
+                xv1 = ldg4(a.conv0 + qn * 16 + 8 + 4 * g);
+            }
+            // ---- same_dim0 ----
+            f32x16 S = bias_tile_lds(lds + L_BS0, g);
+            {
+                const f32x4 wv0 = lds4(w_s0 + lane * 4), wv1 = lds4(w_s0 + (64 + lane) * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) S = MFMA32(wv0[i], x0[i], S);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) S = MFMA32(wv1[i], x1[i], S);
+            }
+            relu16(S);
+            // ---- out0: handed tile (bias + upsampled levels 1..4) + W0_0 * S ----
+            chain_32to64_lds(w_o0, lane, S, P0, P1);
+            relu16(P0);
+            relu16(P1);
+            // ---- out1 ----
+            f32x16 Q0 = bias_tile_lds(lds + L_BO1, g), Q1 = bias_tile_lds(lds + L_BO1 + 32, g);
+            chain_32to64_lds(w_o1, lane, P0, Q0, Q1);
+            chain_32to64_lds(w_o1 + 2 * 4 * 64 * 4, lane, P1, Q0, Q1);
+            relu16(Q0);
+            relu16(Q1);
+            // ---- logits / softmax / argmax ----
+            float lg[NCLS];
+#pragma unroll
+            for (int c = 0; c < NCLS; ++c) {
+                const float *wp = w_lg + (g * NCLS + c) * 32;
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 w = lds4(wp + 4 * j);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc = fmaf(w[i], Q0[4 * j + i], acc);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 w = lds4(wp + 16 + 4 * j);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc = fmaf(w[i], Q1[4 * j + i], acc);
+                }
+                const float other = __shfl_xor(acc, 32);
+                lg[c] = (g == 0 ? acc + other : other + acc) + lds[L_BLG + c];
+            }
+            if (g == 0) {
+                if (a.logits) {
+#pragma unroll
+                    for (int c = 0; c < NCLS; ++c) a.logits[q * NCLS + c] = lg[c];
+                }
+                int best = 0; float m = lg[0];
+#pragma unroll
+                for (int c = 1; c < NCLS; ++c) if (lg[c] > m) { m = lg[c]; best = c; }
+                if (a.pred) a.pred[q] = best;
+                if (a.prob) {
+                    float e[NCLS]; float sum = 0.f;
+#pragma unroll
+                    for (int c = 0; c < NCLS; ++c) { e[c] = expf(lg[c] - m); sum += e[c]; }
+                    const float inv = 1.0f / sum;
+#pragma unroll
+                    for (int c = 0; c < NCLS; ++c) a.prob[q * NCLS + c] = e[c] * inv;
+                }
+            }
+        }
+    }
+}
+
+static hipError_t launch_head_pc(const HeadArgs &a, hipStream_t s) {
+    static const int n_cu = [] { int v = 256; hipDeviceProp_t p; int d = 0;
+                                 if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) v = p.multiProcessorCount;
+                                 return v; }();
+    const int ntiles = a.N * (a.H / HT) * (a.W / HT);
+    dim3 grid((unsigned)(ntiles < n_cu ? ntiles : n_cu)), block(768);
+    const size_t lds = HEADPC_LDS_FLOATS * sizeof(float);
+#define UKBB_HEADPC_CASE(NC)                                                                          \
+    case NC: {                                                                                       \
+        auto k = fcn_head_pc_kernel<NC>;                                                             \
+        static bool done = false;                                                                    \
+        if (!done) {                                                                                 \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),                    \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return e;                                                           \
+            done = true;                                                                             \
+        }                                                                                            \
+        hipLaunchKernelGGL(k, grid, block, lds, s, a);                                               \
+        break;                                                                                       \
+    }
+    switch (a.n_class) {
+        UKBB_HEADPC_CASE(2) UKBB_HEADPC_CASE(3) UKBB_HEADPC_CASE(4) UKBB_HEADPC_CASE(5) UKBB_HEADPC_CASE(6)
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 template <int OCC>
 static hipError_t launch_head_occ(const HeadArgs &a, hipStream_t s) {
     dim3 grid((unsigned)(a.N * (a.H / HT) * (a.W / HT))), block(256);
@@ -315,6 +632,8 @@ static hipError_t launch_head_occ(const HeadArgs &a, hipStream_t s) {
 
 hipError_t launch_head(const HeadArgs &a, hipStream_t s) {
     if ((a.H % HT) || (a.W % HT)) return hipErrorInvalidValue;
+    static const int use_pc = [] { const char *e = getenv("UKBB_HEAD_PC"); return e ? atoi(e) : 1; }();   // A/B knob
+    if (use_pc) return launch_head_pc(a, s);
     const HeadArgs &b = a;
     static const int occ = [] { const char *e = getenv("UKBB_HEAD_OCC"); return e ? atoi(e) : 3; }();   // tuning knob
     if (occ == 2) return launch_head_occ<2>(b, s);
