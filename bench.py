@@ -144,9 +144,19 @@ def main():
         avg = list(warm_avg)
         tf = lambda mac, t_ms: 2.0 * mac / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0
         ach = tf(macs[dom], dom_avg)
+        traffic, traffic_src = None, None
+        try:        # HBM bytes per launch of the dominant kernel, from the committed rocprofv3 --pmc passes
+            tj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
+            if names[dom] == 'head' and n == BATCH:
+                for kname, v in tj['kernels'].items():
+                    if kname.startswith('fcn_head'):
+                        traffic, traffic_src = v['hbm_bytes'], 'profiles/r01_pmc_traffic.json (%s)' % kname
+        except Exception:
+            pass
         roofline = {'bound': 'mfma', 'kernel': names[dom], 'achieved': round(ach, 2),
                     'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-                    'traffic': None, 'avg_launch_us': round(dom_avg * 1e3, 2), 'launches_timed': int(cnt[dom]),
+                    'traffic': traffic, 'traffic_source': traffic_src,
+                    'avg_launch_us': round(dom_avg * 1e3, 2), 'launches_timed': int(cnt[dom]),
                     'algorithmic_flop_per_launch': 2.0 * macs[dom]}
         is3 = [nm.startswith('conv') and nm != 'conv0_0' for nm in names]
         t3 = sum(a for a, f in zip(avg, is3) if f)
