@@ -82,6 +82,15 @@ ukbb_fcn_handle *ukbb_fcn_create(const ukbb_fcn_arch *arch, const float *weights
                                  size_t n_floats, int device);
 void ukbb_fcn_destroy(ukbb_fcn_handle *h);
 
+/* Arithmetic of the MFMA convolutions (BASELINE config 5).  UKBB_PREC_FP32 (default): f32 inputs,
+ * exact f32 MFMA.  UKBB_PREC_BF16: activations and weights rounded to bf16 (RNE) at the MFMA inputs,
+ * fp32 accumulation, fp32 activations in HBM; layers without a bf16 tiling (C_out = 16, the first
+ * layer, the heads) stay fp32.  Not bit-compatible with the reference; meant to be judged by Dice
+ * against the fp32 result (common/image_utils.py:171-175). */
+#define UKBB_PREC_FP32 0
+#define UKBB_PREC_BF16 1
+int ukbb_fcn_set_precision(ukbb_fcn_handle *h, int precision);
+
 /* Pre-size the activation workspace for batches up to n x h x w (optional;
  * forward() grows it on demand, which synchronises the device). */
 int ukbb_fcn_reserve(ukbb_fcn_handle *h, int n, int height, int width);

@@ -233,3 +233,36 @@ def test_sa_pipeline_on_device(engines):
                                     batch_slices=6)
     assert dev.dtype == np.float64 and dev.shape == vol.shape
     assert (dev != ref).sum() <= 2          # only fp32 near-ties may differ between two fp32 evaluations
+
+
+# ---- BASELINE config 5: aortic U-Net, bf16 MFMA path vs fp32 -------------------------------
+def test_unet_bf16_dice_vs_fp32():
+    """bf16 operands / fp32 accumulation on the conv stack: per-class Dice
+    (common/image_utils.py:171-175) against the fp32 path and the fp64 oracle, and logits error."""
+    from oracle import fcn_oracle as O
+    from ukbb_cardiac_amd.arch import MODELS
+    from ukbb_cardiac_amd.engine import Engine
+    from ukbb_cardiac_amd.image_utils import np_categorical_dice
+    from ukbb_cardiac_amd.phantom import cine_phantom
+    from ukbb_cardiac_amd.weights import synthetic_params
+    arch = MODELS['UNet_ao']
+    params = synthetic_params(arch, 1234)
+    img = ((cine_phantom(3, 256, 256, seed=61) - 0.3) / 0.25).astype(np.float32)
+    with Engine(arch, params) as eng:
+        f32 = eng.run(img, want_logits=True)
+        eng.set_precision('bf16')
+        names = eng.kernel_names()
+        b16 = eng.run(img, want_logits=True)
+        cfgs = eng.kernel_configs()
+        assert sum(1 for c in cfgs if 200 <= c < 230) >= 10, 'bf16 tilings not selected: %s' % list(zip(eng.kernel_names(), cfgs))
+        eng.set_precision('fp32')
+        again = eng.run(img, want_logits=True)
+    assert np.array_equal(again['logits'], f32['logits'])                 # switching back is exact
+    scale = np.abs(f32['logits']).max()
+    rel = np.abs(b16['logits'] - f32['logits']).max() / scale
+    assert 1e-5 < rel < 5e-2, rel                                         # really bf16, and sane
+    ref = O.argmax_pred(O.UNet(img[:1], params, 3, n_block=arch.n_block, dtype=np.float64))
+    for k in (1, 2):                                                      # classes 1, 2 as in SURVEY 8(d) config 5
+        assert np_categorical_dice(b16['pred'], f32['pred'], k) >= 0.98
+        assert np_categorical_dice(b16['pred'][:1], ref, k) >= 0.98
+    assert (b16['pred'] != f32['pred']).mean() < 0.02

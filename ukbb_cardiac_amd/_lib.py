@@ -21,7 +21,7 @@ EXPORTS = [
     'ukbb_fcn_destroy', 'ukbb_fcn_reserve', 'ukbb_fcn_forward', 'ukbb_fcn_forward_host',
     'ukbb_fcn_num_kernels', 'ukbb_fcn_kernel_name', 'ukbb_fcn_kernel_macs', 'ukbb_fcn_set_timing',
     'ukbb_fcn_kernel_times', 'ukbb_fcn_get_activation', 'ukbb_fcn_kernel_config', 'ukbb_fcn_conv_config_name',
-    'ukbb_fcn_set_timing_kernel',
+    'ukbb_fcn_set_timing_kernel', 'ukbb_fcn_set_precision',
 ]
 
 
@@ -77,6 +77,7 @@ def _load():
     lib.ukbb_fcn_conv_config_name.argtypes = [C.c_int]
     lib.ukbb_fcn_set_timing.argtypes = [vp, C.c_int]
     lib.ukbb_fcn_set_timing_kernel.argtypes = [vp, C.c_int]
+    lib.ukbb_fcn_set_precision.argtypes = [vp, C.c_int]
     lib.ukbb_fcn_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int, C.c_int]
     lib.ukbb_fcn_get_activation.restype = C.c_int64
     lib.ukbb_fcn_get_activation.argtypes = [vp, C.c_char_p, f32p, C.c_int64]

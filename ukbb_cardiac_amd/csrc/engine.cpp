@@ -103,6 +103,7 @@ struct ukbb_fcn_handle {
     DevBuf io_image, io_logits, io_prob, io_pred;   // staging for forward_host
 
     // plan
+    int precision = 0;                        // 0: fp32; 1: bf16 operands for the MFMA convs (fp32 accumulate)
     int plan_h = 0, plan_w = 0, cap_n = 0;
     std::vector<Op> ops;
     int last_n = 0;
@@ -225,9 +226,11 @@ const Tuned g_tuned[] = {
 // Fallback preference (small tiles / high occupancy won everywhere in the sweep).
 const int g_pref[] = {4, 5, 18, 3, 11, 7, 31, 23, 22, 29, 27, 26};
 
-bool cfg_valid(const ConvConfig &c, int ks, int stride, int c0, int c1, int cout, bool fused_first = false) {
+bool cfg_valid(const ConvConfig &c, int ks, int stride, int c0, int c1, int cout, bool fused_first = false,
+               bool bf16 = false) {
     if (c.ks != ks || c.stride != stride) return false;
     if ((c.pc == 2) != fused_first) return false;
+    if ((c.pc == 3) != bf16) return false;
     if (c.pc == 2 && cout != c.mb * c.cb * c.wm) return false;   // fused kernel stages its weights once: one Cout group
     if (c.lds_bytes > 160 * 1024) return false;      // LDS per CU on gfx950
     const int group = c.mb * c.cb * c.wm;
@@ -235,7 +238,20 @@ bool cfg_valid(const ConvConfig &c, int ks, int stride, int c0, int c1, int cout
 }
 
 int choose_cfg(const std::string &layer, int ks, int stride, int c0, int c1, int cout, int Ho, int Wo, int N,
-               bool fused_first = false) {
+               bool fused_first = false, bool want_bf16 = false) {
+    if (want_bf16 && !fused_first) {          // bf16 tilings first; fall back to fp32 where none fits (e.g. Cout = 16)
+            double best = 1e300; int best_id = -1;
+        for (int i = 0; i < num_conv_configs(); ++i) {
+            const ConvConfig &c = conv_config(i);
+            if (!cfg_valid(c, ks, stride, c0, c1, cout, false, true)) continue;
+            const int group = c.mb * c.cb * c.wm;
+            const int tiles = ((Ho + c.th - 1) / c.th) * ((Wo + c.tw - 1) / c.tw);
+            const int npb = (c.th * c.tw + c.mb - 1) / c.mb, pbw = (npb + c.wn - 1) / c.wn;
+            const double cost = (double)tiles * (cout / group) * pbw * c.cb;
+            if (cost < best) { best = cost; best_id = c.id; }
+        }
+        if (best_id >= 0) return best_id;
+    }
     (void)N;
     const int forced = override_cfg(layer);
     ConvConfig fc;
@@ -287,10 +303,11 @@ int new_act(ukbb_fcn_handle *h, const std::string &name, size_t per_image) {
 int ensure_packed(ukbb_fcn_handle *h, int layer, const ConvConfig &c, const float **wpk) {
     const HostLayer &L = h->layers[layer];
     char key[128];
-    snprintf(key, sizeof key, "%s/pk_mb%d_kc%d_g%d", L.name.c_str(), c.mb, c.kc, c.wm * c.cb);
+    snprintf(key, sizeof key, "%s/pk%s_mb%d_kc%d_g%d", L.name.c_str(), c.pc == 3 ? "bf16" : "", c.mb, c.kc, c.wm * c.cb);
     if (!dev_ptr(h, key)) {
         std::vector<float> pk(L.w.size());
-        pack_conv_weights(L.w.data(), L.ks, L.cin, L.cout, c.mb, c.kc, c.wm * c.cb, pk.data());
+        if (c.pc == 3) pack_conv_weights_bf16(L.w.data(), L.ks, L.cin, L.cout, c.wm * c.cb, pk.data());
+        else pack_conv_weights(L.w.data(), L.ks, L.cin, L.cout, c.mb, c.kc, c.wm * c.cb, pk.data());
         int rc = upload(h, key, pk);
         if (rc) return rc;
     }
@@ -311,7 +328,7 @@ int add_conv(ukbb_fcn_handle *h, const std::string &lname, int in0, int in1, int
     op.pad_x = std::max((op.Wo - 1) * stride + L.ks - W, 0) / 2;
     const int c0 = L.cin - c1;
     op.fused_first = fused_first;
-    op.cfg = choose_cfg(lname, L.ks, stride, c0, c1, L.cout, op.Ho, op.Wo, n_hint, fused_first);
+    op.cfg = choose_cfg(lname, L.ks, stride, c0, c1, L.cout, op.Ho, op.Wo, n_hint, fused_first, h->precision == 1);
     if (op.cfg < 0) { set_err("no conv tiling for layer %s (ks %d stride %d cin %d+%d cout %d)", lname.c_str(), L.ks, stride, c0, c1, L.cout); return UKBB_EARCH; }
     ConvConfig c;
     find_cfg(op.cfg, c);
@@ -332,16 +349,17 @@ int add_tconv(ukbb_fcn_handle *h, const std::string &lname, int in0, int H, int 
     Op op;
     op.kind = OP_TCONV; op.name = lname; op.layer = li; op.in0 = in0;
     op.H = H; op.W = W; op.Ho = H; op.Wo = W; op.stride = 1; op.pad_y = 1; op.pad_x = 1;
-    op.cfg = choose_cfg(lname, 2, 1, L.cin, 0, 4 * L.cout, H, W, n_hint);
+    op.cfg = choose_cfg(lname, 2, 1, L.cin, 0, 4 * L.cout, H, W, n_hint, false, h->precision == 1);
     if (op.cfg < 0) { set_err("no tiling for transposed conv %s", lname.c_str()); return UKBB_EARCH; }
     ConvConfig c;
     find_cfg(op.cfg, c);
     char key[128];
-    snprintf(key, sizeof key, "%s/pk2x2_mb%d_kc%d_g%d", L.name.c_str(), c.mb, c.kc, c.wm * c.cb);
+    snprintf(key, sizeof key, "%s/pk2x2%s_mb%d_kc%d_g%d", L.name.c_str(), c.pc == 3 ? "bf16" : "", c.mb, c.kc, c.wm * c.cb);
     if (!dev_ptr(h, key)) {
         std::vector<float> w2((size_t)4 * L.cin * 4 * L.cout), pk(w2.size());
         tconv_as_conv2x2(L.w.data(), L.cin, L.cout, w2.data());
-        pack_conv_weights(w2.data(), 2, L.cin, 4 * L.cout, c.mb, c.kc, c.wm * c.cb, pk.data());
+        if (c.pc == 3) pack_conv_weights_bf16(w2.data(), 2, L.cin, 4 * L.cout, c.wm * c.cb, pk.data());
+        else pack_conv_weights(w2.data(), 2, L.cin, 4 * L.cout, c.mb, c.kc, c.wm * c.cb, pk.data());
         int rc = upload(h, key, pk);
         if (rc) return rc;
         std::vector<float> b4((size_t)4 * L.cout);
@@ -773,6 +791,16 @@ const char *ukbb_fcn_kernel_name(const ukbb_fcn_handle *h, int i) {
 double ukbb_fcn_kernel_macs(const ukbb_fcn_handle *h, int i) {
     if (!h || i < 0 || i >= (int)h->ops.size()) return 0.0;
     return h->ops[i].macs_per_image * h->last_n;
+}
+
+int ukbb_fcn_set_precision(ukbb_fcn_handle *h, int precision) {
+    if (!h || (precision != UKBB_PREC_FP32 && precision != UKBB_PREC_BF16)) { set_err("set_precision: bad argument"); return UKBB_EINVAL; }
+    if (precision != h->precision) {
+        if (hipSetDevice(h->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { set_err("set_precision: device sync failed"); return UKBB_EDEVICE; }
+        h->precision = precision;
+        h->plan_h = h->plan_w = 0;               // re-plan (tilings and packed weights differ)
+    }
+    return UKBB_OK;
 }
 
 int ukbb_fcn_kernel_config(const ukbb_fcn_handle *h, int i) {

@@ -39,7 +39,8 @@ struct ConvConfig {
     int wm, wn, cb;     // waves along Cout / along pixels; Cout blocks per wave
     int lds_bytes;
     int pc;             // 0: single-role kernel; 1: producer/consumer persistent kernel (512 threads);
-                        // 2: producer/consumer with the C_in = 1 first layer fused into the producers
+                        // 2: producer/consumer with the C_in = 1 first layer fused into the producers;
+                        // 3: single-role kernel with bf16 operands / fp32 accumulation (mb = 32, kc = 16)
     const char *name;
 };
 
@@ -51,6 +52,8 @@ hipError_t launch_conv(int cfg_id, const ConvArgs &a, hipStream_t s);
 // Host-side: pack folded weights W[ks][ks][Cin][Cout] into A-fragment order
 // for tiling (mb, kc) and workgroups of ncbl = wm*cb Cout blocks.  Returns floats written.
 size_t pack_conv_weights(const float *w, int ks, int cin, int cout, int mb, int kc, int ncbl, float *dst);
+// bf16 operand variant (ConvConfig::pc == 3): 8 bf16 per lane per tap, returns dwords written.
+size_t pack_conv_weights_bf16(const float *w, int ks, int cin, int cout, int ncbl, float *dst);
 
 // ---------------------------------------------------------------------------
 // First layer: conv3x3, C_in = 1 (network.py:186 with l = 0), direct stencil.

@@ -22,6 +22,7 @@
 // layout spent 44 % of its LDS cycles in bank conflicts, profiles/r01_pmc_summary_head2.csv).
 #include "kernels.h"
 
+#include <cstring>
 #include <type_traits>
 
 namespace ukbb {
@@ -46,6 +47,20 @@ template <> struct Mfma<16> {
         return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
     }
 };
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// bf16 inputs, fp32 accumulate: one v_mfma_f32_32x32x16_bf16 covers a whole KC = 16 chunk of a tap.
+// Lane (m = lane & 31, h = lane >> 5) supplies A[m][k = 8h..8h+7] and B[k = 8h..8h+7][m] as 8 bf16
+// (4 dwords); the accumulator layout is the same as the f32 32x32 form.
+__device__ __forceinline__ f32x16 mfma_bf16(const f32x4 &a, const f32x4 &b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    const __bf16 l = (__bf16)lo, h = (__bf16)hi;       // RNE; hipcc emits v_cvt_pk_bf16_f32
+    return (unsigned)__builtin_bit_cast(unsigned short, l) | ((unsigned)__builtin_bit_cast(unsigned short, h) << 16);
+}
 
 __host__ __device__ constexpr int xs_stride(int kc) {
     // floats per staged halo pixel: KC channels + 4 pad, so the 16-byte reads of the 16 lanes
@@ -92,14 +107,18 @@ __device__ __forceinline__ void unroll_taps(F &&f) {
     }
 }
 
-template <int KS, int STRIDE, int MB, int TH, int TW, int KC, int WM, int WN, int CB>
+// BF = true: bf16 operands (activations converted while staging, weights pre-converted on the host),
+// fp32 accumulation; requires MB = 32, KC = 16.  LDS then holds [halo px][8 dwords + 4 pad] and
+// one packed 4-dword fragment per lane per tap.
+template <int KS, int STRIDE, int MB, int TH, int TW, int KC, int WM, int WN, int CB, bool BF = false>
 __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM, WN, CB)) void conv_mfma_kernel(const ConvArgs a) {
+    static_assert(!BF || (MB == 32 && KC == 16), "bf16 path: 32x32x16 MFMA, one chunk = one K step");
     using M = Mfma<MB>;
     using Acc = typename M::Acc;
-    constexpr int KK = M::KK, KSTEPS = KC / KK, PB = MB;
+    constexpr int KK = M::KK, KSTEPS = BF ? 4 : KC / KK, PB = MB;   // BF: "k-steps" = the 4 dwords of one bf16 fragment
     constexpr int NPIX = TH * TW, NPB = (NPIX + PB - 1) / PB, PBW = (NPB + WN - 1) / WN;
     constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
-    constexpr int HP = IH * IW, XS = xs_stride(KC), C4 = KC / 4, KS2 = KS * KS;
+    constexpr int HP = IH * IW, XS = BF ? KC / 2 + 4 : xs_stride(KC), C4 = KC / 4, KS2 = KS * KS;
     constexpr int NCBL = WM * CB;                       // Cout blocks per workgroup
     constexpr int SLAB = KS2 * 64 * KSTEPS;             // packed weights of one Cout block, one chunk
     constexpr int NIT = (HP * C4 + 255) / 256;          // activation float4 per thread per chunk
@@ -185,7 +204,13 @@ __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM,
         for (int it = 0; it < NIT; ++it) {
             const int pix = pix0 + it * PSTEP;
             const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-            if (pix < HP) *reinterpret_cast<f32x4 *>(xs + pix * XS + 4 * c4) = goff[it] < 0 ? zero4 : xr[it];
+            if constexpr (BF) {
+                const f32x4 v = goff[it] < 0 ? zero4 : xr[it];
+                uint2 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+                if (pix < HP) *reinterpret_cast<uint2 *>(xs + pix * XS + 2 * c4) = pk;
+            } else {
+                if (pix < HP) *reinterpret_cast<f32x4 *>(xs + pix * XS + 4 * c4) = goff[it] < 0 ? zero4 : xr[it];
+            }
         }
 #pragma unroll
         for (int it = 0; it < NWT; ++it)
@@ -215,6 +240,16 @@ __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM,
                 __builtin_amdgcn_sched_barrier(0);
                 // k-step outer / pixel block inner: consecutive MFMAs write different accumulators
                 // (a 16x16x4 f32 MFMA has 40 cycles dependent latency but issues every 32).
+                if constexpr (BF) {
+#pragma unroll
+                    for (int pb = 0; pb < PBW; ++pb)
+#pragma unroll
+                        for (int cb = 0; cb < CB; ++cb) {
+                            const f32x4 af = {av[t & 1][cb][0], av[t & 1][cb][1], av[t & 1][cb][2], av[t & 1][cb][3]};
+                            const f32x4 bf = {bv[t & 1][pb][0], bv[t & 1][pb][1], bv[t & 1][pb][2], bv[t & 1][pb][3]};
+                            acc[cb][pb] = mfma_bf16(af, bf, acc[cb][pb]);
+                        }
+                } else {
 #pragma unroll
                 for (int s = 0; s < KSTEPS; ++s)
 #pragma unroll
@@ -222,6 +257,7 @@ __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM,
 #pragma unroll
                         for (int cb = 0; cb < CB; ++cb)
                             acc[cb][pb] = M::run(av[t & 1][cb][s], bv[t & 1][pb][s], acc[cb][pb]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             });
 #undef UKBB_LOAD_TAP
@@ -639,6 +675,18 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
     Y(124, 3, 2, 16, 12, 13, 8, 2, 2, 2)             \
     Y(125, 3, 2, 16, 8, 26, 16, 2, 2, 1)
 
+// bf16-operand tilings (single-role kernel, MB = 32, KC = 16).  B(id, KS, STRIDE, TH, TW, WM, WN, CB)
+#define UKBB_BF_CONFIGS(B)                 \
+    B(200, 3, 1, 12, 13, 2, 2, 1)          \
+    B(201, 3, 1, 12, 26, 2, 2, 1)          \
+    B(202, 3, 1, 16, 16, 1, 4, 1)          \
+    B(203, 3, 1, 16, 16, 2, 2, 1)          \
+    B(210, 3, 2, 12, 13, 2, 2, 1)          \
+    B(211, 3, 2, 8, 16, 1, 4, 1)           \
+    B(212, 3, 2, 8, 16, 2, 2, 1)           \
+    B(220, 2, 1, 12, 13, 2, 2, 1)          \
+    B(221, 2, 1, 16, 16, 2, 2, 1)
+
 // Producer/consumer tilings with the fused first layer (C_in = 1 -> KC, then this conv).
 #define UKBB_PCF_CONFIGS(Z)                          \
     Z(130, 3, 1, 16, 16, 16, 16, 1, 4, 1)            \
@@ -651,8 +699,15 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
      2 * conv_lds_bytes(KS, S, MB, TH, TW, KC, WM, CB) + 2 * 4 * (((TH - 1) * S + KS + 2) * ((TW - 1) * S + KS + 2)), 2, \
      "convPCfirst" #KS "x" #KS "s" #S "_mb" #MB "_t" #TH "x" #TW "_kc" #KC "_w" #WM "x" #WN "_cb" #CB},
 
+__host__ __device__ constexpr int conv_bf_lds_bytes(int ks, int s, int th, int tw, int wm, int cb) {
+    return ((16 / 2 + 4) * ((th - 1) * s + ks) * ((tw - 1) * s + ks) + wm * cb * ks * ks * 64 * 4) * 4;
+}
+#define UKBB_BF_ENTRY(ID, KS, S, TH, TW, WM, WN, CB)                                            \
+    {ID, KS, S, 32, TH, TW, 16, WM, WN, CB, conv_bf_lds_bytes(KS, S, TH, TW, WM, CB), 3,       \
+     "convBF16_" #KS "x" #KS "s" #S "_t" #TH "x" #TW "_w" #WM "x" #WN "_cb" #CB},
+
 static const ConvConfig g_cfgs[] = {UKBB_CONV_CONFIGS(UKBB_CFG_ENTRY) UKBB_PC_CONFIGS(UKBB_PC_ENTRY)
-                                    UKBB_PCF_CONFIGS(UKBB_PCF_ENTRY)};
+                                    UKBB_PCF_CONFIGS(UKBB_PCF_ENTRY) UKBB_BF_CONFIGS(UKBB_BF_ENTRY)};
 
 int num_conv_configs() { return (int)(sizeof(g_cfgs) / sizeof(g_cfgs[0])); }
 const ConvConfig &conv_config(int i) { return g_cfgs[i]; }
@@ -724,6 +779,21 @@ hipError_t launch_conv(int cfg_id, const ConvArgs &a, hipStream_t s) {
         break;                                                                                  \
     }
         UKBB_PCF_CONFIGS(UKBB_PCF_CASE)
+#define UKBB_BF_CASE(ID, KS, S, TH, TW, WM, WN, CB)                                             \
+    case ID: {                                                                                  \
+        auto k = conv_mfma_kernel<KS, S, 32, TH, TW, 16, WM, WN, CB, true>;                     \
+        static bool attr_done = false;                                                          \
+        if (!attr_done) {                                                                       \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),               \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                               c->lds_bytes);                                   \
+            if (e != hipSuccess) return e;                                                      \
+            attr_done = true;                                                                   \
+        }                                                                                       \
+        hipLaunchKernelGGL(k, grid, dim3(256), c->lds_bytes, s, a);                             \
+        break;                                                                                  \
+    }
+        UKBB_BF_CONFIGS(UKBB_BF_CASE)
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -746,6 +816,35 @@ size_t pack_conv_weights(const float *w, int ks, int cin, int cout, int mb, int 
                         for (int s = 0; s < ksteps; ++s) {
                             const int ci = ch * kc + g * ksteps + s, co = (grp * ncbl + cbl) * mb + m;
                             dst[o++] = w[((size_t)tap * cin + ci) * cout + co];
+                        }
+                    }
+    return o;
+}
+
+static inline unsigned short f32_to_bf16_rne(float f) {
+    unsigned u; memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+size_t pack_conv_weights_bf16(const float *w, int ks, int cin, int cout, int ncbl, float *dst) {
+    // dst[group][chunk][cbl][tap][lane][4 dwords]; dword d of lane (g<<5)|m holds bf16 pair
+    //   W[tap][ci = chunk*16 + 8g + 2d (+1)][co = cb*32 + m]   (low half = even channel)
+    const int ks2 = ks * ks, nchunk = cin / 16;
+    unsigned *out = reinterpret_cast<unsigned *>(dst);
+    size_t o = 0;
+    for (int grp = 0; grp < cout / (32 * ncbl); ++grp)
+        for (int ch = 0; ch < nchunk; ++ch)
+            for (int cbl = 0; cbl < ncbl; ++cbl)
+                for (int tap = 0; tap < ks2; ++tap)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int m = lane & 31, g = lane >> 5, co = (grp * ncbl + cbl) * 32 + m;
+                        for (int d = 0; d < 4; ++d) {
+                            const int ci = ch * 16 + 8 * g + 2 * d;
+                            const unsigned lo = f32_to_bf16_rne(w[((size_t)tap * cin + ci) * cout + co]);
+                            const unsigned hi = f32_to_bf16_rne(w[((size_t)tap * cin + ci + 1) * cout + co]);
+                            out[o++] = lo | (hi << 16);
                         }
                     }
     return o;

@@ -90,6 +90,11 @@ class Engine:
                                        C.c_void_p(pred_ptr or None), C.c_void_p(stream or None))
         _lib.check(rc, 'ukbb_fcn_forward')
 
+    def set_precision(self, precision: str):
+        """'fp32' (default) or 'bf16' (bf16 MFMA inputs, fp32 accumulate; BASELINE config 5)."""
+        code = {'fp32': 0, 'bf16': 1}[precision]
+        _lib.check(_lib.lib.ukbb_fcn_set_precision(self._h, code), 'ukbb_fcn_set_precision')
+
     # -- measurement -----------------------------------------------------------
     def kernel_names(self):
         n = _lib.lib.ukbb_fcn_num_kernels(self._h)
