@@ -80,6 +80,7 @@ struct Op {                    // one kernel launch of the plan
     int out = -1;
     int sq[4] = {-1, -1, -1, -1};   // OP_HEAD: squeezed maps of levels 1..4
     bool fused_first = false;       // OP_CONV: conv0_0 (C_in = 1) evaluated by this kernel's producers
+    bool on_side = false;           // launched on the handle's side stream (fork/join by events)
     int H = 0, W = 0, Ho = 0, Wo = 0, stride = 1, pad_y = 0, pad_x = 0;
     double macs_per_image = 0; // algorithmic
     const float *wpk = nullptr, *bias = nullptr;
@@ -108,6 +109,11 @@ struct ukbb_fcn_handle {
     std::vector<Op> ops;
     int last_n = 0;
 
+    // side stream for kernels that only feed the head (sqg_l): fork after level l, join before the head
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> ev_fork, ev_join;
+    bool use_side = false;
+
     // timing
     bool timing = false;
     int timing_only = -1;                     // -1: every kernel; else only this op index
@@ -118,6 +124,9 @@ struct ukbb_fcn_handle {
 
     ~ukbb_fcn_handle() {
         for (auto e : ev) (void)hipEventDestroy(e);
+        for (auto e : ev_fork) (void)hipEventDestroy(e);
+        for (auto e : ev_join) (void)hipEventDestroy(e);
+        if (side) (void)hipStreamDestroy(side);
     }
 };
 
@@ -384,7 +393,7 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
     char nm[64];
     // encoder (network.py:179-189 / network_ao.py:31-41)
     int cur = -1, ch = 1, cw = 1;
-    std::vector<int> level_out(a.n_level), lh(a.n_level), lw(a.n_level);
+    std::vector<int> level_out(a.n_level), lh(a.n_level), lw(a.n_level), sqg_out(a.n_level, -1);
     int hh = H, ww = W;
     for (int l = 0; l < a.n_level; ++l) {
         for (int i = 0; i < a.n_block[l]; ++i) {
@@ -415,22 +424,26 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
         }
         level_out[l] = cur; lh[l] = hh; lw[l] = ww;
         h->act_name[cur] = std::string("conv") + std::to_string(l);
-    }
-    (void)ch; (void)cw;
-    if (a.kind == UKBB_KIND_FCN) {
-        std::vector<int> sq(a.n_level, -1);
-        for (int l = 1; l < a.n_level; ++l) {     // same_dim0 lives inside the head kernel
+        if (a.kind == UKBB_KIND_FCN && l >= 1) {
+            // same_dim_l + out0's level-l slice at low resolution (same_dim0 lives inside the head kernel).
+            // Emitted right after its level and run on the side stream: it only feeds the head, is
+            // memory-bound, and overlaps with the MFMA-bound convs of the deeper levels.
             snprintf(nm, sizeof nm, "same_dim%d", l);
             Op op; op.kind = OP_SQG; op.name = std::string("sqg") + std::to_string(l);
             op.layer = h->layer_index.at(nm); op.in0 = level_out[l];
             op.H = op.Ho = lh[l]; op.W = op.Wo = lw[l]; op.stride = l;
+            op.on_side = h->use_side;
             op.out = new_act(h, std::string("g") + std::to_string(l), (size_t)lh[l] * lw[l] * a.fc);
             // algorithmic MACs: the squeeze; the 32->64 projection is out0's work moved to low
             // resolution and is accounted to the head (so the per-layer sums equal Appendix A)
             op.macs_per_image = (double)lh[l] * lw[l] * a.n_filter[l] * a.same_dim;
             h->ops.push_back(op);
-            sq[l] = op.out;
+            sqg_out[l] = op.out;
         }
+    }
+    (void)ch; (void)cw;
+    if (a.kind == UKBB_KIND_FCN) {
+        std::vector<int> &sq = sqg_out;
         Op op; op.kind = OP_HEAD; op.name = "head"; op.in0 = level_out[0];
         op.H = op.Ho = H; op.W = op.Wo = W;
         op.macs_per_image = (double)H * W * (a.n_filter[0] * a.same_dim + a.same_dim * a.n_level * a.fc +
@@ -531,8 +544,28 @@ int run_plan(ukbb_fcn_handle *h, const float *image, int n, float *logits, float
             for (auto &e : h->ev) HIP_TRY(hipEventCreate(&e), UKBB_EDEVICE);
         }
     }
+    hipStream_t s_main = s;
+    bool forked = false;
     for (size_t i = 0; i < h->ops.size(); ++i) {
         const Op &op = h->ops[i];
+        s = s_main;
+        if (op.on_side) {                              // fork: side stream waits for everything issued so far
+            if (!h->side) {
+                HIP_TRY(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking), UKBB_EDEVICE);
+                h->ev_fork.assign(UKBB_FCN_MAX_LEVEL, nullptr);
+                h->ev_join.assign(UKBB_FCN_MAX_LEVEL, nullptr);
+                for (auto &e : h->ev_fork) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming), UKBB_EDEVICE);
+                for (auto &e : h->ev_join) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming), UKBB_EDEVICE);
+            }
+            HIP_TRY(hipEventRecord(h->ev_fork[op.stride], s_main), UKBB_EDEVICE);
+            HIP_TRY(hipStreamWaitEvent(h->side, h->ev_fork[op.stride], 0), UKBB_EDEVICE);
+            s = h->side;
+            forked = true;
+        }
+        if (op.kind == OP_HEAD && forked) {            // join: the head needs every side-stream result
+            for (const Op &o2 : h->ops)
+                if (o2.on_side) HIP_TRY(hipStreamWaitEvent(s_main, h->ev_join[o2.stride], 0), UKBB_EDEVICE);
+        }
         const bool timed = h->timing && (h->timing_only < 0 || h->timing_only == (int)i);
         if (timed) HIP_TRY(hipEventRecord(h->ev[2 * i], s), UKBB_EDEVICE);
         hipError_t e = hipSuccess;
@@ -616,6 +649,7 @@ int run_plan(ukbb_fcn_handle *h, const float *image, int n, float *logits, float
         }
         if (e != hipSuccess) { set_err("launch of %s failed: %s", op.name.c_str(), hipGetErrorString(e)); return UKBB_EDEVICE; }
         if (timed) HIP_TRY(hipEventRecord(h->ev[2 * i + 1], s), UKBB_EDEVICE);
+        if (op.on_side) HIP_TRY(hipEventRecord(h->ev_join[op.stride], h->side), UKBB_EDEVICE);
     }
     if (h->timing) h->ev_pending = true;
     h->last_n = n;
@@ -667,6 +701,10 @@ ukbb_fcn_handle *ukbb_fcn_create(const ukbb_fcn_arch *arch, const float *weights
     std::unique_ptr<ukbb_fcn_handle> h(new ukbb_fcn_handle);
     h->arch = *arch;
     h->device = device;
+    // r01 measurement: running sqg_l concurrently with the deeper convs made the step 9 % SLOWER
+    // (1.88 vs 1.72 ms: the sqg waves take SIMD slots and L2 bandwidth from the MFMA-bound persistent
+    // conv kernels), so the fork/join path is off unless UKBB_SIDE_STREAM is set.
+    h->use_side = getenv("UKBB_SIDE_STREAM") != nullptr;
 
     // ---- fold BN (fp32; same op order as weights.py fold_bn) --------------------------
     const float *p = weights;
