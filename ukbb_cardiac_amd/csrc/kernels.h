@@ -40,7 +40,8 @@ struct ConvConfig {
     int lds_bytes;
     int pc;             // 0: single-role kernel; 1: producer/consumer persistent kernel (512 threads);
                         // 2: producer/consumer with the C_in = 1 first layer fused into the producers;
-                        // 3: single-role kernel with bf16 operands / fp32 accumulation (mb = 32, kc = 16)
+                        // 3: single-role kernel with bf16 operands / fp32 accumulation (mb = 32, kc = 16);
+                        // 4: Winograd F(2x2,3x3) producer/consumer kernel (kernels_wino.hip)
     const char *name;
 };
 
@@ -54,6 +55,12 @@ hipError_t launch_conv(int cfg_id, const ConvArgs &a, hipStream_t s);
 size_t pack_conv_weights(const float *w, int ks, int cin, int cout, int mb, int kc, int ncbl, float *dst);
 // bf16 operand variant (ConvConfig::pc == 3): 8 bf16 per lane per tap, returns dwords written.
 size_t pack_conv_weights_bf16(const float *w, int ks, int cin, int cout, int ncbl, float *dst);
+
+// Winograd F(2x2,3x3) producer/consumer kernel (kernels_wino.hip): 3x3, stride 1, C_out % 64 == 0,
+// C_in % 16 == 0.  ConvConfig::pc == 4, id 300.  Same ConvArgs; wpk from pack_wino_weights().
+hipError_t launch_wino(const ConvArgs &a, hipStream_t s);
+size_t pack_wino_weights(const float *w /*[3][3][cin][cout] folded*/, int cin, int cout, float *dst /*16*cin*cout*/);
+int wino_lds_bytes();
 
 // ---------------------------------------------------------------------------
 // First layer: conv3x3, C_in = 1 (network.py:186 with l = 0), direct stencil.

@@ -1,0 +1,374 @@
+// Winograd F(2x2, 3x3) convolution (+ folded BN bias, ReLU) for the stride-1 3x3 layers with
+// C_out >= 64 (reference common/network.py:19-25; levels 2-4 of build_FCN and of the U-Net).
+//
+//   Y = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A        per 2x2 output tile, 4x4 input patch d
+//
+// 16 multiplies per 2x2 outputs instead of 36: the MFMA work of a layer drops 2.25x.  The 16
+// element-wise products are 16 independent GEMMs over (C_in) between transformed weights
+// U[k][cout][ci] (computed once on the host) and transformed patches V[k][ci][tile], so they run on
+// v_mfma_f32_16x16x4_f32 with A = U (cout on M), B = V (tile on N) exactly like the direct kernel.
+// Arithmetic stays fp32 end to end; the transforms only add/subtract (entries 0, +-1) on the
+// input/output side and the +-1/2 factors sit in the pre-computed weights, so the result differs
+// from the direct sum by ordinary fp32 rounding (measured ~1e-6 of the activation scale).
+//
+// Structure: persistent producer/consumer workgroup (512 threads, one per CU).
+//   item  = (group of 64 output channels, image, region of 4 x 8 Winograd tiles = 8 x 16 pixels)
+//   stage = one chunk of KC = 16 input channels of one item
+//   producers (waves 4-7): global -> registers -> raw halo tile XS (LDS) -> input transform ->
+//       VS[16][32 tiles][KC+4] (LDS), three stages deep (load s+3, park s+2, transform s+1);
+//   consumers (waves 0-3, one 16-channel block each): per k: one A fragment straight from
+//       global/L2 (packed on the host), two B vectors from VS, 8 MFMAs; after the last chunk the
+//       output transform, bias, ReLU and the NHWC stores.
+// One barrier per stage.
+#include "kernels.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+namespace ukbb {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int TRY = 4, TRX = 8, NT = TRY * TRX;       // Winograd tiles per region (32 = two MFMA N blocks)
+constexpr int WKC = 16, WXS = WKC + 4;                // channels per stage, LDS pixel stride (floats)
+constexpr int WIH = 2 * TRY + 2, WIW = 2 * TRX + 2, WHP = WIH * WIW;   // raw halo tile 10 x 18
+constexpr int NITX = (WHP * (WKC / 4) + 255) / 256;   // staging passes of the 256 producer threads (3)
+constexpr int XSZ = NITX * (256 / (WKC / 4)) * WXS;   // floats per XS buffer: padded to 192 pixels, no tail guard
+constexpr int WNCBL = 4;                              // 4 blocks of 16 output channels per item
+constexpr int L_XS = 0;                               // [2][XSZ]
+constexpr int L_VS = L_XS + 2 * XSZ;            // [2][16][NT][WXS]
+constexpr int WINO_LDS_FLOATS = L_VS + 2 * 16 * NT * WXS;
+
+__device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+__device__ __forceinline__ void st4(float *p, const f32x4 &v) { *reinterpret_cast<f32x4 *>(p) = v; }
+
+// Packed fp32 add / subtract on register pairs.  hipcc scalarises the subtractions of the input
+// transform into v_sub_f32 (+ moves) when left to itself; every VALU instruction of a producer wave
+// costs an MFMA slot, so the packed forms are spelled out.
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+    f32x2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+    f32x2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void unroll_k(F &&f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); unroll_k<N, I + 1>(f); }
+}
+
+}  // namespace
+
+// Diagnostic only (-DUKBB_WINO_STAMPS + UKBB_STAMPS=1): s_memtime stamps around the phases of a stage.
+#ifdef UKBB_WINO_STAMPS
+#define STAMP(v) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); }
+#define STAMP_DO(...) __VA_ARGS__
+__device__ unsigned long long g_wstamps[8];
+#else
+#define STAMP(v)
+#define STAMP_DO(...)
+#endif
+__global__ __launch_bounds__(512, 2) void wino_pc_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int cin = a.C0 + a.C1;
+    const int nchunk = cin / WKC;
+    const int regs_x = (a.Wo + 2 * TRX - 1) / (2 * TRX), regs_y = (a.Ho + 2 * TRY - 1) / (2 * TRY);
+    const int regions = regs_x * regs_y;
+    const int per_group = a.N * regions;
+    const int nitems = per_group * (a.Cout / (16 * WNCBL));
+    const int my_items = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nstages = my_items * nchunk;
+    const bool producer = __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256;
+
+    if (producer) {
+        // On a SIMD the producers' VALU instructions share the issue port with the consumer's MFMA
+        // stream and only get a slot between two MFMAs (measured: ~60 cycles per VALU op at equal
+        // priority, ~28 at raised priority, each stealing a few MFMA cycles).  So this role is written
+        // for a minimal VALU count (41 per stage against 128 MFMAs): buffer loads whose out-of-image lanes carry an out-of-range offset
+        // (the hardware returns 0; no select at the LDS write), all per-thread offsets precomputed,
+        // region / chunk bookkeeping on the scalar unit, the stage loop unrolled by two so LDS
+        // addresses are immediates, packed fp32 adds in the transform.  (s_setprio on the producers was
+        // measured: it shortens their phase but lengthens the MFMA phase by the same amount.)
+        const int tid = threadIdx.x - 256;
+        constexpr int C4 = WKC / 4, PSTEP = 256 / C4;                 // 64 halo pixels per pass, 3 passes
+        const int c4 = tid % C4, pix0 = tid / C4;
+        unsigned tb[NITX], pixoff[NITX], pre[NITX];
+#pragma unroll
+        for (int it = 0; it < NITX; ++it) {
+            const int pix = pix0 + it * PSTEP;
+            const int iy = pix / WIW, ix = pix - iy * WIW;
+            tb[it] = pix < WHP ? (1u << iy) | (1u << (WIH + ix)) : 0x80000000u;   // bit 31 is never set in the stage mask
+            pixoff[it] = (unsigned)(iy * a.W + ix);
+            pre[it] = 0;
+        }
+        int cur_cs = 0;
+        u32x4 xr[NITX];
+        // scalar cursor of the next stage to request
+        int l_ch = 0, l_item = blockIdx.x, l_n = 0, l_iy0 = 0, l_ix0 = 0;
+        auto locate = [&]() {
+            const int rest = l_item % per_group;
+            l_n = rest / regions;
+            const int r = rest - l_n * regions;
+            const int ry = r / regs_x, rx = r - ry * regs_x;
+            l_iy0 = ry * 2 * TRY - 1; l_ix0 = rx * 2 * TRX - 1;
+        };
+        locate();
+        auto loadx = [&]() {                            // raw halo of the cursor stage -> registers; advances the cursor
+            const float *src; int cs;
+            if (l_ch * WKC < a.C0) { src = a.in0 + l_ch * WKC; cs = a.C0; }
+            else                   { src = a.in1 + (l_ch * WKC - a.C0); cs = a.C1; }
+            if (cs != cur_cs) {                         // uniform; once per source switch
+                cur_cs = cs;
+#pragma unroll
+                for (int it = 0; it < NITX; ++it) pre[it] = pixoff[it] * (unsigned)(cs * 4) + 16u * c4;
+            }
+            src += ((long long)(l_n * a.H + l_iy0) * a.W + l_ix0) * cs;   // may point before the tensor; masked lanes never use it
+            const int ylo = l_iy0 < 0 ? -l_iy0 : 0, yhi = a.H - l_iy0 < WIH ? a.H - l_iy0 : WIH;
+            const int xlo = l_ix0 < 0 ? -l_ix0 : 0, xhi = a.W - l_ix0 < WIW ? a.W - l_ix0 : WIW;
+            const unsigned cm = (((1u << yhi) - 1u) & ~((1u << ylo) - 1u)) | ((((1u << xhi) - 1u) & ~((1u << xlo) - 1u)) << WIH);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+            for (int it = 0; it < NITX; ++it) {
+                const unsigned vo = (cm & tb[it]) == tb[it] ? pre[it] : 0x80000000u;   // out of range -> zeros
+                xr[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0);
+            }
+            if (++l_ch == nchunk) { l_ch = 0; l_item += gridDim.x; if (l_item < nitems) locate(); }
+        };
+        float *const xs_w = lds + L_XS + pix0 * WXS + 4 * c4;
+        auto storex = [&](auto par) {
+            constexpr int B = decltype(par)::value;
+#pragma unroll
+            for (int it = 0; it < NITX; ++it)
+                *reinterpret_cast<u32x4 *>(xs_w + B * XSZ + it * PSTEP * WXS) = xr[it];
+        };
+        // V = B^T d B per (tile, channel quad).  The two producer wave pairs split the row pass: waves
+        // 4-5 produce rows 0-1 of B^T d (from patch rows 0-2), waves 6-7 rows 2-3 (from patch rows 1-3),
+        // so each thread issues 12 reads, 32 packed adds and 8 writes.
+        const int half = __builtin_amdgcn_readfirstlane(tid) >> 7;
+        const int xt = tid & 127, x_tile = xt / C4, x_q = xt - x_tile * C4;
+        const float *const xs_r = lds + L_XS + ((2 * (x_tile / TRX) + half) * WIW + 2 * (x_tile % TRX)) * WXS + 4 * x_q;
+        float *const vs_w = lds + L_VS + half * 8 * NT * WXS + x_tile * WXS + 4 * x_q;
+        auto xform = [&](auto par) {
+            constexpr int B = decltype(par)::value;
+            const float *xs = xs_r + B * XSZ;
+            float *vs = vs_w + B * 16 * NT * WXS;
+            f32x2 e[3][4][2];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 v = ld4(xs + (i * WIW + j) * WXS);
+                    e[i][j][0] = f32x2{v[0], v[1]}; e[i][j][1] = f32x2{v[2], v[3]};
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            auto put = [&](int k, const f32x2 &lo, const f32x2 &hi) { st4(vs + k * NT * WXS, f32x4{lo[0], lo[1], hi[0], hi[1]}); };
+            auto rows = [&](auto hc) {                  // a real (uniform) branch per wave pair: stores inside keep it from being if-converted
+                constexpr int HALF = decltype(hc)::value;
+                f32x2 wa[4][2], wb[4][2];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        if constexpr (HALF == 0) { wa[j][h] = pk_sub(e[0][j][h], e[2][j][h]); wb[j][h] = pk_add(e[1][j][h], e[2][j][h]); }   // rows 0, 1
+                        else                     { wa[j][h] = pk_sub(e[1][j][h], e[0][j][h]); wb[j][h] = pk_sub(e[0][j][h], e[2][j][h]); }   // rows 2, 3
+                    }
+                put(0, pk_sub(wa[0][0], wa[2][0]), pk_sub(wa[0][1], wa[2][1]));
+                put(1, pk_add(wa[1][0], wa[2][0]), pk_add(wa[1][1], wa[2][1]));
+                put(2, pk_sub(wa[2][0], wa[1][0]), pk_sub(wa[2][1], wa[1][1]));
+                put(3, pk_sub(wa[1][0], wa[3][0]), pk_sub(wa[1][1], wa[3][1]));
+                put(4, pk_sub(wb[0][0], wb[2][0]), pk_sub(wb[0][1], wb[2][1]));
+                put(5, pk_add(wb[1][0], wb[2][0]), pk_add(wb[1][1], wb[2][1]));
+                put(6, pk_sub(wb[2][0], wb[1][0]), pk_sub(wb[2][1], wb[1][1]));
+                put(7, pk_sub(wb[1][0], wb[3][0]), pk_sub(wb[1][1], wb[3][1]));
+            };
+            if (half == 0) rows(std::integral_constant<int, 0>{});
+            else           rows(std::integral_constant<int, 1>{});
+        };
+        constexpr std::integral_constant<int, 0> P0{};
+        constexpr std::integral_constant<int, 1> P1{};
+        // prologue: XS[0] <- stage 0, XS[1] <- stage 1, registers <- stage 2
+        if (nstages > 0) { loadx(); storex(P0); }
+        if (nstages > 1) { loadx(); storex(P1); }
+        if (nstages > 2) loadx();
+        __syncthreads();                                // barrier X: XS[0], XS[1] visible to every producer
+        if (nstages > 0) xform(P0);
+        STAMP_DO(unsigned long long pw = 0, px_ = 0, pl = 0, t0, t1, t2, t3;)
+        auto stage = [&](auto par, auto npar, int s) {
+            STAMP(t0)
+            __syncthreads();                            // barrier #s: VS[s&1] ready / VS[(s+1)&1], XS[s&1] free
+            STAMP(t1)
+            if (s + 1 < nstages) xform(npar);
+            STAMP(t2)
+            if (s + 2 < nstages) storex(par);           // stage s+2 (requested an iteration ago) replaces stage s
+            if (s + 3 < nstages) loadx();
+            STAMP(t3)
+            STAMP_DO(pw += t1 - t0; px_ += t2 - t1; pl += t3 - t2;)
+        };
+#pragma unroll 1
+        for (int s = 0; s < nstages; s += 2) {
+            stage(P0, P1, s);
+            if (s + 1 < nstages) stage(P1, P0, s + 1);
+        }
+        STAMP_DO(if (threadIdx.x == 256) { atomicAdd(g_wstamps + 0, pw); atomicAdd(g_wstamps + 1, px_); atomicAdd(g_wstamps + 2, pl); atomicAdd(g_wstamps + 3, (unsigned long long)nstages); })
+    } else {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;   // wave = Cout block within the item
+        const int t16 = lane & 15, g = lane >> 4;
+        __syncthreads();                                // barrier X
+        int s = 0;
+        STAMP_DO(unsigned long long cw = 0, cc = 0, ce = 0, c0, c1, c2, c3;)
+        for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+            const int grp = item / per_group, rest = item - grp * per_group;
+            const int n = rest / regions, r = rest - n * regions;
+            const int ry = r / regs_x, rx = r - ry * regs_x;
+            f32x4 acc[16][2];
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb) acc[k][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // packed weights: [group][chunk][cbl][k][lane][4].  A fragments come straight from global/L2,
+            // through a rolling 4-deep register queue over the flattened (chunk, k) sequence: the load for
+            // k+4 is issued before the MFMAs of k (4 x 256 MFMA cycles cover the L2 latency), and the queue
+            // runs across stage barriers (the first fragments of the next chunk are requested during the
+            // last k of the current one).
+            const float *wbase = a.wpk + ((size_t)grp * nchunk * WNCBL + wave) * (16 * 64 * 4) + lane * 4;
+            constexpr int AD = 4;
+            f32x4 aq[AD];
+#pragma unroll
+            for (int i = 0; i < AD; ++i) aq[i] = ld4(wbase + i * 64 * 4);
+#pragma unroll 1
+            for (int ch = 0; ch < nchunk; ++ch, ++s) {
+                STAMP(c0)
+                __syncthreads();                        // barrier #s
+                STAMP(c1)
+                const float *vs = lds + L_VS + (s & 1) * 16 * NT * WXS + t16 * WXS + 4 * g;
+                const float *wp = wbase + (size_t)ch * WNCBL * (16 * 64 * 4);
+                // next chunk of this item (clamped to the current one on the last chunk: harmless reload)
+                const float *wn = wbase + (size_t)(ch + 1 < nchunk ? ch + 1 : ch) * WNCBL * (16 * 64 * 4);
+                f32x4 b0[2], b1[2];
+                b0[0] = ld4(vs); b1[0] = ld4(vs + 16 * WXS);
+                unroll_k<16>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    const f32x4 av = aq[k % AD];
+                    if constexpr (k + AD < 16) aq[k % AD] = ld4(wp + (k + AD) * 64 * 4);
+                    else                       aq[k % AD] = ld4(wn + (k + AD - 16) * 64 * 4);
+                    if constexpr (k + 1 < 16) {         // B operands of k+1 in flight during the MFMAs of k
+                        b0[(k + 1) & 1] = ld4(vs + (k + 1) * NT * WXS);
+                        b1[(k + 1) & 1] = ld4(vs + (k + 1) * NT * WXS + 16 * WXS);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        acc[k][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], b0[k & 1][i], acc[k][0], 0, 0, 0);
+                        acc[k][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], b1[k & 1][i], acc[k][1], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                STAMP(c2)
+                STAMP_DO(cw += c1 - c0; cc += c2 - c1;)
+            }
+            STAMP(c2)
+            // ---- output transform Y = A^T M A, bias, ReLU, NHWC stores -----------------------------
+            const int co = (grp * WNCBL + wave) * 16 + 4 * g;
+            const f32x4 bias = ld4(a.bias + co);
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) {
+                const int q = tb * 16 + t16;
+                const int oy = (ry * TRY + q / TRX) * 2, ox = (rx * TRX + q % TRX) * 2;
+                f32x4 t0[4], t1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {           // rows: t = A^T M
+                    t0[j] = acc[0 + j][tb] + acc[4 + j][tb] + acc[8 + j][tb];
+                    t1[j] = acc[4 + j][tb] - acc[8 + j][tb] - acc[12 + j][tb];
+                }
+                f32x4 y[2][2];
+                y[0][0] = t0[0] + t0[1] + t0[2];
+                y[0][1] = t0[1] - t0[2] - t0[3];
+                y[1][0] = t1[0] + t1[1] + t1[2];
+                y[1][1] = t1[1] - t1[2] - t1[3];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        f32x4 v = y[i][j] + bias;
+                        if (a.relu) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
+                        }
+                        if (oy + i < a.Ho && ox + j < a.Wo)
+                            st4(a.out + ((size_t)(n * a.Ho + oy + i) * a.Wo + ox + j) * a.Cout + co, v);
+                    }
+            }
+            STAMP(c3)
+            STAMP_DO(ce += c3 - c2;)
+        }
+        STAMP_DO(if (threadIdx.x == 0) { atomicAdd(g_wstamps + 4, cw); atomicAdd(g_wstamps + 5, cc); atomicAdd(g_wstamps + 6, ce); })
+    }
+}
+
+int wino_lds_bytes() { return WINO_LDS_FLOATS * 4; }
+
+hipError_t launch_wino(const ConvArgs &a, hipStream_t s) {
+    if (a.Cout % (16 * WNCBL) || (a.C0 + a.C1) % WKC || a.C0 % WKC || a.up2) return hipErrorInvalidValue;
+    static const int n_cu = [] { int v = 256; hipDeviceProp_t p; int d = 0;
+                                 if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) v = p.multiProcessorCount;
+                                 return v; }();
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_pc_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, WINO_LDS_FLOATS * 4);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int regs_x = (a.Wo + 2 * TRX - 1) / (2 * TRX), regs_y = (a.Ho + 2 * TRY - 1) / (2 * TRY);
+    const long long nitems = (long long)a.N * regs_x * regs_y * (a.Cout / (16 * WNCBL));
+    dim3 grid((unsigned)(nitems < n_cu ? nitems : n_cu));
+#ifdef UKBB_WINO_STAMPS
+    const bool on = getenv("UKBB_STAMPS") != nullptr;
+    unsigned long long z[8] = {0};
+    if (on) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wstamps), z, 64);
+#endif
+    hipLaunchKernelGGL(wino_pc_kernel, grid, dim3(512), WINO_LDS_FLOATS * 4, s, a);
+#ifdef UKBB_WINO_STAMPS
+    if (on) {
+        unsigned long long h[8];
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wstamps), 64);
+        const double st = (double)h[3];
+        fprintf(stderr, "WINOSTAMPS Cin %d Ho %d: per stage: producer wait %.0f xform %.0f store+load %.0f | consumer wait %.0f "
+                        "mfma %.0f epilogue(avg/stage) %.0f (stages/WG %.0f)\n", a.C0 + a.C1, a.Ho, h[0] / st, h[1] / st, h[2] / st,
+                h[4] / st, h[5] / st, h[6] / st, st / grid.x);
+    }
+#endif
+    return hipGetLastError();
+}
+
+size_t pack_wino_weights(const float *w, int cin, int cout, float *dst) {
+    // w: folded [3][3][cin][cout].  U = G g G^T per (ci, co), G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]].
+    // dst[group][chunk][cbl][k = 4*xi + nu][lane][s]:  lane = (g << 4) | m,
+    //   ci = chunk*16 + 4*g + s, co = (group*4 + cbl)*16 + m          (A fragment of v_mfma_f32_16x16x4_f32)
+    static const float G[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
+    const int nchunk = cin / WKC;
+    size_t o = 0;
+    for (int grp = 0; grp < cout / (16 * WNCBL); ++grp)
+        for (int ch = 0; ch < nchunk; ++ch)
+            for (int cbl = 0; cbl < WNCBL; ++cbl)
+                for (int k = 0; k < 16; ++k)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int s = 0; s < 4; ++s) {
+                            const int m = lane & 15, g = lane >> 4;
+                            const int ci = ch * WKC + 4 * g + s, co = (grp * WNCBL + cbl) * 16 + m;
+                            const int xi = k >> 2, nu = k & 3;
+                            double u = 0.0;                 // exact products of small dyadic factors; one rounding
+                            for (int i = 0; i < 3; ++i)
+                                for (int j = 0; j < 3; ++j)
+                                    u += (double)G[xi][i] * (double)w[((size_t)(i * 3 + j) * cin + ci) * cout + co] * (double)G[nu][j];
+                            dst[o++] = (float)u;
+                        }
+    return o;
+}
+
+}  // namespace ukbb
