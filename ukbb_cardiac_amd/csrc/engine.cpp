@@ -228,7 +228,7 @@ int override_cfg(const std::string &layer) {
 // profiles/r01_tune_convs.txt): {ks, stride, cin, cout, Ho, Wo, cfg}.
 struct Tuned { int ks, stride, cin, cout, ho, wo, cfg; };
 const Tuned g_tuned[] = {
-    {3, 1, 16, 16, 192, 208, 11}, {3, 2, 16, 32, 96, 104, 29},  {3, 1, 32, 32, 96, 104, 15},
+    {3, 1, 16, 16, 192, 208, 11}, {3, 2, 16, 32, 96, 104, 29},  {3, 1, 32, 32, 96, 104, 301},
     {3, 2, 32, 64, 48, 52, 124},  {3, 1, 64, 64, 48, 52, 300},  {3, 2, 64, 128, 24, 26, 22},
     {3, 1, 128, 128, 24, 26, 300},  {3, 2, 128, 256, 12, 13, 31}, {3, 1, 256, 256, 12, 13, 300},
 };
@@ -242,7 +242,7 @@ bool cfg_valid(const ConvConfig &c, int ks, int stride, int c0, int c1, int cout
     if ((c.pc == 3) != bf16) return false;
     if (c.pc == 4) {                                  // Winograd: 3x3 s1, 64-channel output groups, single source ok
         static const bool off = getenv("UKBB_NO_WINOGRAD") != nullptr;
-        return !off && !fused_first && ks == 3 && stride == 1 && cout % 64 == 0 && c0 % 16 == 0 && c1 % 16 == 0;
+        return !off && !fused_first && ks == 3 && stride == 1 && cout % (16 * c.wm) == 0 && c0 % 16 == 0 && c1 % 16 == 0;
     }
     if (c.pc == 2 && cout != c.mb * c.cb * c.wm) return false;   // fused kernel stages its weights once: one Cout group
     if (c.lds_bytes > 160 * 1024) return false;      // LDS per CU on gfx950
@@ -293,7 +293,7 @@ int choose_cfg(const std::string &layer, int ks, int stride, int c0, int c1, int
         // Winograd: one stage (16 input channels of one 8x16 region, 64 output channels) costs ~5.2k cycles
         // per CU measured; 5800 puts it on the scale of the direct estimate above (which ignores the direct
         // kernels' ~70 % matrix-pipe efficiency), calibrated on the three tuned shapes.
-        if (c.pc == 4) cost = (double)tiles * (cout / 64) * ((c0 + c1) / 16) * 5800.0;
+        if (c.pc == 4) cost = (double)tiles * (cout / (16 * c.wm)) * ((c0 + c1) / 16) * (c.wm == 4 ? 5800.0 : 3500.0);
         int rank = 12;
         for (int r = 0; r < (int)(sizeof(g_pref) / sizeof(g_pref[0])); ++r)
             if (g_pref[r] == c.id) { rank = r % 6; break; }
@@ -323,7 +323,7 @@ int ensure_packed(ukbb_fcn_handle *h, int layer, const ConvConfig &c, const floa
     snprintf(key, sizeof key, "%s/pk%s_mb%d_kc%d_g%d", L.name.c_str(), c.pc == 3 ? "bf16" : c.pc == 4 ? "wino" : "", c.mb, c.kc, c.wm * c.cb);
     if (!dev_ptr(h, key)) {
         std::vector<float> pk(c.pc == 4 ? (size_t)16 * L.cin * L.cout : L.w.size());
-        if (c.pc == 4) pack_wino_weights(L.w.data(), L.cin, L.cout, pk.data());
+        if (c.pc == 4) pack_wino_weights(L.w.data(), L.cin, L.cout, c.wm, pk.data());
         else if (c.pc == 3) pack_conv_weights_bf16(L.w.data(), L.ks, L.cin, L.cout, c.wm * c.cb, pk.data());
         else pack_conv_weights(L.w.data(), L.ks, L.cin, L.cout, c.mb, c.kc, c.wm * c.cb, pk.data());
         int rc = upload(h, key, pk);

@@ -39,7 +39,6 @@ constexpr int WKC = 16, WXS = WKC + 4;                // channels per stage, LDS
 constexpr int WIH = 2 * TRY + 2, WIW = 2 * TRX + 2, WHP = WIH * WIW;   // raw halo tile 10 x 18
 constexpr int NITX = (WHP * (WKC / 4) + 255) / 256;   // staging passes of the 256 producer threads (3)
 constexpr int XSZ = NITX * (256 / (WKC / 4)) * WXS;   // floats per XS buffer: padded to 192 pixels, no tail guard
-constexpr int WNCBL = 4;                              // 4 blocks of 16 output channels per item
 constexpr int L_XS = 0;                               // [2][XSZ]
 constexpr int L_VS = L_XS + 2 * XSZ;            // [2][16][NT][WXS]
 constexpr int WINO_LDS_FLOATS = L_VS + 2 * 16 * NT * WXS;
@@ -55,6 +54,18 @@ __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
 }
 __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
     f32x2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+
+__device__ __forceinline__ float relu1(float x) {   // one v_max_f32 (fmaxf adds a canonicalising second one after asm inputs)
+    float r; asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x)); return r;
+}
+__device__ __forceinline__ f32x4 add4(const f32x4 &a, const f32x4 &b) {
+    const f32x2 lo = pk_add(f32x2{a[0], a[1]}, f32x2{b[0], b[1]}), hi = pk_add(f32x2{a[2], a[3]}, f32x2{b[2], b[3]});
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+__device__ __forceinline__ f32x4 sub4(const f32x4 &a, const f32x4 &b) {
+    const f32x2 lo = pk_sub(f32x2{a[0], a[1]}, f32x2{b[0], b[1]}), hi = pk_sub(f32x2{a[2], a[3]}, f32x2{b[2], b[3]});
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
 }
 
 template <int N, int I = 0, class F>
@@ -73,7 +84,12 @@ __device__ unsigned long long g_wstamps[8];
 #define STAMP(v)
 #define STAMP_DO(...)
 #endif
+// NCB = blocks of 16 output channels per item.  NCB = 4: consumer wave w owns channel block w and both
+// 16-tile halves of the region (128 MFMAs per stage); NCB = 2 (layers with 32 output channels):
+// wave w owns channel block w & 1 and tile half w >> 1 (64 MFMAs per stage).
+template <int NCB>
 __global__ __launch_bounds__(512, 2) void wino_pc_kernel(const ConvArgs a) {
+    constexpr int WNCBL = NCB, TBW = NCB == 4 ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int cin = a.C0 + a.C1;
     const int nchunk = cin / WKC;
@@ -153,11 +169,10 @@ __global__ __launch_bounds__(512, 2) void wino_pc_kernel(const ConvArgs a) {
         const int xt = tid & 127, x_tile = xt / C4, x_q = xt - x_tile * C4;
         const float *const xs_r = lds + L_XS + ((2 * (x_tile / TRX) + half) * WIW + 2 * (x_tile % TRX)) * WXS + 4 * x_q;
         float *const vs_w = lds + L_VS + half * 8 * NT * WXS + x_tile * WXS + 4 * x_q;
-        auto xform = [&](auto par) {
+        f32x2 e[3][4][2];
+        auto xform_read = [&](auto par) {               // issue the 12 patch reads of this thread
             constexpr int B = decltype(par)::value;
             const float *xs = xs_r + B * XSZ;
-            float *vs = vs_w + B * 16 * NT * WXS;
-            f32x2 e[3][4][2];
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -165,7 +180,10 @@ __global__ __launch_bounds__(512, 2) void wino_pc_kernel(const ConvArgs a) {
                     const f32x4 v = ld4(xs + (i * WIW + j) * WXS);
                     e[i][j][0] = f32x2{v[0], v[1]}; e[i][j][1] = f32x2{v[2], v[3]};
                 }
-            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto xform_finish = [&](auto par) {             // row pass, column pass, 8 writes
+            constexpr int B = decltype(par)::value;
+            float *vs = vs_w + B * 16 * NT * WXS;
             auto put = [&](int k, const f32x2 &lo, const f32x2 &hi) { st4(vs + k * NT * WXS, f32x4{lo[0], lo[1], hi[0], hi[1]}); };
             auto rows = [&](auto hc) {                  // a real (uniform) branch per wave pair: stores inside keep it from being if-converted
                 constexpr int HALF = decltype(hc)::value;
@@ -196,16 +214,22 @@ __global__ __launch_bounds__(512, 2) void wino_pc_kernel(const ConvArgs a) {
         if (nstages > 1) { loadx(); storex(P1); }
         if (nstages > 2) loadx();
         __syncthreads();                                // barrier X: XS[0], XS[1] visible to every producer
-        if (nstages > 0) xform(P0);
+        if (nstages > 0) { xform_read(P0); xform_finish(P0); }
         STAMP_DO(unsigned long long pw = 0, px_ = 0, pl = 0, t0, t1, t2, t3;)
+        // One stage of the producer role.  The patch reads of the transform are issued first and their
+        // latency is covered by parking stage s+2 in XS and requesting stage s+3 from global memory.
         auto stage = [&](auto par, auto npar, int s) {
             STAMP(t0)
             __syncthreads();                            // barrier #s: VS[s&1] ready / VS[(s+1)&1], XS[s&1] free
             STAMP(t1)
-            if (s + 1 < nstages) xform(npar);
-            STAMP(t2)
+            const bool xf = s + 1 < nstages;
+            if (xf) xform_read(npar);
+            __builtin_amdgcn_sched_barrier(0);
             if (s + 2 < nstages) storex(par);           // stage s+2 (requested an iteration ago) replaces stage s
             if (s + 3 < nstages) loadx();
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP(t2)
+            if (xf) xform_finish(npar);
             STAMP(t3)
             STAMP_DO(pw += t1 - t0; px_ += t2 - t1; pl += t3 - t2;)
         };
@@ -216,91 +240,112 @@ __global__ __launch_bounds__(512, 2) void wino_pc_kernel(const ConvArgs a) {
         }
         STAMP_DO(if (threadIdx.x == 256) { atomicAdd(g_wstamps + 0, pw); atomicAdd(g_wstamps + 1, px_); atomicAdd(g_wstamps + 2, pl); atomicAdd(g_wstamps + 3, (unsigned long long)nstages); })
     } else {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;   // wave = Cout block within the item
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        const int wave = NCB == 4 ? wid : (wid & 1);        // Cout block within the item
+        const int tb0 = NCB == 4 ? 0 : (wid >> 1);         // first 16-tile block of this wave
         const int t16 = lane & 15, g = lane >> 4;
         __syncthreads();                                // barrier X
         int s = 0;
+        constexpr int AD = TBW == 2 ? 4 : 8;             // A-fragment queue depth (k positions)
+        constexpr int BA = TBW == 2 ? 1 : 2, BR = BA + 1; // B lookahead (k positions) and ring size
+        f32x4 aq[AD];
         STAMP_DO(unsigned long long cw = 0, cc = 0, ce = 0, c0, c1, c2, c3;)
         for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
             const int grp = item / per_group, rest = item - grp * per_group;
             const int n = rest / regions, r = rest - n * regions;
             const int ry = r / regs_x, rx = r - ry * regs_x;
-            f32x4 acc[16][2];
-#pragma unroll
-            for (int k = 0; k < 16; ++k)
-#pragma unroll
-                for (int tb = 0; tb < 2; ++tb) acc[k][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int co = (grp * WNCBL + wave) * 16 + 4 * g;
+            const f32x4 bias = ld4(a.bias + co);        // needed after the last chunk; in flight during the stages
+            // Accumulators are never zeroed with moves: the first MFMA of the first chunk takes its C operand
+            // as the constant 0 -- or, for Winograd position (1,1), the bias: A^T M A adds M[1][1] to all four
+            // outputs of the tile, so the folded-BN bias rides through the output transform for free.
+            f32x4 acc[16][TBW];
             // packed weights: [group][chunk][cbl][k][lane][4].  A fragments come straight from global/L2,
-            // through a rolling 4-deep register queue over the flattened (chunk, k) sequence: the load for
-            // k+4 is issued before the MFMAs of k (4 x 256 MFMA cycles cover the L2 latency), and the queue
-            // runs across stage barriers (the first fragments of the next chunk are requested during the
-            // last k of the current one).
+            // through a rolling register queue over the flattened (item, chunk, k) sequence: the load for
+            // k+AD is issued before the MFMAs of k (AD x 256 or 128 MFMA cycles cover the L2 latency); the
+            // queue runs across stage barriers and across items (the last chunk of an item requests the
+            // first fragments of the next item's channel group).
             const float *wbase = a.wpk + ((size_t)grp * nchunk * WNCBL + wave) * (16 * 64 * 4) + lane * 4;
-            constexpr int AD = 4;
-            f32x4 aq[AD];
+            const int item_n = item + (int)gridDim.x < nitems ? item + (int)gridDim.x : item;
+            const float *wnext = a.wpk + ((size_t)(item_n / per_group) * nchunk * WNCBL + wave) * (16 * 64 * 4) + lane * 4;
+            if (item == (int)blockIdx.x) {
 #pragma unroll
-            for (int i = 0; i < AD; ++i) aq[i] = ld4(wbase + i * 64 * 4);
-#pragma unroll 1
-            for (int ch = 0; ch < nchunk; ++ch, ++s) {
+                for (int i = 0; i < AD; ++i) aq[i] = ld4(wbase + i * 64 * 4);
+            }
+            auto chunk = [&](auto firstc, int ch) {
+                constexpr bool FIRST = decltype(firstc)::value;
                 STAMP(c0)
                 __syncthreads();                        // barrier #s
                 STAMP(c1)
-                const float *vs = lds + L_VS + (s & 1) * 16 * NT * WXS + t16 * WXS + 4 * g;
+                const float *vs = lds + L_VS + (s & 1) * 16 * NT * WXS + (tb0 * 16 + t16) * WXS + 4 * g;
                 const float *wp = wbase + (size_t)ch * WNCBL * (16 * 64 * 4);
-                // next chunk of this item (clamped to the current one on the last chunk: harmless reload)
-                const float *wn = wbase + (size_t)(ch + 1 < nchunk ? ch + 1 : ch) * WNCBL * (16 * 64 * 4);
-                f32x4 b0[2], b1[2];
-                b0[0] = ld4(vs); b1[0] = ld4(vs + 16 * WXS);
+                const float *wn = ch + 1 < nchunk ? wp + WNCBL * (16 * 64 * 4) : wnext;
+                f32x4 b0[BR], b1[BR];
+#pragma unroll
+                for (int i = 0; i < BA; ++i) {
+                    b0[i] = ld4(vs + i * NT * WXS);
+                    if constexpr (TBW == 2) b1[i] = ld4(vs + i * NT * WXS + 16 * WXS);
+                }
                 unroll_k<16>([&](auto kc) {
                     constexpr int k = decltype(kc)::value;
                     const f32x4 av = aq[k % AD];
                     if constexpr (k + AD < 16) aq[k % AD] = ld4(wp + (k + AD) * 64 * 4);
                     else                       aq[k % AD] = ld4(wn + (k + AD - 16) * 64 * 4);
-                    if constexpr (k + 1 < 16) {         // B operands of k+1 in flight during the MFMAs of k
-                        b0[(k + 1) & 1] = ld4(vs + (k + 1) * NT * WXS);
-                        b1[(k + 1) & 1] = ld4(vs + (k + 1) * NT * WXS + 16 * WXS);
+                    if constexpr (k + BA < 16) {        // B operands of k+BA in flight during the MFMAs of k
+                        b0[(k + BA) % BR] = ld4(vs + (k + BA) * NT * WXS);
+                        if constexpr (TBW == 2) b1[(k + BA) % BR] = ld4(vs + (k + BA) * NT * WXS + 16 * WXS);
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (FIRST) {
+                        const f32x4 c0v = k == 5 ? bias : f32x4{0.f, 0.f, 0.f, 0.f};
+                        acc[k][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], b0[k % BR][0], c0v, 0, 0, 0);
+                        if constexpr (TBW == 2)
+                            acc[k][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], b1[k % BR][0], c0v, 0, 0, 0);
+                    }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        acc[k][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], b0[k & 1][i], acc[k][0], 0, 0, 0);
-                        acc[k][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], b1[k & 1][i], acc[k][1], 0, 0, 0);
+                    for (int i = FIRST ? 1 : 0; i < 4; ++i) {
+                        acc[k][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], b0[k % BR][i], acc[k][0], 0, 0, 0);
+                        if constexpr (TBW == 2)
+                            acc[k][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], b1[k % BR][i], acc[k][1], 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 });
                 STAMP(c2)
                 STAMP_DO(cw += c1 - c0; cc += c2 - c1;)
-            }
+                ++s;
+            };
+            chunk(std::true_type{}, 0);
+#pragma unroll 1
+            for (int ch = 1; ch < nchunk; ++ch) chunk(std::false_type{}, ch);
             STAMP(c2)
             // ---- output transform Y = A^T M A, bias, ReLU, NHWC stores -----------------------------
-            const int co = (grp * WNCBL + wave) * 16 + 4 * g;
-            const f32x4 bias = ld4(a.bias + co);
 #pragma unroll
-            for (int tb = 0; tb < 2; ++tb) {
-                const int q = tb * 16 + t16;
+            for (int tb = 0; tb < TBW; ++tb) {
+                const int q = (tb0 + tb) * 16 + t16;
                 const int oy = (ry * TRY + q / TRX) * 2, ox = (rx * TRX + q % TRX) * 2;
                 f32x4 t0[4], t1[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {           // rows: t = A^T M
-                    t0[j] = acc[0 + j][tb] + acc[4 + j][tb] + acc[8 + j][tb];
-                    t1[j] = acc[4 + j][tb] - acc[8 + j][tb] - acc[12 + j][tb];
+                    t0[j] = add4(add4(acc[0 + j][tb], acc[4 + j][tb]), acc[8 + j][tb]);
+                    t1[j] = sub4(sub4(acc[4 + j][tb], acc[8 + j][tb]), acc[12 + j][tb]);
                 }
                 f32x4 y[2][2];
-                y[0][0] = t0[0] + t0[1] + t0[2];
-                y[0][1] = t0[1] - t0[2] - t0[3];
-                y[1][0] = t1[0] + t1[1] + t1[2];
-                y[1][1] = t1[1] - t1[2] - t1[3];
+                y[0][0] = add4(add4(t0[0], t0[1]), t0[2]);
+                y[0][1] = sub4(sub4(t0[1], t0[2]), t0[3]);
+                y[1][0] = add4(add4(t1[0], t1[1]), t1[2]);
+                y[1][1] = sub4(sub4(t1[1], t1[2]), t1[3]);
+                float *const o00 = a.out + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.Cout + co;
+                const size_t dx = (size_t)a.Cout, dy = (size_t)a.Wo * a.Cout;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        f32x4 v = y[i][j] + bias;
+                        f32x4 v = y[i][j];
                         if (a.relu) {
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
+                            for (int c = 0; c < 4; ++c) v[c] = relu1(v[c]);
                         }
-                        if (oy + i < a.Ho && ox + j < a.Wo)
-                            st4(a.out + ((size_t)(n * a.Ho + oy + i) * a.Wo + ox + j) * a.Cout + co, v);
+                        if (oy + i < a.Ho && ox + j < a.Wo) st4(o00 + i * dy + j * dx, v);
                     }
             }
             STAMP(c3)
@@ -312,41 +357,47 @@ __global__ __launch_bounds__(512, 2) void wino_pc_kernel(const ConvArgs a) {
 
 int wino_lds_bytes() { return WINO_LDS_FLOATS * 4; }
 
-hipError_t launch_wino(const ConvArgs &a, hipStream_t s) {
-    if (a.Cout % (16 * WNCBL) || (a.C0 + a.C1) % WKC || a.C0 % WKC || a.up2) return hipErrorInvalidValue;
+template <int NCB>
+static hipError_t launch_wino_t(const ConvArgs &a, hipStream_t s) {
+    if (a.Cout % (16 * NCB) || (a.C0 + a.C1) % WKC || a.C0 % WKC || a.up2) return hipErrorInvalidValue;
     static const int n_cu = [] { int v = 256; hipDeviceProp_t p; int d = 0;
                                  if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) v = p.multiProcessorCount;
                                  return v; }();
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_pc_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_pc_kernel<NCB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, WINO_LDS_FLOATS * 4);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     const int regs_x = (a.Wo + 2 * TRX - 1) / (2 * TRX), regs_y = (a.Ho + 2 * TRY - 1) / (2 * TRY);
-    const long long nitems = (long long)a.N * regs_x * regs_y * (a.Cout / (16 * WNCBL));
+    const long long nitems = (long long)a.N * regs_x * regs_y * (a.Cout / (16 * NCB));
     dim3 grid((unsigned)(nitems < n_cu ? nitems : n_cu));
 #ifdef UKBB_WINO_STAMPS
     const bool on = getenv("UKBB_STAMPS") != nullptr;
     unsigned long long z[8] = {0};
     if (on) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wstamps), z, 64);
 #endif
-    hipLaunchKernelGGL(wino_pc_kernel, grid, dim3(512), WINO_LDS_FLOATS * 4, s, a);
+    hipLaunchKernelGGL(wino_pc_kernel<NCB>, grid, dim3(512), WINO_LDS_FLOATS * 4, s, a);
 #ifdef UKBB_WINO_STAMPS
     if (on) {
         unsigned long long h[8];
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wstamps), 64);
         const double st = (double)h[3];
-        fprintf(stderr, "WINOSTAMPS Cin %d Ho %d: per stage: producer wait %.0f xform %.0f store+load %.0f | consumer wait %.0f "
-                        "mfma %.0f epilogue(avg/stage) %.0f (stages/WG %.0f)\n", a.C0 + a.C1, a.Ho, h[0] / st, h[1] / st, h[2] / st,
+        fprintf(stderr, "WINOSTAMPS Cin %d Cout %d Ho %d: per stage: producer wait %.0f read+store+load %.0f transform %.0f | consumer wait %.0f "
+                        "mfma %.0f epilogue(avg/stage) %.0f (stages/WG %.0f)\n", a.C0 + a.C1, a.Cout, a.Ho, h[0] / st, h[1] / st, h[2] / st,
                 h[4] / st, h[5] / st, h[6] / st, st / grid.x);
     }
 #endif
     return hipGetLastError();
 }
 
-size_t pack_wino_weights(const float *w, int cin, int cout, float *dst) {
+hipError_t launch_wino(const ConvArgs &a, int ncb, hipStream_t s) {
+    return ncb == 4 ? launch_wino_t<4>(a, s) : ncb == 2 ? launch_wino_t<2>(a, s) : hipErrorInvalidValue;
+}
+
+size_t pack_wino_weights(const float *w, int cin, int cout, int ncb, float *dst) {
+    const int WNCBL = ncb;
     // w: folded [3][3][cin][cout].  U = G g G^T per (ci, co), G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]].
     // dst[group][chunk][cbl][k = 4*xi + nu][lane][s]:  lane = (g << 4) | m,
     //   ci = chunk*16 + 4*g + s, co = (group*4 + cbl)*16 + m          (A fragment of v_mfma_f32_16x16x4_f32)
