@@ -38,6 +38,11 @@ __host__ __device__ __forceinline__ constexpr int rowmap(int r, int g) {
     return (r & 3) + 8 * (r >> 2) + 4 * g;
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 r; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
+}
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 __device__ __forceinline__ f32x4 ldg4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
@@ -55,9 +60,18 @@ __device__ __forceinline__ f32x16 bias_tile(const float *bias, int g) {
     return acc;
 }
 
+// ReLU as one integer max: for IEEE floats max_i32(bits(x), 0) is x for x >= +0 and +0 for anything
+// with the sign bit set.  fmaxf() on an MFMA result compiles to two instructions (a canonicalising
+// max and the max), and on gfx950 every VALU instruction takes issue time away from the fp32 MFMA
+// stream (tools/mfma_coissue.hip).  Deliberately not inline asm: the compiler must see a VALU read of
+// the accumulator to insert the MFMA -> VALU wait states.
+__device__ __forceinline__ float relu1(float x) {
+    const int b = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
 __device__ __forceinline__ void relu16(f32x16 &acc) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);
+    for (int r = 0; r < 16; ++r) acc[r] = relu1(acc[r]);
 }
 
 // D0/D1 (two Cout blocks of 32) += W[64][32 rows of X] * X, X given as an accumulator tile.
@@ -390,47 +404,71 @@ __global__ __launch_bounds__(768) void fcn_head_pc_kernel(const HeadArgs a) {
         // level, so level, window width and the row/column split are compile-time per iteration:
         // l=1: 81 px -> 3 iterations, l=2: 36 -> 2, l=3: 16 -> 1, l=4: 9 -> 1.
         constexpr int NIT = 7;
-        f32x4 gv[NIT];
+        u32x4 gv[NIT];
         const int sp32 = tid >> 4, c4 = tid & 15;
+        // Every VALU instruction of this role takes issue time from the consumers' MFMA stream (they
+        // share the SIMDs), so the staging keeps its per-tile arithmetic on the scalar unit: per-thread
+        // window coordinates and byte offsets are computed once, validity is one and/compare against a
+        // per-tile row|column mask, and taps outside the map are buffer loads with an out-of-range
+        // offset (the hardware returns 0, border taps are dropped).
+        unsigned tbit[NIT], goff[NIT];
+        unroll_n<NIT>([&](auto ic) {
+            constexpr int it = decltype(ic)::value;
+            constexpr int l = it < 3 ? 1 : it < 5 ? 2 : it < 6 ? 3 : 4;
+            constexpr int it0 = l == 1 ? 0 : l == 2 ? 3 : l == 3 ? 5 : 6;
+            constexpr int wn_ = win_n(l);
+            const int rel = (it - it0) * 32 + sp32;
+            const int ry = rel / wn_, rx = rel - ry * wn_;
+            tbit[it] = rel < wn_ * wn_ ? (1u << ry) | (1u << (16 + rx)) : 0x80000000u;   // bit 31 never set in a tile mask
+            goff[it] = (unsigned)((ry * (a.W >> l) + rx) * 64 + 4 * c4) * 4u;
+        });
         auto g_load = [&](int k) {                      // G windows of this workgroup's k-th tile -> registers
             int bid = blockIdx.x + k * gridDim.x;
             const int tx = bid % tiles_x; bid /= tiles_x;
             const int ty = bid % tiles_y;
             const int n = bid / tiles_y;
             const int y0 = ty * HT, x0 = tx * HT;
+            __amdgpu_buffer_rsrc_t rs[4];
+            unsigned cm[4];
+#pragma unroll
+            for (int l = 1; l <= 4; ++l) {
+                const int hl = a.H >> l, wl = a.W >> l, wn_ = win_n(l);
+                const int sy0 = (y0 >> l) - 1, sx0 = (x0 >> l) - 1;     // window origin in the level-l map
+                const int ylo = sy0 < 0 ? -sy0 : 0, yhi = hl - sy0 < wn_ ? hl - sy0 : wn_;
+                const int xlo = sx0 < 0 ? -sx0 : 0, xhi = wl - sx0 < wn_ ? wl - sx0 : wn_;
+                cm[l - 1] = (((1u << yhi) - 1u) & ~((1u << ylo) - 1u)) | ((((1u << xhi) - 1u) & ~((1u << xlo) - 1u)) << 16);
+                const float *base = a.G[l - 1] + ((long long)(n * hl + sy0) * wl + sx0) * 64;   // may precede the map; masked lanes never use it
+                rs[l - 1] = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0x7fffffff, 0x00020000);
+            }
             unroll_n<NIT>([&](auto ic) {
                 constexpr int it = decltype(ic)::value;
                 constexpr int l = it < 3 ? 1 : it < 5 ? 2 : it < 6 ? 3 : 4;
-                constexpr int it0 = l == 1 ? 0 : l == 2 ? 3 : l == 3 ? 5 : 6;
-                constexpr int wn_ = win_n(l);
-                const int rel = (it - it0) * 32 + sp32;
-                const int ry = rel / wn_, rx = rel - ry * wn_;
-                const int hl = a.H >> l, wl = a.W >> l;
-                const int sy = (y0 >> l) - 1 + ry, sx = (x0 >> l) - 1 + rx;
-                const bool ok = rel < wn_ * wn_ && (unsigned)sy < (unsigned)hl && (unsigned)sx < (unsigned)wl;
-                // unconditional load from a clamped address (keeps the prefetch asynchronous);
-                // out-of-map taps become zeros (border taps are dropped)
-                const f32x4 t = ldg4(a.G[l - 1] + (ok ? (((size_t)n * hl + sy) * wl + sx) * 64 + 4 * c4 : 0));
-                gv[it] = ok ? t : f32x4{0.f, 0.f, 0.f, 0.f};
+                const unsigned vo = (cm[l - 1] & tbit[it]) == tbit[it] ? goff[it] : 0x80000000u;
+                gv[it] = __builtin_amdgcn_raw_buffer_load_b128(rs[l - 1], vo, 0, 0);
             });
         };
+        float *const gdst = gw + sp32 * GSTRIDE + 4 * c4;
         auto g_store = [&](int b) {
-            float *dst = gw + b * GPIX * GSTRIDE;
+            float *dst = gdst + b * GPIX * GSTRIDE;
             unroll_n<NIT>([&](auto ic) {
                 constexpr int it = decltype(ic)::value;
                 constexpr int l = it < 3 ? 1 : it < 5 ? 2 : it < 6 ? 3 : 4;
                 constexpr int it0 = l == 1 ? 0 : l == 2 ? 3 : l == 3 ? 5 : 6;
                 const int rel = (it - it0) * 32 + sp32;
                 if (rel < win_n(l) * win_n(l))
-                    *reinterpret_cast<f32x4 *>(dst + (win_base(l) + rel) * GSTRIDE + 4 * c4) = gv[it];
+                    *reinterpret_cast<u32x4 *>(dst + (win_base(l) + (it - it0) * 32) * GSTRIDE) = gv[it];
             });
         };
-        f32x16 P;
-        auto gather = [&](int s) {                      // stage s: tile k = s>>1, block 2*pw + (s&1)  -> P (32 channels)
-            const float *gl = gw + ((s >> 1) & 1) * GPIX * GSTRIDE + 32 * half;
-            const int blk = pw * 2 + (s & 1);
+        // Gather constants of this thread, for both block parities (a wave alternates between the two
+        // 32-pixel blocks 2*pw and 2*pw+1 of a tile): LDS offset of the top-left tap and the four tap
+        // weights per level.  Computed once; the stage loop is unrolled by four so the block parity and
+        // the window buffer are compile-time and every LDS address is base register + immediate.
+        int tap0[2][4];
+        float tw[2][4][4];
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            const int blk = pw * 2 + par;
             const int yl = 2 * blk + (p >> 4), xl = p & 15;
-            P = bias_tile_lds(lds + L_BO0 + 32 * half, g);
 #pragma unroll
             for (int l = 1; l <= 4; ++l) {
                 const int f = 1 << l, pb = (f - 1) >> 1;
@@ -440,10 +478,21 @@ __global__ __launch_bounds__(768) void fcn_head_pc_kernel(const HeadArgs a) {
                 const int jy = tyy & (f - 1), jx = txx & (f - 1);
                 const float wy1 = (float)(jy + 1) * inv, wy0 = (float)(f - 1 - jy) * inv;
                 const float wx1 = (float)(jx + 1) * inv, wx0 = (float)(f - 1 - jx) * inv;
+                tap0[par][l - 1] = (win_base(l) + (ry1 - 1) * win_n(l) + (rx1 - 1)) * GSTRIDE + 4 * g + 32 * half;
+                tw[par][l - 1][0] = wy0 * wx0; tw[par][l - 1][1] = wy0 * wx1;
+                tw[par][l - 1][2] = wy1 * wx0; tw[par][l - 1][3] = wy1 * wx1;
+            }
+        }
+        f32x16 P;
+        auto gather = [&](auto parc, auto bufc) {       // block 2*pw + PAR of the tile staged in window buffer BUF -> P (32 channels)
+            constexpr int PAR = decltype(parc)::value, BUF = decltype(bufc)::value;
+            P = bias_tile_lds(lds + L_BO0 + 32 * half, g);
+#pragma unroll
+            for (int l = 1; l <= 4; ++l) {
                 const int wn_ = win_n(l);
-                const float *b11 = gl + (win_base(l) + ry1 * wn_ + rx1) * GSTRIDE + 4 * g;
-                const float *b10 = b11 - GSTRIDE, *b01 = b11 - wn_ * GSTRIDE, *b00 = b01 - GSTRIDE;
-                const float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
+                const float *b00 = gw + BUF * GPIX * GSTRIDE + tap0[PAR][l - 1];
+                const float *b01 = b00 + GSTRIDE, *b10 = b00 + wn_ * GSTRIDE, *b11 = b10 + GSTRIDE;
+                const float w00 = tw[PAR][l - 1][0], w01 = tw[PAR][l - 1][1], w10 = tw[PAR][l - 1][2], w11 = tw[PAR][l - 1][3];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const f32x4 a00 = lds4(b00 + 8 * j), a01 = lds4(b01 + 8 * j), a10 = lds4(b10 + 8 * j), a11 = lds4(b11 + 8 * j);
@@ -463,26 +512,31 @@ __global__ __launch_bounds__(768) void fcn_head_pc_kernel(const HeadArgs a) {
                 *reinterpret_cast<f32x4 *>(dst + j * 256) = v;
             }
         };
-        // prologue: windows of tiles 0 and 1 into LDS, tile 2 stays in registers until GW[0] is free
-#pragma unroll 1
-        for (int k = 0; k < 3; ++k) {
-            if (k < my_tiles) {
-                g_load(k);
-                if (k < 2) g_store(k);
-            }
-        }
+        // prologue: windows of tiles 0 and 1 into LDS
+        if (my_tiles > 0) { g_load(0); g_store(0); }
+        if (my_tiles > 1) { g_load(1); g_store(1); }
         __syncthreads();                                // barrier X: weights, GW[0], GW[1] visible
-#pragma unroll 1
-        for (int s = 0; s < nstages; ++s) {
-            gather(s);                                  // LDS windows -> registers (consumers still busy with s-1)
+        auto stage = [&](auto parc, auto bufc, int s) {
+            constexpr int PAR = decltype(parc)::value, BUF = decltype(bufc)::value;
+            gather(parc, bufc);                         // LDS windows -> registers (consumers still busy with s-1)
             hand_over();                                // px was released at barrier B of stage s-1
             __syncthreads();                            // barrier A_s: px ready
             __syncthreads();                            // barrier B_s: px consumed
-            if (s & 1) {                                // tile k = s>>1 fully gathered: its window buffer is free
+            if constexpr (PAR == 1) {                   // tile k = s>>1 fully gathered: its window buffer is free
+                // Fetch the windows of tile k+2 into it now, synchronously: the producers are far ahead of the
+                // MFMA waves (they would only wait at barrier A), and a prefetch held in registers across the
+                // next two gathers pushed the kernel into scratch spills.
                 const int k = s >> 1;
-                if (k + 2 < my_tiles) g_store(k & 1);   // G(k+2), requested two stages ago
-                if (k + 3 < my_tiles) g_load(k + 3);
+                if (k + 2 < my_tiles) { g_load(k + 2); g_store(BUF); }
             }
+        };
+        constexpr std::integral_constant<int, 0> I0{};
+        constexpr std::integral_constant<int, 1> I1{};
+#pragma unroll 1
+        for (int s = 0; s < nstages; s += 4) {          // nstages is even
+            stage(I0, I0, s);
+            stage(I1, I0, s + 1);
+            if (s + 2 < nstages) { stage(I0, I1, s + 2); stage(I1, I1, s + 3); }
         }
     } else {
         const int wave = threadIdx.x >> 6;
@@ -546,23 +600,26 @@ __global__ __launch_bounds__(768) void fcn_head_pc_kernel(const HeadArgs a) {
             relu16(Q0);
             relu16(Q1);
             // ---- logits / softmax / argmax ----
+            // Packed over channel pairs (weights and activations are both consecutive registers), so
+            // each class costs 16 v_pk_fma_f32 + 1 add and no operand shuffling.
             float lg[NCLS];
 #pragma unroll
             for (int c = 0; c < NCLS; ++c) {
                 const float *wp = w_lg + (g * NCLS + c) * 32;
-                float acc = 0.f;
+                f32x2 acc2 = {0.f, 0.f};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const f32x4 w = lds4(wp + 4 * j);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc = fmaf(w[i], Q0[4 * j + i], acc);
+                    acc2 = pk_fma(f32x2{w[0], w[1]}, f32x2{Q0[4 * j], Q0[4 * j + 1]}, acc2);
+                    acc2 = pk_fma(f32x2{w[2], w[3]}, f32x2{Q0[4 * j + 2], Q0[4 * j + 3]}, acc2);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const f32x4 w = lds4(wp + 16 + 4 * j);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc = fmaf(w[i], Q1[4 * j + i], acc);
+                    acc2 = pk_fma(f32x2{w[0], w[1]}, f32x2{Q1[4 * j], Q1[4 * j + 1]}, acc2);
+                    acc2 = pk_fma(f32x2{w[2], w[3]}, f32x2{Q1[4 * j + 2], Q1[4 * j + 3]}, acc2);
                 }
+                const float acc = acc2[0] + acc2[1];
                 const float other = __shfl_xor(acc, 32);
                 lg[c] = (g == 0 ? acc + other : other + acc) + lds[L_BLG + c];
             }

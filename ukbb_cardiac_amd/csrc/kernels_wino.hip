@@ -56,8 +56,9 @@ __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
     f32x2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r;
 }
 
-__device__ __forceinline__ float relu1(float x) {   // one v_max_f32 (fmaxf adds a canonicalising second one after asm inputs)
-    float r; asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x)); return r;
+__device__ __forceinline__ float relu1(float x) {   // one v_max_i32 (fmaxf adds a canonicalising second instruction)
+    const int b = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
 }
 __device__ __forceinline__ f32x4 add4(const f32x4 &a, const f32x4 &b) {
     const f32x2 lo = pk_add(f32x2{a[0], a[1]}, f32x2{b[0], b[1]}), hi = pk_add(f32x2{a[2], a[3]}, f32x2{b[2], b[3]});
@@ -319,6 +320,9 @@ __global__ __launch_bounds__(512, 2) void wino_pc_kernel(const ConvArgs a) {
             for (int ch = 1; ch < nchunk; ++ch) chunk(std::false_type{}, ch);
             STAMP(c2)
             // ---- output transform Y = A^T M A, bias, ReLU, NHWC stores -----------------------------
+            // The packed adds below are inline asm, which the compiler's hazard recogniser does not treat as a
+            // VALU read of MFMA results: cover the MFMA -> VALU wait states (11 for this 8-pass MFMA) by hand.
+            asm volatile("s_nop 15" ::: "memory");
 #pragma unroll
             for (int tb = 0; tb < TBW; ++tb) {
                 const int q = (tb0 + tb) * 16 + t16;
