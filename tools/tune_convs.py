@@ -36,19 +36,21 @@ if __name__ == '__main__':
         return res
 
     names, cfgs, base, macs = measure('')
-    ids = [i for i in range(128) if _lib.lib.ukbb_fcn_conv_config_name(i)]
+    ids = [i for i in range(400) if _lib.lib.ukbb_fcn_conv_config_name(i)]
     best = {}
     for li, nm in enumerate(names):
         if cfgs[li] < 0:
             continue
         rows = []
         for cid in ids:
-            nm2, cf2, t2, _ = measure('%s:%d' % (nm, cid))
+            nm2, cf2, t2, _ = measure('%s:%d' % (nm.split('+')[-1], cid))   # fused kernels are keyed by their last layer
             if cf2[li] != cid:
                 continue                      # tiling not valid for this layer
             rows.append((t2[li], cid))
         rows.sort()
-        best[nm] = rows[0][1]
+        if not rows:
+            continue
+        best[nm.split('+')[-1]] = rows[0][1]
         peak = 157.3e12
         print('%-10s default cfg %2d %7.1f us | ' % (nm, cfgs[li], base[li] * 1e3) + '  '.join(
             '%d:%.1f(%.0f%%)' % (cid, t * 1e3, 100 * 2 * macs[li] / (t * 1e-3) / peak) for t, cid in rows), flush=True)

@@ -228,9 +228,9 @@ int override_cfg(const std::string &layer) {
 // profiles/r01_tune_convs.txt): {ks, stride, cin, cout, Ho, Wo, cfg}.
 struct Tuned { int ks, stride, cin, cout, ho, wo, cfg; };
 const Tuned g_tuned[] = {
-    {3, 1, 16, 16, 192, 208, 11}, {3, 2, 16, 32, 96, 104, 29},  {3, 1, 32, 32, 96, 104, 301},
+    {3, 1, 16, 16, 192, 208, 11}, {3, 2, 16, 32, 96, 104, 123},  {3, 1, 32, 32, 96, 104, 301},
     {3, 2, 32, 64, 48, 52, 124},  {3, 1, 64, 64, 48, 52, 300},  {3, 2, 64, 128, 24, 26, 22},
-    {3, 1, 128, 128, 24, 26, 300},  {3, 2, 128, 256, 12, 13, 31}, {3, 1, 256, 256, 12, 13, 300},
+    {3, 1, 128, 128, 24, 26, 300},  {3, 2, 128, 256, 12, 13, 24}, {3, 1, 256, 256, 12, 13, 300},
 };
 // Fallback preference (small tiles / high occupancy won everywhere in the sweep).
 const int g_pref[] = {4, 5, 18, 3, 11, 7, 31, 23, 22, 29, 27, 26};

@@ -29,6 +29,13 @@ namespace ukbb {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// ReLU as one v_max_i32 on the bit pattern (fmaxf on an MFMA result compiles to two v_max_f32).
+__device__ __forceinline__ float relu_bits(float x) {
+    const int b = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
 
 template <int MB> struct Mfma;
 template <> struct Mfma<32> {
@@ -473,31 +480,98 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
                 }
             }
         } else {
-            auto load = [&]() {
+            // Lean producer (r01: fp32 MFMA and VALU instructions serialise on a SIMD, tools/mfma_coissue.hip,
+            // so every VALU instruction here is time taken from the consumers).  Halo-tile coordinates and
+            // byte offsets of this thread's float4s are computed once; per stage the scalar unit builds a
+            // buffer descriptor at the tile origin and the valid row/column range; pixels outside the image
+            // are buffer loads with an out-of-range offset (the hardware returns 0 = this conv's zero
+            // padding, no select at the LDS write); tiles entirely inside the image skip the range test.
+            int hy[NIT], hx[NIT];
+            unsigned pre[NIT];
+            u32x4 xq[NIT], wq[NWT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int pix = pix0 + it * PSTEP;
+                hy[it] = pix / IW; hx[it] = pix - hy[it] * IW;
+                pre[it] = 0x80000000u;
+            }
+            unsigned wvo[NWT];
+#pragma unroll
+            for (int it = 0; it < NWT; ++it) wvo[it] = it * 256 + tid < WF4 ? 16u * (it * 256 + tid) : 0x80000000u;
+            int cur_cs = 0;
+            int n_ = 0, iy0_ = 0, ix0_ = 0, grp_ = 0;
+            auto locate = [&]() {
+                grp_ = item / per_group;
+                const int rest = item - grp_ * per_group;
+                n_ = rest / tiles;
+                const int t = rest - n_ * tiles;
+                const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+                iy0_ = ty * TH * STRIDE - a.pad_y; ix0_ = tx * TW * STRIDE - a.pad_x;
+            };
+            int wkey0 = -1, wkey1 = -1;                 // (group, chunk) whose weights each LDS buffer holds
+            bool wfresh = false;                        // weights of the stage in flight need storing
+            auto load = [&](int b) {                    // request the cursor stage (destined for buffer b)
                 const float *src; int cs;
                 if (ch * KC < a.C0) { src = a.in0 + ch * KC; cs = a.C0; }
                 else                { src = a.in1 + (ch * KC - a.C0); cs = a.C1; }
-                src += 4 * c4;
+                if (cs != cur_cs) {                     // uniform; once per source switch
+                    cur_cs = cs;
 #pragma unroll
-                for (int it = 0; it < NIT; ++it)     // unconditional, clamped address (no branch -> stays asynchronous)
-                    xr[it] = *reinterpret_cast<const f32x4 *>(src + (size_t)(goff[it] < 0 ? 0 : goff[it]) * cs);
-                load_w();
+                    for (int it = 0; it < NIT; ++it)
+                        pre[it] = pix0 + it * PSTEP < HP ? (unsigned)((hy[it] * a.W + hx[it]) * cs + 4 * c4) * 4u : 0x80000000u;
+                }
+                src += ((long long)(n_ * a.H + iy0_) * a.W + ix0_) * cs;      // may precede the tensor; such lanes are masked
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, 0x7fffffff, 0x00020000);
+                const int ylo = iy0_ < 0 ? -iy0_ : 0, yhi = a.H - iy0_ < IH ? a.H - iy0_ : IH;
+                const int xlo = ix0_ < 0 ? -ix0_ : 0, xhi = a.W - ix0_ < IW ? a.W - ix0_ : IW;
+                if (ylo == 0 && xlo == 0 && yhi == IH && xhi == IW) {
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) xq[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, pre[it], 0, 0);
+                } else {
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        const bool ok = (unsigned)(hy[it] - ylo) < (unsigned)(yhi - ylo) && (unsigned)(hx[it] - xlo) < (unsigned)(xhi - xlo);
+                        xq[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? pre[it] : 0x80000000u, 0, 0);
+                    }
+                }
+                // weights: skipped when this buffer already holds the slab of (group, chunk)
+                const int key = grp_ * nchunk + ch;
+                const int held = b ? wkey1 : wkey0;
+                wfresh = key != held;
+                if (wfresh) {
+                    if (b) wkey1 = key; else wkey0 = key;
+                    const float *wp = a.wpk + (size_t)key * (NCBL * SLAB);
+                    const __amdgpu_buffer_rsrc_t ws_ = __builtin_amdgcn_make_buffer_rsrc((void *)wp, 0, NCBL * SLAB * 4, 0x00020000);
+#pragma unroll
+                    for (int it = 0; it < NWT; ++it) wq[it] = __builtin_amdgcn_raw_buffer_load_b128(ws_, wvo[it], 0, 0);
+                }
             };
-            auto store = [&](int b) { store_x(b); store_w(b); };
+            float *const xs_w = lds + pix0 * XS + 4 * c4;
+            float *const ws_w = lds + HP * XS + 4 * tid;
+            auto store = [&](int b) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it)
+                    if (pix0 + it * PSTEP < HP) *reinterpret_cast<u32x4 *>(xs_w + b * BUF + it * PSTEP * XS) = xq[it];
+                if (wfresh) {
+#pragma unroll
+                    for (int it = 0; it < NWT; ++it)
+                        if (it * 256 + tid < WF4) *reinterpret_cast<u32x4 *>(ws_w + b * BUF + it * 1024) = wq[it];
+                }
+            };
             auto advance = [&]() {
-                if (++ch == nchunk) { ch = 0; item += gridDim.x; if (item < nitems) decode(); }
+                if (++ch == nchunk) { ch = 0; item += gridDim.x; if (item < nitems) locate(); }
             };
             if (nstages > 0) {
-                decode();
-                load();
+                locate();
+                load(0);
                 store(0);                          // stage 0
-                if (nstages > 1) { advance(); load(); }   // stage 1 in flight
+                if (nstages > 1) { advance(); load(1); }   // stage 1 in flight
             }
             for (int s = 0; s < nstages; ++s) {
                 __syncthreads();                   // barrier #s
                 if (s + 1 < nstages) {
                     store((s + 1) & 1);            // registers hold stage s+1 (requested one stage ago)
-                    if (s + 2 < nstages) { advance(); load(); }
+                    if (s + 2 < nstages) { advance(); load(s & 1); }
                 }
             }
         }
@@ -515,15 +589,29 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
         }
         int s = 0;
         if constexpr (FIRST) __syncthreads();          // matches the producers' raw-tile barrier
+        // The folded-BN bias enters as the C operand of the first MFMA of every accumulator (no zeroing
+        // moves, no bias adds in the epilogue); the tile is reloaded only when the Cout group changes.
+        constexpr int NJ = M::NACC / 4;
+        Acc biasT[CB];
+        int cur_grp = -1;
         for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+            const int grp = item / per_group;
+            if (grp != cur_grp) {
+                cur_grp = grp;
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+                    const float *bp = a.bias + (grp * NCBL + wm * CB + cb) * MB + 4 * g;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const f32x4 bv4 = *reinterpret_cast<const f32x4 *>(bp + 8 * j);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) biasT[cb][4 * j + i] = bv4[i];
+                    }
+                }
+            }
             Acc acc[CB][PBW];
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-                for (int pb = 0; pb < PBW; ++pb)
-#pragma unroll
-                    for (int r = 0; r < M::NACC; ++r) acc[cb][pb][r] = 0.f;
-            for (int ch = 0; ch < nchunk; ++ch, ++s) {
+            auto chunk = [&](auto firstc) {
+                constexpr bool FIRSTCH = decltype(firstc)::value;
                 __syncthreads();               // barrier #s: buffer s&1 holds this stage
                 const float *xs = lds + (s & 1) * BUF;
                 const float *wbase = xs + HP * XS + (wm * CB) * KS2 * 64 * KSTEPS + lane * KSTEPS;
@@ -546,25 +634,29 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
 #pragma unroll
                         for (int pb = 0; pb < PBW; ++pb)
 #pragma unroll
-                            for (int cb = 0; cb < CB; ++cb)
-                                acc[cb][pb] = M::run(av[t & 1][cb][ks_], bv[t & 1][pb][ks_], acc[cb][pb]);
+                            for (int cb = 0; cb < CB; ++cb) {
+                                if (FIRSTCH && t == 0 && ks_ == 0)
+                                    acc[cb][pb] = M::run(av[t & 1][cb][ks_], bv[t & 1][pb][ks_], biasT[cb]);
+                                else
+                                    acc[cb][pb] = M::run(av[t & 1][cb][ks_], bv[t & 1][pb][ks_], acc[cb][pb]);
+                            }
                     __builtin_amdgcn_sched_barrier(0);
                 });
 #undef UKBB_LOAD_TAP
-            }
-            // ---- epilogue of this item ----
-            const int grp = item / per_group, rest = item - grp * per_group;
+                ++s;
+            };
+            chunk(std::true_type{});
+#pragma unroll 1
+            for (int ch = 1; ch < nchunk; ++ch) chunk(std::false_type{});
+            // ---- epilogue of this item (bias already inside the accumulators) ----
+            const int rest = item - grp * per_group;
             const int n = rest / tiles, t = rest - n * tiles;
             const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
             const int oy0 = ty * TH, ox0 = tx * TW;
             const int cbg = grp * NCBL + wm * CB;
-            constexpr int NJ = M::NACC / 4;
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
                 const int co0 = (cbg + cb) * MB + 4 * g;
-                float4 bi[NJ];
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) bi[j] = *reinterpret_cast<const float4 *>(a.bias + co0 + 8 * j);
 #pragma unroll
                 for (int pb = 0; pb < PBW; ++pb) {
                     const int q = (wn + pb * WN) * PB + pl;
@@ -579,16 +671,10 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
                         }
 #pragma unroll
                         for (int j = 0; j < NJ; ++j) {
-                            float4 v;
-                            v.x = acc[cb][pb][4 * j + 0] + bi[j].x;
-                            v.y = acc[cb][pb][4 * j + 1] + bi[j].y;
-                            v.z = acc[cb][pb][4 * j + 2] + bi[j].z;
-                            v.w = acc[cb][pb][4 * j + 3] + bi[j].w;
-                            if (a.relu) {
-                                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
-                                v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                            }
-                            *reinterpret_cast<float4 *>(o + 8 * j) = v;
+                            f32x4 v;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[i] = a.relu ? relu_bits(acc[cb][pb][4 * j + i]) : acc[cb][pb][4 * j + i];
+                            *reinterpret_cast<f32x4 *>(o + 8 * j) = v;
                         }
                     }
                 }

@@ -140,14 +140,84 @@ __global__ __launch_bounds__(256) void sqg_kernel(const SqgArgs a) {
     }
 }
 
+// Levels 1 and 2 (C_in = 32, 64) are big enough to be bandwidth-bound (level 1 of the batch-64
+// workload: 82 MB in, 164 MB out against 27 us of MFMA time), so this variant keeps both weight
+// matrices and the bias tile in registers and requests the features of the wave's next 32-pixel
+// block before it starts the MFMA chains of the current one: loads, MFMAs and stores of different
+// blocks overlap inside a wave instead of relying on occupancy alone.
+template <int CIN>
+__global__ __launch_bounds__(256) void sqg_stream_kernel(const SqgArgs a) {
+    constexpr int NJ = CIN / 8;
+    const int lane = threadIdx.x & 63;
+    const int p = lane & 31, g = lane >> 5;
+    const long long nblk = (a.npix + 31) >> 5;
+    const long long step = (long long)gridDim.x * 4;
+    f32x4 ws[NJ], wa[4], wb[4];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) ws[j] = ldg4(a.w_s + (j * 64 + lane) * 4);
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+        wa[q4] = ldg4(a.w_g + ((0 * 4 + q4) * 64 + lane) * 4);
+        wb[q4] = ldg4(a.w_g + ((1 * 4 + q4) * 64 + lane) * 4);
+    }
+    const f32x16 bias = bias_tile(a.b_s, g);
+    auto row = [&](long long blk) { const long long q = blk * 32 + p; return a.x + (q < a.npix ? q : a.npix - 1) * CIN + 4 * g; };
+    long long blk = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    f32x4 xn[NJ];
+    if (blk < nblk) {
+        const float *xp = row(blk);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) xn[j] = ldg4(xp + 8 * j);
+    }
+    for (; blk < nblk; blk += step) {
+        f32x4 xv[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) xv[j] = xn[j];
+        if (blk + step < nblk) {
+            const float *xp = row(blk + step);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) xn[j] = ldg4(xp + 8 * j);
+        }
+        f32x16 S = bias;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) S = MFMA32(ws[j][i], xv[j][i], S);
+        relu16(S);
+        f32x16 G0, G1;
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        G0 = MFMA32(wa[0][0], S[0], zero);              // C = 0 as an inline constant: no accumulator clearing
+        G1 = MFMA32(wb[0][0], S[0], zero);
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+            for (int i = (q4 == 0 ? 1 : 0); i < 4; ++i) {
+                G0 = MFMA32(wa[q4][i], S[4 * q4 + i], G0);
+                G1 = MFMA32(wb[q4][i], S[4 * q4 + i], G1);
+            }
+        const long long q = blk * 32 + p;
+        if (q < a.npix) {
+            float *o = a.out + q * 64 + 4 * g;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v0, v1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { v0[i] = G0[4 * j + i]; v1[i] = G1[4 * j + i]; }
+                *reinterpret_cast<f32x4 *>(o + 8 * j) = v0;
+                *reinterpret_cast<f32x4 *>(o + 32 + 8 * j) = v1;
+            }
+        }
+    }
+}
+
 hipError_t launch_sqg(const SqgArgs &a, hipStream_t s) {
     const long long nblk = (a.npix + 31) / 32;
     long long wg = (nblk + 3) / 4;
     if (wg > 256 * 8) wg = 256 * 8;
     dim3 grid((unsigned)wg), block(256);
     switch (a.cin) {
-        case 32: hipLaunchKernelGGL(sqg_kernel<32>, grid, block, 0, s, a); break;
-        case 64: hipLaunchKernelGGL(sqg_kernel<64>, grid, block, 0, s, a); break;
+        case 32: hipLaunchKernelGGL(sqg_stream_kernel<32>, grid, block, 0, s, a); break;
+        case 64: hipLaunchKernelGGL(sqg_stream_kernel<64>, grid, block, 0, s, a); break;
         case 128: hipLaunchKernelGGL(sqg_kernel<128>, grid, block, 0, s, a); break;
         case 256: hipLaunchKernelGGL(sqg_kernel<256>, grid, block, 0, s, a); break;
         default: return hipErrorInvalidValue;
