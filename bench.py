@@ -33,11 +33,11 @@ def cpu_baseline(arch, params, target_seconds=12.0):
     from ukbb_cardiac_amd.weights import pack_flat
     flat = pack_flat(arch, params)
     img = uniform_slices(8, H, W, seed=1)
-    c_oracle.forward(arch, flat, img[:1], want_logits=False)           # warm-up / page-in
+    c_oracle.forward(arch, flat, img, want_logits=False)               # warm-up: thread pool, buffer pool, page-in
     t0 = time.perf_counter()
-    c_oracle.forward(arch, flat, img[:2], want_logits=False)
-    per = (time.perf_counter() - t0) / 2
-    chunks = int(max(1, min(32, round(target_seconds / (per * 8)))))
+    c_oracle.forward(arch, flat, img, want_logits=False)
+    per = (time.perf_counter() - t0) / 8
+    chunks = int(max(1, min(400, round(target_seconds / (per * 8)))))
     t0 = time.perf_counter()
     for _ in range(chunks):
         c_oracle.forward(arch, flat, img, want_logits=False)
@@ -139,7 +139,7 @@ def main():
     if use_events:
         ms, cnt = eng.kernel_times(reset=True)
         eng.set_timing(False)
-        names, macs = eng.kernel_names(), eng.kernel_macs()
+        names, macs, xmacs = eng.kernel_names(), eng.kernel_macs(), eng.kernel_mfma_macs()
         dom_avg = ms[dom] / max(cnt[dom], 1)          # measured inside the timed region
         avg = list(warm_avg)
         tf = lambda mac, t_ms: 2.0 * mac / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0
@@ -157,19 +157,27 @@ def main():
                     'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                     'traffic': traffic, 'traffic_source': traffic_src,
                     'avg_launch_us': round(dom_avg * 1e3, 2), 'launches_timed': int(cnt[dom]),
-                    'algorithmic_flop_per_launch': 2.0 * macs[dom]}
+                    'algorithmic_flop_per_launch': 2.0 * macs[dom],
+                    # 'achieved' credits the reference graph's FLOPs; the kernel issues fewer
+                    # multiplies (head: only the level-0 slice of the 160->64 conv at full resolution)
+                    'mfma_issued_flop_per_launch': 2.0 * xmacs[dom],
+                    'mfma_issued_frac': round(tf(xmacs[dom], dom_avg) / PEAK_FP32_MFMA_TFLOPS, 4)}
         is3 = [nm.startswith('conv') and nm != 'conv0_0' for nm in names]
         t3 = sum(a for a, f in zip(avg, is3) if f)
         mac3 = sum(m for m, f in zip(macs, is3) if f)
+        xmac3 = sum(m for m, f in zip(xmacs, is3) if f)
         tall = sum(avg)
         detail = {
-            'note': 'per-kernel survey from an untimed pass with all kernels bracketed by HIP events',
+            'note': 'per-kernel survey from an untimed pass with all kernels bracketed by HIP events; frac = algorithmic (reference graph) FLOPs / peak, mfma_issued_frac = multiplies actually issued to the matrix pipe / peak (Winograd layers and the head run fewer than the reference graph)',
             'conv3x3_mfma_stack': {'tflops': round(tf(mac3, t3), 2), 'frac': round(tf(mac3, t3) / PEAK_FP32_MFMA_TFLOPS, 4),
+                                   'mfma_issued_frac': round(tf(xmac3, t3) / PEAK_FP32_MFMA_TFLOPS, 4),
                                    'us_per_step': round(t3 * 1e3, 1)},
             'all_kernels': {'tflops': round(tf(sum(macs), tall), 2),
-                            'frac': round(tf(sum(macs), tall) / PEAK_FP32_MFMA_TFLOPS, 4), 'us_per_step': round(tall * 1e3, 1)},
+                            'frac': round(tf(sum(macs), tall) / PEAK_FP32_MFMA_TFLOPS, 4),
+                            'mfma_issued_frac': round(tf(sum(xmacs), tall) / PEAK_FP32_MFMA_TFLOPS, 4), 'us_per_step': round(tall * 1e3, 1)},
             'per_kernel_us': {nm: round(a * 1e3, 1) for nm, a in zip(names, avg)},
             'per_kernel_frac': {nm: round(tf(m, a) / PEAK_FP32_MFMA_TFLOPS, 3) for nm, m, a in zip(names, macs, avg)},
+            'per_kernel_mfma_issued_frac': {nm: round(tf(m, a) / PEAK_FP32_MFMA_TFLOPS, 3) for nm, m, a in zip(names, xmacs, avg)},
         }
 
     if rank == 0:

@@ -116,6 +116,11 @@ int ukbb_fcn_num_kernels(const ukbb_fcn_handle *h);
 const char *ukbb_fcn_kernel_name(const ukbb_fcn_handle *h, int i);
 /* Algorithmic MACs kernel i performs for the LAST forward's shape. */
 double ukbb_fcn_kernel_macs(const ukbb_fcn_handle *h, int i);
+/* Multiplies kernel i actually issues to the matrix pipe for that shape (tile padding excluded).
+ * Differs from the algorithmic count where the kernel runs a cheaper algorithm: Winograd F(2x2,3x3)
+ * layers (16/36 of the direct count), the head (level-0 slice of the 160->64 conv only; the other
+ * slices run at low resolution inside the sqg kernels), the first layer (vector ALU, reported as 0). */
+double ukbb_fcn_kernel_mfma_macs(const ukbb_fcn_handle *h, int i);
 
 /* Tiling id the plan chose for kernel i (conv kernels; -1 for the others) and
  * its descriptive name; used by tools/tune_convs.py.  The environment variable

@@ -21,7 +21,7 @@ EXPORTS = [
     'ukbb_fcn_destroy', 'ukbb_fcn_reserve', 'ukbb_fcn_forward', 'ukbb_fcn_forward_host',
     'ukbb_fcn_num_kernels', 'ukbb_fcn_kernel_name', 'ukbb_fcn_kernel_macs', 'ukbb_fcn_set_timing',
     'ukbb_fcn_kernel_times', 'ukbb_fcn_get_activation', 'ukbb_fcn_kernel_config', 'ukbb_fcn_conv_config_name',
-    'ukbb_fcn_set_timing_kernel', 'ukbb_fcn_set_precision',
+    'ukbb_fcn_set_timing_kernel', 'ukbb_fcn_set_precision', 'ukbb_fcn_kernel_mfma_macs',
 ]
 
 
@@ -72,6 +72,8 @@ def _load():
     lib.ukbb_fcn_kernel_name.argtypes = [vp, C.c_int]
     lib.ukbb_fcn_kernel_macs.restype = C.c_double
     lib.ukbb_fcn_kernel_macs.argtypes = [vp, C.c_int]
+    lib.ukbb_fcn_kernel_mfma_macs.restype = C.c_double
+    lib.ukbb_fcn_kernel_mfma_macs.argtypes = [vp, C.c_int]
     lib.ukbb_fcn_kernel_config.argtypes = [vp, C.c_int]
     lib.ukbb_fcn_conv_config_name.restype = C.c_char_p
     lib.ukbb_fcn_conv_config_name.argtypes = [C.c_int]

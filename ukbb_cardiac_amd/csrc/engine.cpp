@@ -83,6 +83,7 @@ struct Op {                    // one kernel launch of the plan
     bool on_side = false;           // launched on the handle's side stream (fork/join by events)
     int H = 0, W = 0, Ho = 0, Wo = 0, stride = 1, pad_y = 0, pad_x = 0;
     double macs_per_image = 0; // algorithmic
+    double mfma_macs_per_image = -1; // issued to the matrix pipe; -1 = same as algorithmic
     const float *wpk = nullptr, *bias = nullptr;
 };
 
@@ -355,6 +356,8 @@ int add_conv(ukbb_fcn_handle *h, const std::string &lname, int in0, int in1, int
     op.bias = dev_ptr(h, lname + "/bias");
     op.out = new_act(h, lname, (size_t)op.Ho * op.Wo * L.cout);
     op.macs_per_image = (double)op.Ho * op.Wo * L.ks * L.ks * L.cin * L.cout;
+    if (c.pc == 4) op.mfma_macs_per_image = op.macs_per_image * (16.0 / 36.0);   // F(2x2,3x3): 16 products per 4 outputs
+    else if (fused_first) op.mfma_macs_per_image = op.macs_per_image;              // conv0_0 itself runs on the vector ALU
     h->ops.push_back(op);
     *out_buf = op.out;
     return UKBB_OK;
@@ -416,6 +419,7 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
                 op.H = op.Ho = H; op.W = op.Wo = W;
                 op.out = new_act(h, nm, (size_t)H * W * a.n_filter[0]);
                 op.macs_per_image = (double)H * W * 9 * a.n_filter[0];
+                op.mfma_macs_per_image = 0;          // vector ALU kernel
                 h->ops.push_back(op);
                 cur = op.out;
             } else {
@@ -446,6 +450,7 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
             // algorithmic MACs: the squeeze; the 32->64 projection is out0's work moved to low
             // resolution and is accounted to the head (so the per-layer sums equal Appendix A)
             op.macs_per_image = (double)lh[l] * lw[l] * a.n_filter[l] * a.same_dim;
+            op.mfma_macs_per_image = (double)lh[l] * lw[l] * (a.n_filter[l] * a.same_dim + a.same_dim * a.fc);
             h->ops.push_back(op);
             sqg_out[l] = op.out;
         }
@@ -457,6 +462,8 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
         op.H = op.Ho = H; op.W = op.Wo = W;
         op.macs_per_image = (double)H * W * (a.n_filter[0] * a.same_dim + a.same_dim * a.n_level * a.fc +
                                              a.fc * a.fc + a.fc * a.n_class);
+        // matrix pipe: same_dim0, the level-0 slice of out0, out1 (the logits run on the vector ALU)
+        op.mfma_macs_per_image = (double)H * W * (a.n_filter[0] * a.same_dim + a.same_dim * a.fc + a.fc * a.fc);
         for (int l = 1; l < 5; ++l) op.sq[l - 1] = sq[l];
         h->ops.push_back(op);
     } else {
@@ -838,6 +845,12 @@ const char *ukbb_fcn_kernel_name(const ukbb_fcn_handle *h, int i) {
 double ukbb_fcn_kernel_macs(const ukbb_fcn_handle *h, int i) {
     if (!h || i < 0 || i >= (int)h->ops.size()) return 0.0;
     return h->ops[i].macs_per_image * h->last_n;
+}
+
+double ukbb_fcn_kernel_mfma_macs(const ukbb_fcn_handle *h, int i) {
+    if (!h || i < 0 || i >= (int)h->ops.size()) return 0.0;
+    const Op &op = h->ops[i];
+    return (op.mfma_macs_per_image >= 0 ? op.mfma_macs_per_image : op.macs_per_image) * h->last_n;
 }
 
 int ukbb_fcn_set_precision(ukbb_fcn_handle *h, int precision) {

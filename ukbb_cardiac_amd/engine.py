@@ -104,6 +104,12 @@ class Engine:
         n = _lib.lib.ukbb_fcn_num_kernels(self._h)
         return [_lib.lib.ukbb_fcn_kernel_macs(self._h, i) for i in range(n)]
 
+    def kernel_mfma_macs(self):
+        """Multiplies each kernel issues to the matrix pipe (Winograd / head algebra run fewer than the
+        reference graph's algorithmic count returned by kernel_macs)."""
+        n = _lib.lib.ukbb_fcn_num_kernels(self._h)
+        return [_lib.lib.ukbb_fcn_kernel_mfma_macs(self._h, i) for i in range(n)]
+
     def kernel_configs(self):
         n = _lib.lib.ukbb_fcn_num_kernels(self._h)
         return [_lib.lib.ukbb_fcn_kernel_config(self._h, i) for i in range(n)]
