@@ -138,16 +138,21 @@ class Engine:
 
 def load_model(model_path: str):
     """Resolve the reference's ``--model_path`` (a TF checkpoint prefix,
-    ``demo_pipeline.py:63``) to this repo's weight blob ``<model_path>.ukbbw``."""
+    ``demo_pipeline.py:63``): this repo's weight blob ``<model_path>.ukbbw`` if present, else the
+    checkpoint-V2 files themselves (``tf_checkpoint.py``)."""
     for cand in (model_path, model_path + MODEL_EXT):
         if os.path.isfile(cand):
             try:
                 return load_blob(cand)
             except ValueError:
                 continue
+    # the reference's own format: a TF checkpoint-V2 prefix (deploy_network.py:48-49)
+    from . import tf_checkpoint
+    if tf_checkpoint.is_checkpoint(model_path):
+        return tf_checkpoint.checkpoint_to_params(model_path)
     raise FileNotFoundError(
-        'no weight blob at %s%s. TF checkpoints (.meta/.index/.data) are not read yet; '
-        'convert or create a blob with ukbb_cardiac_amd.weights.save_blob' % (model_path, MODEL_EXT))
+        'no weight blob at %s%s and no TF checkpoint at %s.index (convert with '
+        '`python -m ukbb_cardiac_amd.tf_checkpoint %s`)' % (model_path, MODEL_EXT, model_path, model_path))
 
 
 class Session:
