@@ -109,6 +109,31 @@ int ukbb_fcn_forward(ukbb_fcn_handle *h, const float *image, int n, int height, 
 int ukbb_fcn_forward_host(ukbb_fcn_handle *h, const float *image, int n, int height, int width,
                           float *logits, float *prob, int32_t *pred);
 
+/* ---- device-side pre/post-processing of the deploy loop ----------------
+ * Stateless; device pointers; asynchronous on `stream` unless stated.  They take the host numpy work
+ * (a full sort of ~20 M voxels per subject, pad, transposes) off the critical path of the reference's
+ * common/deploy_network.py:86-131. */
+
+/* Exact order statistics: out_host[i] = the ranks[i]-th smallest (0-based) of the n float32 values at
+ * d_data (16-byte aligned, any order; NaNs are not expected in MR magnitudes and sort as their bit
+ * pattern).  4-pass radix select on device; synchronous (the few results are copied back).
+ * Replaces the sort inside np.percentile(image, thres), common/image_utils.py:72 -- the caller does
+ * numpy's linear interpolation between neighbouring ranks on the host.  1 <= nranks <= 8. */
+int ukbb_fcn_select_kth(const float *d_data, size_t n, const uint64_t *ranks, int nranks, float *out_host, void *stream);
+
+/* (X,Y,Z,T) float32 volume with element strides (sx,sy,sz,st) -> network input d_batch[T*Z][X2][Y2]:
+ * the in-place clip to [lo, hi] as stored in float32, (v - lo) / (hi - lo) in float64 rounded to
+ * float32, centred zero padding (x_pre, y_pre before; X2, Y2 multiples of 16), batch index b = t*Z + z.
+ * Replaces common/image_utils.py:73-76 and common/deploy_network.py:97-107. */
+int ukbb_fcn_rescale_pack(const float *d_vol, int X, int Y, int Z, int T, int64_t sx, int64_t sy, int64_t sz, int64_t st,
+                          double lo, double hi, int X2, int Y2, int x_pre, int y_pre, float *d_batch, void *stream);
+
+/* int32 labels d_pred[T*Z][X2][Y2] -> cropped uint8 volume d_vol in NIfTI order (x fastest, then y, z, t)
+ * and d_counts[T][n_class] = voxels of each class per frame (what the ES pick of
+ * common/deploy_network.py:125-130 sums).  Replaces :114-116.  n_class <= 16. */
+int ukbb_fcn_unpack_labels(const int32_t *d_pred, int X, int Y, int Z, int T, int X2, int Y2, int x_pre, int y_pre, int n_class,
+                           uint8_t *d_vol, uint64_t *d_counts, void *stream);
+
 /* ---- measurement / introspection (bench.py, tests) ---------------------- */
 
 /* Kernel launches of one forward, in launch order. */

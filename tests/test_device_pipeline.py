@@ -1,0 +1,148 @@
+"""Device-side pre/post-processing.  CPU: the host half of the percentile
+(ranks + numpy's interpolation) against np.percentile.  GPU: radix select vs np.partition, the
+packed network input and the unpacked labels bit for bit against the numpy mirror of
+common/deploy_network.py:86-131."""
+import numpy as np
+import pytest
+
+from ukbb_cardiac_amd import device_pipeline as dp
+from ukbb_cardiac_amd.pipeline import pad_amounts, pick_ed_es, segment_sequence
+
+
+@pytest.mark.parametrize('n', [2, 3, 101, 1000, 99991])
+@pytest.mark.parametrize('q', [1, 10, 50, 99, 0, 100, 37.5])
+def test_host_half_of_percentile_matches_numpy(n, q):
+    rng = np.random.default_rng(n * 1000 + int(q * 10))
+    a = (1000 * rng.gamma(2.0, 1.0, size=n)).astype(np.float32)
+    a[rng.integers(0, n, size=max(1, n // 10))] = a[0]              # ties
+    s = np.sort(a)
+    k, k1, g = dp.percentile_ranks(n, q)
+    got = dp.lerp_like_numpy(s[k], s[k1], g)
+    want = np.percentile(a, (q, 50.0))[0]        # tuple q, as rescale_intensity passes it (float64 quantiles)
+    assert got == want and got.dtype == want.dtype
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n', [1, 5, 4096, 1000003])
+def test_select_kth_exact(n):
+    import ctypes as C
+    import torch
+    from ukbb_cardiac_amd import _lib
+    rng = np.random.default_rng(n)
+    a = (rng.standard_normal(n) * 1000).astype(np.float32)
+    if n > 10:
+        a[::7] = a[3]                                              # heavy ties
+        a[1] = 0.0; a[2] = -0.0; a[4] = np.float32(3.0e38); a[5] = np.float32(-3.0e38); a[6] = np.float32(1e-42)   # denormal
+    t = torch.from_numpy(a).cuda()
+    ranks = sorted({0, n - 1, n // 2, n // 100, (99 * n) // 100, min(n - 1, n // 100 + 1)})
+    r = (C.c_uint64 * len(ranks))(*ranks)
+    out = np.empty(len(ranks), np.float32)
+    _lib.check(_lib.lib.ukbb_fcn_select_kth(t.data_ptr(), n, r, len(ranks), _lib.f32ptr(out), 0), 'select')
+    s = np.sort(a)
+    np.testing.assert_array_equal(out, s[ranks])                    # -0.0 == 0.0 compares equal, as in a sort
+    with pytest.raises(_lib.UkbbFcnError):
+        bad = (C.c_uint64 * 1)(n)
+        _lib.check(_lib.lib.ukbb_fcn_select_kth(t.data_ptr(), n, bad, 1, _lib.f32ptr(out), 0), 'select')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('order', ['F', 'C'])
+def test_device_percentiles_equal_numpy(order):
+    import torch
+    rng = np.random.default_rng(5)
+    vol = np.asarray((1000 * rng.gamma(2.0, 1.0, size=(37, 41, 3, 5))).astype(np.float32), order=order)
+    lo, hi = dp.device_percentiles(torch.from_numpy(vol).cuda(), (1, 99))
+    want = np.percentile(vol, (1, 99))
+    assert lo == want[0] and hi == want[1]
+
+
+def _engine(model='FCN_sa'):
+    from ukbb_cardiac_amd.arch import MODELS
+    from ukbb_cardiac_amd.engine import Engine
+    from ukbb_cardiac_amd.weights import synthetic_params
+    arch = MODELS[model]
+    return Engine(arch, synthetic_params(arch, 1234))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape,order', [((162, 204, 2, 3), 'F'), ((192, 208, 3, 4), 'F'), ((50, 33, 1, 2), 'C')])
+def test_rescale_pack_and_unpack_bit_exact(shape, order):
+    """Network input and label volume equal the numpy mirror of the reference loop exactly."""
+    import torch
+    from ukbb_cardiac_amd import _lib
+    from ukbb_cardiac_amd.image_utils import rescale_intensity
+    X, Y, Z, T = shape
+    rng = np.random.default_rng(X)
+    vol = np.asarray((1000 * rng.gamma(2.0, 1.0, size=shape)).astype(np.float32), order=order)
+    ref = vol.copy(order='K')
+    scaled = rescale_intensity(ref, (1, 99))                        # clips ref in place
+    X2, Y2, x_pre, x_post, y_pre, y_post = pad_amounts(X, Y)
+    padded = np.pad(scaled, ((x_pre, x_post), (y_pre, y_post), (0, 0), (0, 0)), 'constant')
+    want = np.transpose(padded, (3, 2, 0, 1)).reshape(T * Z, X2, Y2).astype(np.float32)
+    t = torch.from_numpy(vol).cuda()
+    lo, hi = dp.device_percentiles(t, (1, 99))
+    batch = torch.empty((T * Z, X2, Y2), dtype=torch.float32, device='cuda')
+    sx, sy, sz, st = t.stride()
+    _lib.check(_lib.lib.ukbb_fcn_rescale_pack(t.data_ptr(), X, Y, Z, T, sx, sy, sz, st, float(lo), float(hi), X2, Y2, x_pre, y_pre,
+                                              batch.data_ptr(), 0), 'pack')
+    np.testing.assert_array_equal(batch.cpu().numpy(), want)
+    np.testing.assert_array_equal(dp.clip_like_reference(vol[..., 0], (lo, hi)), ref[..., 0])
+    # labels: random label batch -> volume + counts
+    n_class = 4
+    lab = rng.integers(0, n_class, size=(T * Z, X2, Y2)).astype(np.int32)
+    pred = torch.from_numpy(lab).cuda()
+    out = torch.empty(X * Y * Z * T, dtype=torch.uint8, device='cuda')
+    counts = torch.empty((T, n_class), dtype=torch.int64, device='cuda')
+    _lib.check(_lib.lib.ukbb_fcn_unpack_labels(pred.data_ptr(), X, Y, Z, T, X2, Y2, x_pre, y_pre, n_class, out.data_ptr(),
+                                               counts.data_ptr(), 0), 'unpack')
+    want_vol = lab.reshape(T, Z, X2, Y2).transpose(2, 3, 1, 0)[x_pre:x_pre + X, y_pre:y_pre + Y]
+    got_vol = out.cpu().numpy().reshape((X, Y, Z, T), order='F')
+    np.testing.assert_array_equal(got_vol, want_vol)
+    want_counts = np.stack([[np.sum(want_vol[..., t_] == c) for c in range(n_class)] for t_ in range(T)])
+    np.testing.assert_array_equal(counts.cpu().numpy(), want_counts)
+
+
+@pytest.mark.gpu
+def test_segment_sequence_device_equals_host_path():
+    from ukbb_cardiac_amd.phantom import cine_phantom
+    eng = _engine()
+    Z, T = 4, 6
+    vol = cine_phantom(Z * T, 162, 204, seed=3)[..., 0].reshape(T, Z, 162, 204).transpose(2, 3, 1, 0) * 1000.0
+    vol = np.asfortranarray(vol.astype(np.float32))
+    host_in = vol.copy(order='F')
+    want = segment_sequence(host_in, lambda b: eng.run(b, want_prob=False), batch_slices=7)
+    got, aux = dp.segment_sequence_device(vol, eng, batch_slices=7, return_aux=True)
+    assert got.dtype == np.float64 and got.shape == vol.shape
+    np.testing.assert_array_equal(got, want)
+    assert pick_ed_es(want, 'sa') == dp.pick_ed_es_from_counts(aux['counts'], 'sa')
+    assert pick_ed_es(want, 'la_2ch') == dp.pick_ed_es_from_counts(aux['counts'], 'la_2ch')
+    np.testing.assert_array_equal(dp.clip_like_reference(vol[..., 2], aux['clip']), host_in[..., 2])   # what ED/ES frames save
+    with pytest.raises(TypeError):
+        dp.segment_sequence_device(vol.astype(np.float64), eng)
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_drop_in_script_writes_identical_files_with_and_without_device_preproc(tmp_path):
+    """The reference command line (demo_pipeline.py:63-64) through ukbb_cardiac_amd.deploy_network: the five
+    output files (deploy_network.py:136-151) are byte-identical between the host and the device pre-processing."""
+    import gzip
+    from ukbb_cardiac_amd import deploy_network, nifti
+    from ukbb_cardiac_amd.arch import MODELS
+    from ukbb_cardiac_amd.weights import save_blob, synthetic_params
+    arch = MODELS['FCN_sa']
+    model = str(tmp_path / 'FCN_sa')
+    save_blob(model + '.ukbbw', arch, synthetic_params(arch, 1234))
+    rng = np.random.default_rng(11)
+    vol = (1000 * rng.gamma(2.0, 1.0, size=(100, 90, 3, 4))).astype(np.float32)
+    outs = {}
+    for mode in ('device', 'host'):
+        d = tmp_path / mode / 'subj1'
+        d.mkdir(parents=True)
+        nifti.save(vol, str(d / 'sa.nii.gz'), np.diag([1.8, 1.8, 10.0, 1.0]), pixdim=[1, 1.8, 1.8, 10, 0.03, 0, 0, 0])
+        deploy_network.main(['--seq_name', 'sa', '--data_dir', str(tmp_path / mode), '--model_path', model,
+                             '--device_preproc' if mode == 'device' else '--nodevice_preproc'])
+        outs[mode] = {f: gzip.open(str(d / f)).read() for f in
+                      ('seg_sa.nii.gz', 'sa_ED.nii.gz', 'sa_ES.nii.gz', 'seg_sa_ED.nii.gz', 'seg_sa_ES.nii.gz')}
+    for f in outs['host']:
+        assert outs['device'][f] == outs['host'][f], f

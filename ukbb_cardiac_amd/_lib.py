@@ -22,6 +22,7 @@ EXPORTS = [
     'ukbb_fcn_num_kernels', 'ukbb_fcn_kernel_name', 'ukbb_fcn_kernel_macs', 'ukbb_fcn_set_timing',
     'ukbb_fcn_kernel_times', 'ukbb_fcn_get_activation', 'ukbb_fcn_kernel_config', 'ukbb_fcn_conv_config_name',
     'ukbb_fcn_set_timing_kernel', 'ukbb_fcn_set_precision', 'ukbb_fcn_kernel_mfma_macs',
+    'ukbb_fcn_select_kth', 'ukbb_fcn_rescale_pack', 'ukbb_fcn_unpack_labels',
 ]
 
 
@@ -80,6 +81,11 @@ def _load():
     lib.ukbb_fcn_set_timing.argtypes = [vp, C.c_int]
     lib.ukbb_fcn_set_timing_kernel.argtypes = [vp, C.c_int]
     lib.ukbb_fcn_set_precision.argtypes = [vp, C.c_int]
+    lib.ukbb_fcn_select_kth.argtypes = [vp, C.c_size_t, C.POINTER(C.c_uint64), C.c_int, f32p, vp]
+    lib.ukbb_fcn_rescale_pack.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                          C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+    lib.ukbb_fcn_unpack_labels.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           vp, vp, vp]
     lib.ukbb_fcn_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int, C.c_int]
     lib.ukbb_fcn_get_activation.restype = C.c_int64
     lib.ukbb_fcn_get_activation.argtypes = [vp, C.c_char_p, f32p, C.c_int64]

@@ -32,6 +32,19 @@ void set_err(const char *fmt, ...) {
     g_err = buf;
 }
 
+}  // namespace
+
+void ukbb::set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+namespace {
+
 #define HIP_TRY(expr, code)                                                            \
     do {                                                                               \
         hipError_t e_ = (expr);                                                        \

@@ -58,6 +58,9 @@ size_t pack_conv_weights_bf16(const float *w, int ks, int cin, int cout, int ncb
 
 // Winograd F(2x2,3x3) producer/consumer kernel (kernels_wino.hip): 3x3, stride 1, C_out % 64 == 0,
 // C_in % 16 == 0.  ConvConfig::pc == 4, id 300.  Same ConvArgs; wpk from pack_wino_weights().
+// thread-local error string behind ukbb_fcn_last_error() (engine.cpp)
+void set_error(const char *fmt, ...);
+
 hipError_t launch_wino(const ConvArgs &a, int ncb /*16-channel blocks per item: 4 or 2*/, hipStream_t s);
 size_t pack_wino_weights(const float *w /*[3][3][cin][cout] folded*/, int cin, int cout, int ncb, float *dst /*16*cin*cout*/);
 int wino_lds_bytes();

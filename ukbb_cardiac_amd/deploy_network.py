@@ -44,6 +44,8 @@ def define_flags():
     env_idx, env_cnt = shard_from_env()
     fs.DEFINE_integer('device', 0, 'HIP device ordinal (after HIP_VISIBLE_DEVICES).')
     fs.DEFINE_integer('batch_slices', 128, 'Slices per forward call.')
+    fs.DEFINE_boolean('device_preproc', True, 'Percentile rescale, padding, transposes and label counting on the GPU '
+                      '(float32 sequences; results identical to the host path).')
     fs.DEFINE_integer('num_shards', env_cnt, 'Number of workers sharing data_dir.')
     fs.DEFINE_integer('shard_index', env_idx, 'This worker: subjects i with i % num_shards == shard_index.')
     return fs
@@ -53,8 +55,9 @@ def seg_prefix(FLAGS):
     return 'seg4' if (FLAGS.seq_name == 'la_4ch' and FLAGS.seg4) else 'seg'
 
 
-def run(FLAGS, forward, log=print):
-    """The subject loop of deploy_network.py:52-225 with ``forward`` standing for sess.run."""
+def run(FLAGS, forward, log=print, engine=None):
+    """The subject loop of deploy_network.py:52-225 with ``forward`` standing for sess.run.
+    With ``engine`` (and --device_preproc) float32 sequences take the device pipeline."""
     start_time = time.time()
     data_list = subjects_for_shard(sorted(os.listdir(FLAGS.data_dir)), FLAGS.shard_index, FLAGS.num_shards)
     processed, table_time = [], []
@@ -80,12 +83,20 @@ def run(FLAGS, forward, log=print):
                 continue
             log('  Segmenting full sequence ...')
             t0 = time.time()
-            pred = pipeline.segment_sequence(image, forward, FLAGS.batch_slices)   # clips `image` in place
+            on_device = engine is not None and getattr(FLAGS, 'device_preproc', False) and image.dtype == np.float32
+            if on_device:
+                from . import device_pipeline
+                pred, aux = device_pipeline.segment_sequence_device(image, engine, FLAGS.batch_slices, return_aux=True)
+            else:
+                pred = pipeline.segment_sequence(image, forward, FLAGS.batch_slices)   # clips `image` in place
             seg_time = time.time() - t0
             log('  Segmentation time = {:3f}s'.format(seg_time))
             table_time.append(seg_time)
             processed.append(data)
-            k_ed, k_es = pipeline.pick_ed_es(pred, seq, FLAGS.seg4)
+            if on_device:
+                k_ed, k_es = device_pipeline.pick_ed_es_from_counts(aux['counts'], seq, FLAGS.seg4)
+            else:
+                k_ed, k_es = pipeline.pick_ed_es(pred, seq, FLAGS.seg4)
             log('  ED frame = {:d}, ES frame = {:d}'.format(k_ed, k_es))
             if FLAGS.save_seg:
                 log('  Saving segmentation ...')
@@ -93,7 +104,8 @@ def run(FLAGS, forward, log=print):
                 nifti.save(pred, '{0}/{1}_{2}.nii.gz'.format(data_dir, pre, seq), nim.affine, pixdim)
                 for fr, k in (('ED', k_ed), ('ES', k_es)):
                     # the saved frames are the CLIPPED intensities (alias quirk)
-                    nifti.save(image[:, :, :, k], '{0}/{1}_{2}.nii.gz'.format(data_dir, seq, fr), nim.affine)
+                    frame = device_pipeline.clip_like_reference(image[:, :, :, k], aux['clip']) if on_device else image[:, :, :, k]
+                    nifti.save(frame, '{0}/{1}_{2}.nii.gz'.format(data_dir, seq, fr), nim.affine)
                     nifti.save(pred[:, :, :, k], '{0}/{1}_{2}_{3}.nii.gz'.format(data_dir, pre, seq, fr), nim.affine)
         else:
             names = {fr: '{0}/{1}_{2}.nii.gz'.format(data_dir, seq, fr) for fr in ('ED', 'ES')}
@@ -141,7 +153,7 @@ def main(argv=None):
         def forward(batch):
             pred = sess.run('pred:0', feed_dict={'image:0': batch, 'training:0': False})
             return {'pred': pred}
-        run(FLAGS, forward)
+        run(FLAGS, forward, engine=sess.engine)
 
 
 if __name__ == '__main__':
