@@ -49,6 +49,11 @@ extern "C" {
 
 #define UKBB_KIND_FCN 0    /* common/network.py:170 build_FCN */
 #define UKBB_KIND_UNET 1   /* common/network_ao.py:18 UNet    */
+#define UKBB_KIND_UNET_LSTM 2 /* common/network_ao.py:322 UNet_LSTM_Model, bidirectional (BiConv_LSTM :255);
+                               same_dim = ConvLSTM hidden channels (16), fc = unrolled time steps (9);
+                               weights: the UNet layers without its conv_out, then per direction the gate
+                               kernel [3,3,16+16,64] + bias[64] (forward, backward), then the output conv
+                               kernel [1,1,32,n_class] + bias.  Use forward_seq / forward_cine. */
 
 /* Hyper-parameters of build_FCN / UNet as bound in common/train_network.py:174-195
  * and common/train_network_ao.py:268,275-284. */
@@ -108,6 +113,24 @@ int ukbb_fcn_forward(ukbb_fcn_handle *h, const float *image, int n, int height, 
  * the exact shape of the reference's sess.run call. */
 int ukbb_fcn_forward_host(ukbb_fcn_handle *h, const float *image, int n, int height, int width,
                           float *logits, float *prob, int32_t *pred);
+
+/* ---- UNet-LSTM (kind 2): the default aortic model of demo_pipeline.py:116-117 -------------------
+ * Reference call (common/deploy_network_ao.py:171-172):
+ *   prob_idx = sess.run('prob:0', {'image:0': image_idx [N,T,X,Y,1], 'training:0': False})  -> [N,T,X,Y,C]
+ * forward_seq is that call: n_seq sequences of T = arch.fc frames each, frame (s, t) at image + (s*T + t)*H*W;
+ * outputs in the same [N][T] order (any of logits / prob / pred may be NULL).  Device pointers, asynchronous. */
+int ukbb_fcn_forward_seq(ukbb_fcn_handle *h, const float *image, int n_seq, int height, int width,
+                         float *logits, float *prob, int32_t *pred, void *stream);
+
+/* The whole 'UNet-LSTM' branch of the reference's per-subject loop (common/deploy_network_ao.py:129-183,189)
+ * for one slice position: n_frames cine frames at image[f], every frame is the centre of one circular window of
+ * T frames (time_step = 1), window probabilities are tiled with the weights (1 - |k - rad|/weight_R)^weight_r
+ * exactly as the reference accumulates them (float32 accumulator updated through float64, same order), then
+ * prob /= weight and pred = argmax.  The U-Net features of a frame are computed once instead of once per
+ * window (T times in the reference); results are identical because the U-Net acts per frame.
+ * Requires 2*weight_R - 1 == arch.fc and n_frames >= arch.fc.  prob [n_frames][H][W][C], pred [n_frames][H][W]. */
+int ukbb_fcn_forward_cine(ukbb_fcn_handle *h, const float *image, int n_frames, int height, int width,
+                          int weight_R, double weight_r, float *prob, int32_t *pred, void *stream);
 
 /* ---- device-side pre/post-processing of the deploy loop ----------------
  * Stateless; device pointers; asynchronous on `stream` unless stated.  They take the host numpy work

@@ -234,6 +234,95 @@ def UNet(images, params, n_class=3, n_level=5, n_filter=(16, 32, 64, 128, 256),
     return logits
 
 
+def unet_features(images, params, n_level=5, n_filter=(16, 32, 64, 128, 256), n_block=(2, 2, 2, 2, 2), dtype=np.float64):
+    """net['conv0_up'] of common/network_ao.py:18-55 -- what UNet_LSTM_Model feeds to the LSTM (:343-347)."""
+    x = np.asarray(images, dtype=dtype)
+    net = {}
+    for l in range(n_level):
+        x = conv2d_bn_relu(x, params['conv%d_0' % l], 3, 1 if l == 0 else 2)
+        for i in range(1, n_block[l]):
+            x = conv2d_bn_relu(x, params['conv%d_%d' % (l, i)], 3)
+        net['conv%d' % l] = x
+    up = net['conv%d' % (n_level - 1)]
+    for l in range(n_level - 2, -1, -1):
+        x = conv2d_transpose_bn_relu(up, params['up%d_t' % l], 3, 2)
+        x = np.concatenate([net['conv%d' % l], x], axis=-1)
+        for i in range(n_block[l]):
+            x = conv2d_bn_relu(x, params['up%d_%d' % (l, i)], 3)
+        up = x
+    return up
+
+
+def sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def conv_lstm_cell(x, h, c, p, forget_bias=1.0):
+    """One step of tf.contrib.rnn.Conv2DLSTMCell(kernel_shape=[3,3]) as used at common/network_ao.py:225,276,288
+    [TF-recall, SURVEY.md App. B.6]: one SAME conv over concat([x, h]) -> 4*hidden channels (+bias),
+    split in the order (input gate i, new input j, forget gate f, output gate o);
+    c' = sigmoid(f + forget_bias) * c + sigmoid(i) * tanh(j);  h' = tanh(c') * sigmoid(o).  No peepholes."""
+    dt = x.dtype
+    z = conv2d_same(np.concatenate([x, h], axis=-1), p['kernel'], 1) + p['bias'].astype(dt)
+    i, j, f, o = np.split(z, 4, axis=-1)
+    c_new = sigmoid(f + dt.type(forget_bias)) * c + sigmoid(i) * np.tanh(j)
+    h_new = np.tanh(c_new) * sigmoid(o)
+    return h_new, c_new
+
+
+def biconv_lstm(features, params, n_hidden):
+    """BiConv_LSTM, common/network_ao.py:255-319.  features [N,T,H,W,C] -> logits [N,T,H,W,n_class].
+    Zero initial state (:278,:290); forward over t = 0..T-1, backward over t = T-1..0; the output conv sees
+    concat([h_fw[t], h_bw[t]]) (:305: cell_outputs_bw is stored in processing order, hence the index
+    n_step-1-t)."""
+    N, T, H, W, _ = features.shape
+    dt = features.dtype
+    zeros = np.zeros((N, H, W, n_hidden), dt)
+    h, c, fw = zeros, zeros, []
+    for t in range(T):
+        h, c = conv_lstm_cell(features[:, t], h, c, params['lstm_fw'])
+        fw.append(h)
+    h, c, bw = zeros, zeros, [None] * T
+    for t in range(T - 1, -1, -1):
+        h, c = conv_lstm_cell(features[:, t], h, c, params['lstm_bw'])
+        bw[t] = h
+    po = params['lstm_out']
+    outs = [conv2d_same(np.concatenate([fw[t], bw[t]], axis=-1), po['kernel'], 1) + po['bias'].astype(dt) for t in range(T)]
+    return np.stack(outs, axis=1)
+
+
+def unet_lstm(images, params, n_hidden=16, n_level=5, n_filter=(16, 32, 64, 128, 256), n_block=(2, 2, 2, 2, 2),
+              dtype=np.float64):
+    """UNet_LSTM_Model inference graph, common/network_ao.py:322-399 (bidirectional): images [N,T,H,W,1] ->
+    logits [N,T,H,W,n_class]; prob = softmax, pred = argmax (:396-397)."""
+    x = np.asarray(images, dtype=dtype)
+    N, T, H, W, C = x.shape
+    feats = unet_features(x.reshape(N * T, H, W, C), params, n_level, n_filter, n_block, dtype)
+    return biconv_lstm(feats.reshape(N, T, H, W, feats.shape[-1]), params, n_hidden)
+
+
+def aortic_lstm_prob_sequence(image, forward_seq, weight_R=5, weight_r=0.1, time_step=1, n_class=3):
+    """'UNet-LSTM' branch of common/deploy_network_ao.py:99-107,129-183 on a normalised (X,Y,Z,T) volume:
+    fixed 256x256 pad, circular 9-frame windows, weighted tiling of the window probabilities.
+    ``forward_seq(image_idx[N,T,256,256,1] f32) -> prob[N,T,256,256,C]`` stands for sess.run (:171-172)."""
+    X, Y, Z, T = image.shape
+    prob = np.zeros((X, Y, Z, T, n_class), dtype=np.float32)
+    X2, Y2, x_pre, x_post, y_pre, y_post = pad_to_fixed(X, Y)
+    image = np.pad(image, ((x_pre, x_post), (y_pre, y_post), (0, 0), (0, 0)), 'constant')
+    time_window = weight_R * 2 - 1
+    weight = np.zeros((1, 1, 1, T, 1))
+    w = np.reshape(aortic_window_weights(weight_R, weight_r), (1, 1, 1, time_window, 1))
+    for t in range(0, T, time_step):
+        idx = aortic_window_indices(t, T, weight_R)
+        image_idx = np.transpose(image[:, :, :, idx], axes=(2, 3, 0, 1)).astype(np.float32)
+        image_idx = np.expand_dims(image_idx, axis=-1)
+        prob_idx = np.transpose(forward_seq(image_idx), axes=(2, 3, 0, 1, 4))
+        prob[:, :, :, idx] += prob_idx[x_pre:x_pre + X, y_pre:y_pre + Y] * w
+        weight[:, :, :, idx] += w
+    prob /= weight
+    return prob
+
+
 def prob_pred(logits):
     """common/train_network.py:198-199 / common/network_ao.py:159-160."""
     prob = softmax(logits)

@@ -190,3 +190,39 @@ def test_product_path_does_not_import_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, re.M), f
                 assert 'fcn_oracle' not in src.replace('oracle/fcn_oracle.py', ''), f
+
+
+def test_aortic_lstm_sequence_vs_oracle_loop():
+    """'UNet-LSTM' branch: pad to 256, per-slice circular windows, weighted tiling, crop -- the host mirror
+    (pipeline.aortic_lstm_prob_sequence + a per-slice cine function) against the restatement of
+    deploy_network_ao.py:99-107,129-183 (oracle) with the same stand-in network."""
+    from oracle import fcn_oracle as O
+    from ukbb_cardiac_amd import pipeline
+    rng = np.random.default_rng(21)
+    X, Y, Z, T = 20, 31, 2, 11
+    image = (100 * rng.gamma(2.0, 1.0, size=(X, Y, Z, T))).astype(np.float32)
+
+    def forward_seq(image_idx):                      # [N,9,256,256,1] -> prob [N,9,256,256,3], depends on the whole window
+        x = image_idx[..., 0].astype(np.float64)
+        ctx = x.mean(axis=1, keepdims=True) + 0.1 * np.arange(x.shape[1])[None, :, None, None]
+        lg = np.stack([x, ctx - x, 0.5 * ctx], axis=-1)
+        return O.softmax(lg).astype(np.float32)
+
+    def cine_forward(frames, weight_R, weight_r):    # independent per-slice tiling in plain numpy
+        F = frames.shape[0]
+        w = O.aortic_window_weights(weight_R, weight_r)
+        acc = np.zeros((F,) + frames.shape[1:] + (3,), np.float32)
+        ws = np.zeros(F)
+        for t in range(F):
+            idx = O.aortic_window_indices(t, F, weight_R)
+            p = forward_seq(frames[idx][None, ..., None])[0]
+            for k, f in enumerate(idx):
+                acc[f] = (acc[f].astype(np.float64) + p[k].astype(np.float64) * w[k]).astype(np.float32)
+                ws[f] += w[k]
+        return (acc.astype(np.float64) / ws[:, None, None, None]).astype(np.float32)
+
+    got = pipeline.aortic_lstm_prob_sequence(image.copy(), cine_forward, z_score=True)
+    from ukbb_cardiac_amd.image_utils import normalise_intensity
+    want = O.aortic_lstm_prob_sequence(normalise_intensity(image.copy(), 10.0), forward_seq)
+    assert got.shape == (X, Y, Z, T, 3) and got.dtype == np.float32
+    np.testing.assert_array_equal(got, want)

@@ -98,6 +98,29 @@ def test_unet_graph_vs_torch():
     assert np.allclose(a, b, rtol=1e-10, atol=1e-10)
 
 
+def test_unet_lstm_graph_vs_torch():
+    """BiConvLSTM head: numpy restatement vs an independent torch formulation."""
+    from tests.torch_ref import unet_lstm_forward
+    arch = MODELS['UNet-LSTM_ao']
+    params = synthetic_params(arch, 1234)
+    x = np.random.default_rng(8).standard_normal((2, 9, 32, 16, 1)).astype(np.float32)
+    a = O.unet_lstm(x, params, arch.n_hidden, n_block=arch.n_block, dtype=np.float64)
+    b = unet_lstm_forward(x, params, arch)
+    assert a.shape == (2, 9, 32, 16, 3)
+    assert np.abs(a - b).max() <= 1e-9 * max(1.0, np.abs(b).max())
+    # a window is order-sensitive: reversing time must change the result (fw/bw weights differ)
+    c = O.unet_lstm(x[:, ::-1], params, arch.n_hidden, n_block=arch.n_block, dtype=np.float64)[:, ::-1]
+    assert np.abs(a - c).max() > 1e-3
+
+
+def test_aortic_window_known_answers():
+    """deploy_network_ao.py:130-158: 9 weights (1-|t-4|/5)^0.1 and the circular window."""
+    w = O.aortic_window_weights(5, 0.1)
+    assert len(w) == 9 and w[4] == 1.0 and abs(w[0] - 0.2 ** 0.1) < 1e-15 and np.allclose(w, w[::-1])
+    assert O.aortic_window_indices(0, 50) == [46, 47, 48, 49, 0, 1, 2, 3, 4]
+    assert O.aortic_window_indices(48, 50) == [44, 45, 46, 47, 48, 49, 0, 1, 2]
+
+
 def test_softmax_argmax_ties_lowest_index():
     logits = np.array([[1.0, 3.0, 3.0, 0.0]])
     prob, pred = O.prob_pred(logits)

@@ -44,7 +44,7 @@ def test_snappy_literal_and_copies():
         tfc.snappy_uncompress(bytes([4]) + bytes([((4 - 4) << 2) | 1, 9]))                    # offset beyond output
 
 
-@pytest.mark.parametrize('model', ['FCN_sa', 'FCN_la_2ch', 'FCN_la_4ch', 'FCN_la_4ch_seg4', 'UNet_ao'])
+@pytest.mark.parametrize('model', ['FCN_sa', 'FCN_la_2ch', 'FCN_la_4ch', 'FCN_la_4ch_seg4', 'UNet_ao', 'UNet-LSTM_ao'])
 def test_round_trip_all_models(tmp_path, model):
     arch = MODELS[model]
     params = synthetic_params(arch, 7)

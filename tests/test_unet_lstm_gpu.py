@@ -1,0 +1,107 @@
+"""UNet-LSTM (BiConvLSTM head) on the GPU against the numpy restatement of
+common/network_ao.py:255-399 and the tiling loop of common/deploy_network_ao.py:129-183."""
+import numpy as np
+import pytest
+
+from oracle import fcn_oracle as O
+
+pytestmark = pytest.mark.gpu
+LOGIT_RTOL = 1e-3           # north_star: logits within 1e-3 relative (fp32)
+
+
+@pytest.fixture(scope='module')
+def model():
+    from ukbb_cardiac_amd.arch import MODELS
+    from ukbb_cardiac_amd.engine import Engine
+    from ukbb_cardiac_amd.weights import synthetic_params
+    arch = MODELS['UNet-LSTM_ao']
+    params = synthetic_params(arch, 1234)
+    eng = Engine(arch, params)
+    yield arch, params, eng
+    eng.close()
+
+
+@pytest.mark.parametrize('shape', [(1, 9, 32, 48), (2, 9, 64, 32)])
+def test_forward_seq_vs_oracle(model, shape):
+    arch, params, eng = model
+    x = np.random.default_rng(shape[2]).standard_normal(shape + (1,)).astype(np.float32)
+    out = eng.run_seq(x, want_logits=True)
+    ref = O.unet_lstm(x, params, arch.n_hidden, n_block=arch.n_block, dtype=np.float64)
+    scale = np.abs(ref).max()
+    err = np.abs(out['logits'] - ref).max()
+    assert err <= LOGIT_RTOL * scale, 'logits err %.3e vs scale %.3e' % (err, scale)
+    prob_ref = O.softmax(ref)
+    assert np.abs(out['prob'] - prob_ref).max() < 1e-4
+    bad = out['pred'] != O.argmax_pred(ref)
+    assert np.all(O.top2_margin(ref)[bad] < 1e-4), 'label disagreement away from a tie'
+    assert out['pred'].dtype == np.int32 and out['pred'].shape == shape
+    assert np.array_equal(out['pred'], np.argmax(out['prob'], -1))           # pred is the argmax of prob
+    assert len(np.unique(out['pred'])) > 1
+
+
+def test_sequences_are_independent_and_order_sensitive(model):
+    arch, params, eng = model
+    x = np.random.default_rng(2).standard_normal((3, 9, 32, 32, 1)).astype(np.float32)
+    all_ = eng.run_seq(x, want_logits=True)['logits']
+    one = eng.run_seq(x[1:2], want_logits=True)['logits']
+    assert np.array_equal(all_[1:2], one)                                    # batch composition does not matter
+    rev = eng.run_seq(x[1:2, ::-1].copy(), want_logits=True)['logits'][:, ::-1]
+    assert np.abs(rev - one).max() > 1e-3                                    # forward/backward cells differ
+
+
+def test_forward_cine_equals_reference_tiling_of_window_calls(model):
+    """ukbb_fcn_forward_cine (features once per frame, all windows batched, tiling on device) against the
+    reference's loop -- one forward_seq call per window centre, numpy accumulation (deploy_network_ao.py:147-183)."""
+    arch, params, eng = model
+    F, H, W = 13, 32, 48
+    frames = np.random.default_rng(7).standard_normal((F, H, W)).astype(np.float32)
+    prob, pred = eng.run_cine(frames)
+    image = np.transpose(frames, (1, 2, 0))[:, :, None, :]                    # (X, Y, Z=1, T)
+    prob_ref = np.zeros((H, W, 1, F, 3), np.float32)
+    weight = np.zeros((1, 1, 1, F, 1))
+    w = np.reshape(O.aortic_window_weights(5, 0.1), (1, 1, 1, 9, 1))
+    for t in range(F):
+        idx = O.aortic_window_indices(t, F, 5)
+        image_idx = np.transpose(image[:, :, :, idx], axes=(2, 3, 0, 1)).astype(np.float32)[..., None]
+        prob_idx = np.transpose(eng.run_seq(image_idx)['prob'], axes=(2, 3, 0, 1, 4))
+        prob_ref[:, :, :, idx] += prob_idx * w
+        weight[:, :, :, idx] += w
+    prob_ref /= weight
+    want = np.transpose(prob_ref[:, :, 0], (2, 0, 1, 3))                      # [F,H,W,C]
+    np.testing.assert_array_equal(prob, want)                                 # same arithmetic, same order
+    np.testing.assert_array_equal(pred, np.argmax(want, -1).astype(np.int32))
+
+
+def test_errors(model):
+    from ukbb_cardiac_amd import _lib
+    arch, params, eng = model
+    with pytest.raises(_lib.UkbbFcnError, match='sequences'):
+        eng.run(np.zeros((1, 32, 32, 1), np.float32))
+    with pytest.raises(_lib.UkbbFcnError, match='at least'):
+        eng.run_cine(np.zeros((5, 32, 32), np.float32))
+    with pytest.raises(_lib.UkbbFcnError, match='window'):
+        eng.run_cine(np.zeros((12, 32, 32), np.float32), weight_R=4)
+
+
+def test_drop_in_aortic_script_with_the_default_model(tmp_path, model):
+    """demo_pipeline.py:116-117 (`--model UNet-LSTM` is the default): seg_ao.nii.gz == argmax of the tiling loop
+    restated in the oracle, driven by this engine's per-window forward_seq."""
+    import gzip
+    from ukbb_cardiac_amd import deploy_network_ao, nifti
+    from ukbb_cardiac_amd.image_utils import normalise_intensity
+    from ukbb_cardiac_amd.weights import save_blob
+    arch, params, eng = model
+    mp = str(tmp_path / 'UNet-LSTM_ao')
+    save_blob(mp + '.ukbbw', arch, params)
+    rng = np.random.default_rng(31)
+    vol = (100 * rng.gamma(2.0, 1.0, size=(70, 90, 1, 11))).astype(np.float32)
+    d = tmp_path / 'data' / 'subj1'
+    d.mkdir(parents=True)
+    nifti.save(vol, str(d / 'ao.nii.gz'), np.diag([1.6, 1.6, 6.0, 1.0]), pixdim=[1, 1.6, 1.6, 6, 0.01, 0, 0, 0])
+    deploy_network_ao.main(['--seq_name', 'ao', '--data_dir', str(tmp_path / 'data'), '--model_path', mp])
+    seg = nifti.load(str(d / 'seg_ao.nii.gz')).get_data()
+    want = O.aortic_lstm_prob_sequence(normalise_intensity(vol.copy(), 10.0), lambda x: eng.run_seq(x)['prob'])
+    assert seg.dtype == np.int32 and seg.shape == vol.shape
+    np.testing.assert_array_equal(seg, np.argmax(want, -1).astype(np.int32))
+    with pytest.raises(SystemExit):                                        # a plain UNet flag on an LSTM model
+        deploy_network_ao.main(['--seq_name', 'ao', '--data_dir', str(tmp_path / 'data'), '--model_path', mp, '--model', 'UNet'])

@@ -96,6 +96,37 @@ def unet_forward(image_nhwc, params, arch, dtype=torch.float64):
         for i in range(arch.n_block[l]):
             x = unit(x, params['up%d_%d' % (l, i)], 1, dtype)
         up = x
+    if 'logits' not in params:                       # UNet-LSTM: the feature map itself (NCHW tensor)
+        return up
     p = params['logits']
     y = conv_same(up, p['kernel'], 1, dtype) + _t(p['bias'], dtype)[None, :, None, None]
     return y.permute(0, 2, 3, 1).contiguous().numpy()
+
+
+def unet_lstm_forward(image_nthwc, params, arch, dtype=torch.float64):
+    """Independent formulation of UNet_LSTM_Model (common/network_ao.py:322-399, bidirectional): torch convs,
+    gates via chunk(4) in the order i, j, f, o, forget bias 1.0 [TF-recall]."""
+    N, T, H, W, C = image_nthwc.shape
+    feats = unet_forward(np.asarray(image_nthwc).reshape(N * T, H, W, C), params, arch, dtype)   # (N*T, 16, H, W)
+    feats = feats.reshape(N, T, feats.shape[1], H, W)
+    nh = arch.n_hidden
+
+    def run(direction, order):
+        p = params[direction]
+        b = _t(p['bias'], dtype)[None, :, None, None]
+        h = torch.zeros((N, nh, H, W), dtype=dtype)
+        c = torch.zeros_like(h)
+        out = {}
+        for t in order:
+            z = conv_same(torch.cat([feats[:, t], h], dim=1), p['kernel'], 1, dtype) + b
+            i, j, f, o = torch.chunk(z, 4, dim=1)
+            c = torch.sigmoid(f + 1.0) * c + torch.sigmoid(i) * torch.tanh(j)
+            h = torch.tanh(c) * torch.sigmoid(o)
+            out[t] = h
+        return out
+    fw = run('lstm_fw', range(T))
+    bw = run('lstm_bw', range(T - 1, -1, -1))
+    po = params['lstm_out']
+    ys = [conv_same(torch.cat([fw[t], bw[t]], dim=1), po['kernel'], 1, dtype) + _t(po['bias'], dtype)[None, :, None, None]
+          for t in range(T)]
+    return torch.stack(ys, dim=1).permute(0, 1, 3, 4, 2).contiguous().numpy()

@@ -1,0 +1,43 @@
+"""Aortic UNet-LSTM (the reference's default aortic model): one slice position, T = 100 frames of 256x256,
+circular 9-frame windows (common/deploy_network_ao.py:129-183).  GPU box only."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+if __name__ == '__main__':
+    import ctypes as C
+    import torch
+    from ukbb_cardiac_amd import _lib
+    from ukbb_cardiac_amd.arch import MODELS
+    from ukbb_cardiac_amd.engine import Engine
+    from ukbb_cardiac_amd.weights import synthetic_params
+    arch = MODELS['UNet-LSTM_ao']
+    eng = Engine(arch, synthetic_params(arch, 1234))
+    F, H, W = 100, 256, 256
+    x = torch.randn((F, H, W), device='cuda')
+    prob = torch.empty((F, H, W, 3), device='cuda')
+    pred = torch.empty((F, H, W), dtype=torch.int32, device='cuda')
+
+    def step():
+        _lib.check(_lib.lib.ukbb_fcn_forward_cine(eng._h, C.c_void_p(x.data_ptr()), F, H, W, 5, 0.1, C.c_void_p(prob.data_ptr()),
+                                                  C.c_void_p(pred.data_ptr()), None), 'forward_cine')
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 5
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    unet = 3183.5e6 * 2                      # FLOP per 256x256 frame through the U-Net
+    lstm = 2 * 9 * 256 * 256 * (9 * 32 * 64) * 2 + 9 * 256 * 256 * 32 * 3 * 2     # per window: 18 gate convs + 9 output convs
+    ref_flop = F * (9 * unet + lstm)         # the reference recomputes the U-Net for each of the 9 window positions
+    our_flop = F * (unet + lstm)
+    print('UNet-LSTM cine, %d frames of %dx%d, fp32: %.1f ms per slice position = %.0f frames/s' % (F, H, W, dt * 1e3, F / dt))
+    print('   work as the reference executes it: %.2f TFLOP (U-Net 9x per frame) -> %.0f TFLOP/s equivalent; '
+          'as executed here (features once): %.2f TFLOP -> %.0f TFLOP/s' % (ref_flop / 1e12, ref_flop / dt / 1e12, our_flop / 1e12, our_flop / dt / 1e12))

@@ -23,6 +23,7 @@ EXPORTS = [
     'ukbb_fcn_kernel_times', 'ukbb_fcn_get_activation', 'ukbb_fcn_kernel_config', 'ukbb_fcn_conv_config_name',
     'ukbb_fcn_set_timing_kernel', 'ukbb_fcn_set_precision', 'ukbb_fcn_kernel_mfma_macs',
     'ukbb_fcn_select_kth', 'ukbb_fcn_rescale_pack', 'ukbb_fcn_unpack_labels',
+    'ukbb_fcn_forward_seq', 'ukbb_fcn_forward_cine',
 ]
 
 
@@ -81,6 +82,8 @@ def _load():
     lib.ukbb_fcn_set_timing.argtypes = [vp, C.c_int]
     lib.ukbb_fcn_set_timing_kernel.argtypes = [vp, C.c_int]
     lib.ukbb_fcn_set_precision.argtypes = [vp, C.c_int]
+    lib.ukbb_fcn_forward_seq.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
+    lib.ukbb_fcn_forward_cine.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, vp, vp, vp]
     lib.ukbb_fcn_select_kth.argtypes = [vp, C.c_size_t, C.POINTER(C.c_uint64), C.c_int, f32p, vp]
     lib.ukbb_fcn_rescale_pack.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                           C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]

@@ -11,6 +11,7 @@ from typing import List, Tuple
 
 KIND_FCN = 0    # common/network.py:170-230  build_FCN
 KIND_UNET = 1   # common/network_ao.py:18-64 UNet
+KIND_UNET_LSTM = 2   # common/network_ao.py:322-399 UNet_LSTM_Model with BiConv_LSTM (:255-319)
 
 
 @dataclass(frozen=True)
@@ -40,8 +41,16 @@ class ModelArch:
     n_level: int = 5
     n_filter: Tuple[int, ...] = (16, 32, 64, 128, 256)
     n_block: Tuple[int, ...] = (2, 2, 3, 3, 3)
-    same_dim: int = 32
-    fc: int = 64
+    same_dim: int = 32                    # KIND_UNET_LSTM: number of ConvLSTM hidden channels (n_hidden)
+    fc: int = 64                          # KIND_UNET_LSTM: number of unrolled time steps (n_step)
+
+    @property
+    def n_hidden(self) -> int:
+        return self.same_dim
+
+    @property
+    def n_step(self) -> int:
+        return self.fc
 
     def layer_specs(self) -> List[LayerSpec]:
         """Canonical layer order == order of tensors in the flat weight array
@@ -59,14 +68,23 @@ class ModelArch:
             L.append(LayerSpec('out0', (1, 1, self.same_dim * self.n_level, self.fc), True, False))
             L.append(LayerSpec('out1', (1, 1, self.fc, self.fc), True, False))
             L.append(LayerSpec('logits', (1, 1, self.fc, self.n_class), False, True))
-        else:
+        else:                                  # UNet and UNet-LSTM share encoder + decoder
             for l in range(self.n_level - 2, -1, -1):
                 L.append(LayerSpec('up%d_t' % l, (3, 3, nf[l], nf[l + 1]), True, False, transposed=True))
                 c = 2 * nf[l]
                 for i in range(self.n_block[l]):
                     L.append(LayerSpec('up%d_%d' % (l, i), (3, 3, c, nf[l]), True, False))
                     c = nf[l]
-            L.append(LayerSpec('logits', (1, 1, nf[0], self.n_class), False, True))
+            if self.kind == KIND_UNET:
+                L.append(LayerSpec('logits', (1, 1, nf[0], self.n_class), False, True))
+            else:
+                # BiConv_LSTM (network_ao.py:255-319): one 3x3 conv over concat([x, h]) -> 4*n_hidden gate
+                # channels (+bias) per direction, then 1x1 over concat([h_fw, h_bw]) -> n_class (+bias).
+                # The UNet's own conv_out layer exists in the graph but its output is unused (:343-347).
+                nh = self.n_hidden
+                L.append(LayerSpec('lstm_fw', (3, 3, nf[0] + nh, 4 * nh), False, True))
+                L.append(LayerSpec('lstm_bw', (3, 3, nf[0] + nh, 4 * nh), False, True))
+                L.append(LayerSpec('lstm_out', (1, 1, 2 * nh, self.n_class), False, True))
         return L
 
     def n_weight_floats(self) -> int:
@@ -91,6 +109,8 @@ MODELS = {
     'FCN_la_4ch': ModelArch('FCN_la_4ch', KIND_FCN, 3),
     'FCN_la_4ch_seg4': ModelArch('FCN_la_4ch_seg4', KIND_FCN, 6),
     'UNet_ao': ModelArch('UNet_ao', KIND_UNET, 3, n_block=(2, 2, 2, 2, 2)),
+    # train_network_ao.py:292-298 with the demo model's name (...tw9_h16_bidir...): 9 steps, 16 hidden channels
+    'UNet-LSTM_ao': ModelArch('UNet-LSTM_ao', KIND_UNET_LSTM, 3, n_block=(2, 2, 2, 2, 2), same_dim=16, fc=9),
 }
 
 

@@ -123,6 +123,12 @@ struct ukbb_fcn_handle {
     std::vector<Op> ops;
     int last_n = 0;
 
+    // UNet-LSTM (kind 2)
+    int feat_buf = -1;                        // activation index of net['conv0_up']
+    int lstm_cfg_fw = -1, lstm_cfg_bw = -1;
+    const float *lstm_wpk_fw = nullptr, *lstm_wpk_bw = nullptr;
+    DevBuf lstm_gates, lstm_h, lstm_c, lstm_probw, lstm_aux;   // lstm_aux: int maps / orders / double weights (raw bytes)
+
     // side stream for kernels that only feed the head (sqg_l): fork after level l, join before the head
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> ev_fork, ev_join;
@@ -182,7 +188,7 @@ bool arch_specs(const ukbb_fcn_arch &a, std::vector<Spec> &out) {
         out.push_back({"out0", 1, a.same_dim * a.n_level, a.fc, true, false, false});
         out.push_back({"out1", 1, a.fc, a.fc, true, false, false});
         out.push_back({"logits", 1, a.fc, a.n_class, false, true, false});
-    } else if (a.kind == UKBB_KIND_UNET) {
+    } else if (a.kind == UKBB_KIND_UNET || a.kind == UKBB_KIND_UNET_LSTM) {
         for (int l = a.n_level - 2; l >= 0; --l) {
             snprintf(nm, sizeof nm, "up%d_t", l);
             out.push_back({nm, 3, a.n_filter[l + 1], a.n_filter[l], true, false, true});
@@ -193,7 +199,14 @@ bool arch_specs(const ukbb_fcn_arch &a, std::vector<Spec> &out) {
                 c = a.n_filter[l];
             }
         }
-        out.push_back({"logits", 1, a.n_filter[0], a.n_class, false, true, false});
+        if (a.kind == UKBB_KIND_UNET) {
+            out.push_back({"logits", 1, a.n_filter[0], a.n_class, false, true, false});
+        } else {                                  // BiConv_LSTM, network_ao.py:255-319 (same_dim = hidden channels)
+            if (a.same_dim < 1 || a.fc < 1) return false;
+            out.push_back({"lstm_fw", 3, a.n_filter[0] + a.same_dim, 4 * a.same_dim, false, true, false});
+            out.push_back({"lstm_bw", 3, a.n_filter[0] + a.same_dim, 4 * a.same_dim, false, true, false});
+            out.push_back({"lstm_out", 1, 2 * a.same_dim, a.n_class, false, true, false});
+        }
     } else {
         return false;
     }
@@ -217,6 +230,10 @@ bool supported(const ukbb_fcn_arch &a, std::string &why) {
         if (a.n_class < 2 || a.n_class > 6) { why = "n_class must be in 2..6"; return false; }
     } else {
         if (a.n_class < 2 || a.n_class > 4) { why = "UNet n_class must be in 2..4"; return false; }
+        if (a.kind == UKBB_KIND_UNET_LSTM) {
+            if (a.same_dim != 16) { why = "ConvLSTM kernels are built for 16 hidden channels"; return false; }
+            if (a.fc < 1 || a.fc > 31 || !(a.fc & 1)) { why = "the time window must be odd and < 32 steps"; return false; }
+        }
     }
     return true;
 }
@@ -497,10 +514,30 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
             up = x;
             h->act_name[up] = std::string("up") + std::to_string(l);
         }
-        Op op; op.kind = OP_LOGITS; op.name = "logits"; op.layer = h->layer_index.at("logits"); op.in0 = up;
-        op.H = op.Ho = H; op.W = op.Wo = W;
-        op.macs_per_image = (double)H * W * a.n_filter[0] * a.n_class;
-        h->ops.push_back(op);
+        h->feat_buf = up;                              // net['conv0_up']: what UNet_LSTM_Model feeds the LSTM (:343-347)
+        if (a.kind == UKBB_KIND_UNET) {
+            Op op; op.kind = OP_LOGITS; op.name = "logits"; op.layer = h->layer_index.at("logits"); op.in0 = up;
+            op.H = op.Ho = H; op.W = op.Wo = W;
+            op.macs_per_image = (double)H * W * a.n_filter[0] * a.n_class;
+            h->ops.push_back(op);
+        } else {
+            // gate convolutions of the two directions: tiling + packed weights chosen once per plan
+            for (const char *nm2 : {"lstm_fw", "lstm_bw"}) {
+                const int li = h->layer_index.at(nm2);
+                const HostLayer &L = h->layers[li];
+                const int cfg = choose_cfg(nm2, 3, 1, a.n_filter[0], a.same_dim, L.cout, H, W, n_hint, false, false);
+                ConvConfig c;
+                if (cfg < 0 || find_cfg(cfg, c) || c.pc != 4) {
+                    set_err("the ConvLSTM gate conv needs the Winograd kernel (unset UKBB_NO_WINOGRAD / UKBB_CONV_CFG overrides)");
+                    return UKBB_EARCH;
+                }
+                const float *wpk = nullptr;
+                int rc = ensure_packed(h, li, c, &wpk);
+                if (rc) return rc;
+                (std::string(nm2) == "lstm_fw" ? h->lstm_cfg_fw : h->lstm_cfg_bw) = cfg;
+                (std::string(nm2) == "lstm_fw" ? h->lstm_wpk_fw : h->lstm_wpk_bw) = wpk;
+            }
+        }
     }
     h->plan_h = H; h->plan_w = W;
     // events
@@ -777,6 +814,10 @@ ukbb_fcn_handle *ukbb_fcn_create(const ukbb_fcn_arch *arch, const float *weights
         const HostLayer &L0 = h->layers[h->layer_index.at("conv0_0")];
         if (upload(h.get(), "conv0_0/w", L0.w)) return nullptr;      // [9][16]
     }
+    if (arch->kind == UKBB_KIND_UNET_LSTM) {
+        const HostLayer &lo = h->layers[h->layer_index.at("lstm_out")];   // [2*NH][n_class]
+        if (upload(h.get(), "lstm_out/w", lo.w)) return nullptr;
+    }
     if (arch->kind == UKBB_KIND_FCN) {
         const HostLayer &s0 = h->layers[h->layer_index.at("same_dim0")];
         const HostLayer &o0 = h->layers[h->layer_index.at("out0")];
@@ -800,7 +841,7 @@ ukbb_fcn_handle *ukbb_fcn_create(const ukbb_fcn_arch *arch, const float *weights
             v.assign(2 * 4 * 64 * 4, 0.f);       pack_rowmap_32x64(o0.w.data() + (size_t)32 * l * 64, 64, v.data());
             if (upload(h.get(), "sqg" + std::to_string(l) + "/w_g", v)) return nullptr;
         }
-    } else {
+    } else if (arch->kind == UKBB_KIND_UNET) {
         const HostLayer &lg = h->layers[h->layer_index.at("logits")];
         if (upload(h.get(), "logits/w", lg.w)) return nullptr;
     }
@@ -822,6 +863,7 @@ int ukbb_fcn_reserve(ukbb_fcn_handle *h, int n, int height, int width) {
 int ukbb_fcn_forward(ukbb_fcn_handle *h, const float *image, int n, int height, int width,
                      float *logits, float *prob, int32_t *pred, void *stream) {
     if (!h || !image) { set_err("forward: NULL argument"); return UKBB_EINVAL; }
+    if (h->arch.kind == UKBB_KIND_UNET_LSTM) { set_err("forward: UNet-LSTM models take sequences: use ukbb_fcn_forward_seq / ukbb_fcn_forward_cine"); return UKBB_EINVAL; }
     int rc = prepare(h, n, height, width);
     if (rc) return rc;
     return run_plan(h, image, n, logits, prob, pred, static_cast<hipStream_t>(stream));
@@ -830,6 +872,7 @@ int ukbb_fcn_forward(ukbb_fcn_handle *h, const float *image, int n, int height, 
 int ukbb_fcn_forward_host(ukbb_fcn_handle *h, const float *image, int n, int height, int width,
                           float *logits, float *prob, int32_t *pred) {
     if (!h || !image) { set_err("forward_host: NULL argument"); return UKBB_EINVAL; }
+    if (h->arch.kind == UKBB_KIND_UNET_LSTM) { set_err("forward_host: UNet-LSTM models take sequences: use ukbb_fcn_forward_seq / ukbb_fcn_forward_cine"); return UKBB_EINVAL; }
     int rc = prepare(h, n, height, width);
     if (rc) return rc;
     const size_t npix = (size_t)n * height * width, ncls = h->arch.n_class;
@@ -845,6 +888,144 @@ int ukbb_fcn_forward_host(ukbb_fcn_handle *h, const float *image, int n, int hei
     if (prob) HIP_TRY(hipMemcpyAsync(prob, h->io_prob.p, npix * ncls * sizeof(float), hipMemcpyDeviceToHost, nullptr), UKBB_EDEVICE);
     if (pred) HIP_TRY(hipMemcpyAsync(pred, h->io_pred.p, npix * sizeof(int32_t), hipMemcpyDeviceToHost, nullptr), UKBB_EDEVICE);
     HIP_TRY(hipStreamSynchronize(nullptr), UKBB_EDEVICE);
+    return UKBB_OK;
+}
+
+// ---- UNet-LSTM --------------------------------------------------------------------------------------
+namespace {
+
+// BiConvLSTM over Wn windows of T steps.  map[k*Wn + w] = feature frame of step k of window w.
+// out: per (k, w) n_class floats per pixel at out + k*k_stride + w*w_stride (softmax probabilities);
+// logits / pred optional with the same addressing (pred strides divided by n_class).
+int run_bilstm(ukbb_fcn_handle *h, const float *feat, const int *d_map, int Wn, int H, int W,
+               float *out, long long k_stride, long long w_stride, float *logits, int32_t *pred, hipStream_t s) {
+    const ukbb_fcn_arch &a = h->arch;
+    const int T = a.fc, NHID = a.same_dim, C = a.n_class;
+    const size_t HW = (size_t)H * W;
+    HIP_TRY(h->lstm_gates.ensure((size_t)Wn * HW * 4 * NHID), UKBB_ENOMEM);
+    HIP_TRY(h->lstm_h.ensure((size_t)Wn * HW * NHID), UKBB_ENOMEM);
+    HIP_TRY(h->lstm_c.ensure((size_t)Wn * HW * NHID), UKBB_ENOMEM);
+    const float *w_out = dev_ptr(h, "lstm_out/w"), *b_out = dev_ptr(h, "lstm_out/bias");
+    for (int dir = 0; dir < 2; ++dir) {
+        HIP_TRY(hipMemsetAsync(h->lstm_h.p, 0, (size_t)Wn * HW * NHID * sizeof(float), s), UKBB_EDEVICE);   // zero_state (:278,:290)
+        HIP_TRY(hipMemsetAsync(h->lstm_c.p, 0, (size_t)Wn * HW * NHID * sizeof(float), s), UKBB_EDEVICE);
+        const int cfg = dir ? h->lstm_cfg_bw : h->lstm_cfg_fw;
+        ConvConfig c;
+        find_cfg(cfg, c);
+        for (int step = 0; step < T; ++step) {
+            const int k = dir ? T - 1 - step : step;
+            ConvArgs ca{};
+            ca.in0 = feat; ca.in0_map = d_map + (size_t)k * Wn; ca.C0 = a.n_filter[0];
+            ca.in1 = h->lstm_h.p; ca.C1 = NHID;
+            ca.wpk = dir ? h->lstm_wpk_bw : h->lstm_wpk_fw;
+            ca.bias = dev_ptr(h, dir ? "lstm_bw/bias" : "lstm_fw/bias");
+            ca.out = h->lstm_gates.p;
+            ca.N = Wn; ca.H = H; ca.W = W; ca.Ho = H; ca.Wo = W; ca.Cout = 4 * NHID;
+            ca.pad_y = 1; ca.pad_x = 1;
+            ca.tiles_y = (H + c.th - 1) / c.th; ca.tiles_x = (W + c.tw - 1) / c.tw;
+            ca.relu = 0;
+            hipError_t e = launch_conv(cfg, ca, s);
+            if (e != hipSuccess) { set_err("ConvLSTM gate conv launch failed: %s", hipGetErrorString(e)); return UKBB_EDEVICE; }
+            LstmCellArgs la{};
+            la.gates = h->lstm_gates.p; la.c = h->lstm_c.p; la.h = h->lstm_h.p;
+            la.w_out = w_out + (size_t)dir * NHID * C; la.b_out = b_out;
+            la.acc = out + (size_t)k * k_stride; la.m_stride = w_stride;
+            la.logits = (dir && logits) ? logits + (size_t)k * k_stride : nullptr;
+            la.pred = (dir && pred) ? pred + (size_t)k * (k_stride / C) : nullptr;
+            la.M = Wn; la.HW = (int)HW; la.n_class = C; la.forget_bias = 1.0f; la.finish = dir;
+            e = launch_lstm_cell(la, s);
+            if (e != hipSuccess) { set_err("ConvLSTM cell launch failed: %s", hipGetErrorString(e)); return UKBB_EDEVICE; }
+        }
+    }
+    return UKBB_OK;
+}
+
+int lstm_common_checks(ukbb_fcn_handle *h, const float *image, const char *what) {
+    if (!h || !image) { set_err("%s: NULL argument", what); return UKBB_EINVAL; }
+    if (h->arch.kind != UKBB_KIND_UNET_LSTM) { set_err("%s: the model is not a UNet-LSTM", what); return UKBB_EINVAL; }
+    return UKBB_OK;
+}
+
+}  // namespace
+
+int ukbb_fcn_forward_seq(ukbb_fcn_handle *h, const float *image, int n_seq, int height, int width,
+                         float *logits, float *prob, int32_t *pred, void *stream) {
+    int rc = lstm_common_checks(h, image, "forward_seq");
+    if (rc) return rc;
+    const int T = h->arch.fc, C = h->arch.n_class;
+    if (n_seq < 1) { set_err("forward_seq: n_seq must be positive"); return UKBB_EINVAL; }
+    rc = prepare(h, n_seq * T, height, width);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    rc = run_plan(h, image, n_seq * T, nullptr, nullptr, nullptr, s);       // U-Net features of every frame
+    if (rc) return rc;
+    const size_t HW = (size_t)height * width;
+    // map[k][w] = w*T + k; outputs straight into [N][T] order
+    std::vector<int> map((size_t)T * n_seq);
+    for (int k = 0; k < T; ++k)
+        for (int w = 0; w < n_seq; ++w) map[(size_t)k * n_seq + w] = w * T + k;
+    HIP_TRY(h->lstm_aux.ensure((map.size() * sizeof(int) + 3) / 4), UKBB_ENOMEM);
+    HIP_TRY(hipMemcpyAsync(h->lstm_aux.p, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice, s), UKBB_EDEVICE);
+    HIP_TRY(hipStreamSynchronize(s), UKBB_EDEVICE);                          // `map` is pageable host memory
+    float *out = prob;
+    if (!out) {                                                              // the cell kernel needs an accumulator
+        HIP_TRY(h->lstm_probw.ensure((size_t)n_seq * T * HW * C), UKBB_ENOMEM);
+        out = h->lstm_probw.p;
+    }
+    return run_bilstm(h, h->act[h->feat_buf]->p, reinterpret_cast<const int *>(h->lstm_aux.p), n_seq, height, width,
+                      out, (long long)HW * C, (long long)T * HW * C, logits, pred, s);
+}
+
+int ukbb_fcn_forward_cine(ukbb_fcn_handle *h, const float *image, int n_frames, int height, int width,
+                          int weight_R, double weight_r, float *prob, int32_t *pred, void *stream) {
+    int rc = lstm_common_checks(h, image, "forward_cine");
+    if (rc) return rc;
+    const int T = h->arch.fc, C = h->arch.n_class, F = n_frames;
+    if (!prob) { set_err("forward_cine: prob must not be NULL"); return UKBB_EINVAL; }
+    if (2 * weight_R - 1 != T) { set_err("forward_cine: time window 2*weight_R-1 = %d, the model is unrolled for %d steps", 2 * weight_R - 1, T); return UKBB_EINVAL; }
+    if (F < T) { set_err("forward_cine: %d frames, need at least the window length %d", F, T); return UKBB_EINVAL; }
+    rc = prepare(h, F, height, width);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    rc = run_plan(h, image, F, nullptr, nullptr, nullptr, s);               // each frame's U-Net features, once
+    if (rc) return rc;
+    const size_t HW = (size_t)height * width;
+    const int rad = (T - 1) / 2;
+    // host-side tables: window maps (deploy_network_ao.py:147-158), weights (:134-144), per-frame order + weight sums
+    std::vector<int> map((size_t)T * F), order((size_t)F * T);
+    std::vector<double> wk(T), wsum(F, 0.0);
+    for (int k = 0; k < T; ++k) {
+        const int d = k > rad ? k - rad : rad - k;
+        wk[k] = d <= weight_R ? pow(1.0 - (double)d / weight_R, weight_r) : 0.0;
+        for (int w = 0; w < F; ++w) map[(size_t)k * F + w] = ((w - rad + k) % F + F) % F;
+    }
+    std::vector<int> cnt(F, 0);
+    for (int t = 0; t < F; ++t)                                             // the reference's loop over window centres
+        for (int k = 0; k < T; ++k) {
+            const int f = map[(size_t)k * F + t];
+            order[(size_t)f * T + cnt[f]++] = t * T + k;
+            wsum[f] += wk[k];
+        }
+    const size_t b_map = map.size() * sizeof(int), b_ord = order.size() * sizeof(int);
+    const size_t off_ord = (b_map + 7) / 8 * 8, off_wk = (off_ord + b_ord + 7) / 8 * 8, off_ws = off_wk + T * sizeof(double);
+    const size_t total = off_ws + F * sizeof(double);
+    HIP_TRY(h->lstm_aux.ensure((total + 3) / 4), UKBB_ENOMEM);
+    char *aux = reinterpret_cast<char *>(h->lstm_aux.p);
+    HIP_TRY(hipMemcpyAsync(aux, map.data(), b_map, hipMemcpyHostToDevice, s), UKBB_EDEVICE);
+    HIP_TRY(hipMemcpyAsync(aux + off_ord, order.data(), b_ord, hipMemcpyHostToDevice, s), UKBB_EDEVICE);
+    HIP_TRY(hipMemcpyAsync(aux + off_wk, wk.data(), T * sizeof(double), hipMemcpyHostToDevice, s), UKBB_EDEVICE);
+    HIP_TRY(hipMemcpyAsync(aux + off_ws, wsum.data(), F * sizeof(double), hipMemcpyHostToDevice, s), UKBB_EDEVICE);
+    HIP_TRY(hipStreamSynchronize(s), UKBB_EDEVICE);                          // tables are pageable host memory
+    HIP_TRY(h->lstm_probw.ensure((size_t)T * F * HW * C), UKBB_ENOMEM);
+    rc = run_bilstm(h, h->act[h->feat_buf]->p, reinterpret_cast<const int *>(aux), F, height, width,
+                    h->lstm_probw.p, (long long)F * HW * C, (long long)HW * C, nullptr, nullptr, s);
+    if (rc) return rc;
+    LstmTileArgs ta{};
+    ta.probw = h->lstm_probw.p; ta.order = reinterpret_cast<const int *>(aux + off_ord);
+    ta.wk = reinterpret_cast<const double *>(aux + off_wk); ta.wsum = reinterpret_cast<const double *>(aux + off_ws);
+    ta.prob = prob; ta.pred = pred; ta.F = F; ta.K = T; ta.Wn = F; ta.HW = (int)HW; ta.C = C;
+    hipError_t e = launch_lstm_tile(ta, s);
+    if (e != hipSuccess) { set_err("tiling kernel launch failed: %s", hipGetErrorString(e)); return UKBB_EDEVICE; }
     return UKBB_OK;
 }
 

@@ -27,6 +27,8 @@ struct ConvArgs {
     const float *first_b;   //   and bias [KC]; in0 is then the 1-channel network input [N,H,W]
     int up2;            // 0: plain conv.  C > 0: the 4*C output channels are the 4 sub-pixel phases of a
                         // stride-2 transposed conv with C real channels; scatter to out[N,2Ho,2Wo,C]
+    const int *in0_map; // optional (Winograd kernel only): image n of the batch reads in0 image in0_map[n]
+                        // (ConvLSTM windows share cached U-Net feature frames); in1 / out are not remapped
 };
 
 // One compiled tiling of the conv kernel.
@@ -134,5 +136,34 @@ struct LogitsArgs {         // 1x1 conv C -> n_class + bias, softmax / argmax (n
     int64_t npix; int C, n_class;
 };
 hipError_t launch_logits(const LogitsArgs &a, hipStream_t s);
+
+// ---- BiConvLSTM head of the aortic UNet-LSTM (network_ao.py:255-319), kernels_lstm.hip ----
+struct LstmCellArgs {       // one ConvLSTM step after the gate conv: state update + this direction's half of the 1x1 output conv
+    const float *gates;     // [M][HW][4*NH] pre-activations in the order i, j, f, o (bias already added by the conv)
+    float *c;               // [M][HW][NH] cell state, updated in place
+    float *h;               // [M][HW][NH] hidden state, overwritten
+    const float *w_out;     // [NH][n_class]: this direction's rows of the output conv kernel [2*NH][n_class]
+    const float *b_out;     // [n_class] (used in the finishing pass)
+    float *acc;             // per (window m, pixel): n_class floats at acc + m*m_stride + pix*n_class
+    float *logits;          // optional, same addressing: the finished logits (finishing pass only)
+    int32_t *pred;          // optional: argmax at pred + m*(m_stride/n_class) + pix (finishing pass only)
+    long long m_stride;     // floats between consecutive windows in acc / logits
+    int M, HW, n_class;
+    float forget_bias;
+    int finish;             // 0: acc = W.h (forward direction);  1: acc = softmax(acc + W.h + b) (backward direction)
+};
+hipError_t launch_lstm_cell(const LstmCellArgs &a, hipStream_t s);
+
+struct LstmTileArgs {       // weighted tiling of the window probabilities, deploy_network_ao.py:176-183
+    const float *probw;     // [K][Wn][HW][C] window probabilities (K = window length, Wn = F windows, centre t = w)
+    const int *order;       // [F][K] for frame f: the K contributing (window w, position k) pairs packed w*K + k,
+                            //        sorted the way the reference's loop over t adds them
+    const double *wk;       // [K] window weights
+    const double *wsum;     // [F] accumulated weight per frame
+    float *prob;            // [F][HW][C]
+    int32_t *pred;          // [F][HW]
+    int F, K, Wn, HW, C;
+};
+hipError_t launch_lstm_tile(const LstmTileArgs &a, hipStream_t s);
 
 }  // namespace ukbb

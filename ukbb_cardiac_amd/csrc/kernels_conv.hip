@@ -807,6 +807,7 @@ hipError_t launch_conv(int cfg_id, const ConvArgs &a, hipStream_t s) {
     if (!c) return hipErrorInvalidValue;
     const int group = c->mb * c->cb * c->wm;
     if (c->pc == 4) return launch_wino(a, c->wm, s);
+    if (a.in0_map) return hipErrorInvalidValue;       // image remapping exists in the Winograd kernel only
     if (c->pc == 2) {
         if (!a.first_w || !a.first_b || a.Cout != group) return hipErrorInvalidValue;
     } else if (a.Cout % group || (a.C0 + a.C1) % c->kc || a.C0 % c->kc) {

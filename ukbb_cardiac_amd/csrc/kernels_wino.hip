@@ -126,10 +126,11 @@ __global__ __launch_bounds__(512, 2) void wino_pc_kernel(const ConvArgs a) {
         int cur_cs = 0;
         u32x4 xr[NITX];
         // scalar cursor of the next stage to request
-        int l_ch = 0, l_item = blockIdx.x, l_n = 0, l_iy0 = 0, l_ix0 = 0;
+        int l_ch = 0, l_item = blockIdx.x, l_n = 0, l_n0 = 0, l_iy0 = 0, l_ix0 = 0;
         auto locate = [&]() {
             const int rest = l_item % per_group;
             l_n = rest / regions;
+            l_n0 = a.in0_map ? a.in0_map[l_n] : l_n;     // scalar load; ConvLSTM windows index shared feature frames
             const int r = rest - l_n * regions;
             const int ry = r / regs_x, rx = r - ry * regs_x;
             l_iy0 = ry * 2 * TRY - 1; l_ix0 = rx * 2 * TRX - 1;
@@ -137,14 +138,16 @@ __global__ __launch_bounds__(512, 2) void wino_pc_kernel(const ConvArgs a) {
         locate();
         auto loadx = [&]() {                            // raw halo of the cursor stage -> registers; advances the cursor
             const float *src; int cs;
-            if (l_ch * WKC < a.C0) { src = a.in0 + l_ch * WKC; cs = a.C0; }
-            else                   { src = a.in1 + (l_ch * WKC - a.C0); cs = a.C1; }
+            const bool from0 = l_ch * WKC < a.C0;
+            if (from0) { src = a.in0 + l_ch * WKC; cs = a.C0; }
+            else       { src = a.in1 + (l_ch * WKC - a.C0); cs = a.C1; }
+            const int nimg = from0 ? l_n0 : l_n;
             if (cs != cur_cs) {                         // uniform; once per source switch
                 cur_cs = cs;
 #pragma unroll
                 for (int it = 0; it < NITX; ++it) pre[it] = pixoff[it] * (unsigned)(cs * 4) + 16u * c4;
             }
-            src += ((long long)(l_n * a.H + l_iy0) * a.W + l_ix0) * cs;   // may point before the tensor; masked lanes never use it
+            src += ((long long)(nimg * a.H + l_iy0) * a.W + l_ix0) * cs;   // may point before the tensor; masked lanes never use it
             const int ylo = l_iy0 < 0 ? -l_iy0 : 0, yhi = a.H - l_iy0 < WIH ? a.H - l_iy0 : WIH;
             const int xlo = l_ix0 < 0 ? -l_ix0 : 0, xhi = a.W - l_ix0 < WIW ? a.W - l_ix0 : WIW;
             const unsigned cm = (((1u << yhi) - 1u) & ~((1u << ylo) - 1u)) | ((((1u << xhi) - 1u) & ~((1u << xlo) - 1u)) << WIH);

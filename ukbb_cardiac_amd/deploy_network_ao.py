@@ -4,9 +4,10 @@ segmentation) on the MI355X HIP engine.
 
 Command line as in ``demo_pipeline.py:116-117``.  Implemented: ``--model UNet``
 (frame-wise 2-D U-Net, ``deploy_network_ao.py:111-128``) in sequence and ED/ES
-mode.  The reference's default ``--model UNet-LSTM`` (bidirectional ConvLSTM over
-a 9-frame window, ``:129-183``) is a "next" row and is
-refused with a clear message rather than silently replaced.
+mode, and the reference's default ``--model UNet-LSTM`` (U-Net features +
+bidirectional ConvLSTM over circular 9-frame windows with weighted tiling,
+``:129-183``) in sequence mode with ``--time_step 1``.  ``Temporal-UNet`` is not
+built and is refused with a clear message rather than silently replaced.
 
 Output: ``seg_ao.nii.gz`` int32 with the input's affine and pixdim (``:189-196``).
 """
@@ -46,11 +47,16 @@ def define_flags():
     return fs
 
 
-def run(FLAGS, forward, log=print):
-    if FLAGS.model != 'UNet':
-        raise NotImplementedError(
-            "--model %s: the ConvLSTM / temporal heads (common/network_ao.py:67-399) are not built yet; "
-            "only the frame-wise 2-D 'UNet' (--model UNet) is available" % FLAGS.model)
+def run(FLAGS, forward, log=print, cine_forward=None):
+    """``forward`` stands for the frame-wise sess.run ('UNet'); ``cine_forward`` for the windowed one ('UNet-LSTM')."""
+    if FLAGS.model == 'Temporal-UNet':
+        raise NotImplementedError("--model Temporal-UNet (common/network_ao.py:67-114, 3-D convolutions) is not built")
+    if FLAGS.model == 'UNet-LSTM':
+        if cine_forward is None:
+            raise ValueError('--model UNet-LSTM needs a UNet-LSTM model (cine_forward)')
+        if FLAGS.time_step != 1:
+            raise NotImplementedError('--time_step %d: only the default 1 is supported (other steps leave frames '
+                                      'uncovered when they do not divide the window)' % FLAGS.time_step)
     start_time = time.time()
     data_list = subjects_for_shard(sorted(os.listdir(FLAGS.data_dir)), FLAGS.shard_index, FLAGS.num_shards)
     processed = []
@@ -71,7 +77,10 @@ def run(FLAGS, forward, log=print):
             image = nim.get_data()
             log('  Segmenting full sequence ...')
             t0 = time.time()
-            prob = pipeline.aortic_prob_sequence(image, forward, FLAGS.z_score, FLAGS.batch_slices)
+            if FLAGS.model == 'UNet-LSTM':
+                prob = pipeline.aortic_lstm_prob_sequence(image, cine_forward, FLAGS.z_score, FLAGS.weight_R, FLAGS.weight_r)
+            else:
+                prob = pipeline.aortic_prob_sequence(image, forward, FLAGS.z_score, FLAGS.batch_slices)
             pred = np.argmax(prob, axis=-1).astype(np.int32)          # host argmax, as :189
             if FLAGS.save_seg:
                 log('  Saving segmentation ...')
@@ -79,6 +88,9 @@ def run(FLAGS, forward, log=print):
             log('  Segmentation time = {:3f}s'.format(time.time() - t0))
             processed.append(data)
         else:
+            if FLAGS.model == 'UNet-LSTM':                             # reference: deploy_network_ao.py:202-205
+                log('UNet-LSTM does not support frame-wise segmentation. Please use the -process_seq flag.')
+                return processed
             names = {fr: '{0}/{1}_{2}.nii.gz'.format(data_dir, seq, fr) for fr in ('ED', 'ES')}
             if not all(os.path.exists(p) for p in names.values()):
                 log('  Directory {0} does not contain an image with file name {1} or {2}. Skip.'.format(
@@ -110,17 +122,23 @@ def main(argv=None):
         sys.exit('FATAL Flags parsing error: %s\n%s' % (e, fs.usage()))
     if 'CUDA_VISIBLE_DEVICES' in os.environ and 'HIP_VISIBLE_DEVICES' not in os.environ:
         os.environ['HIP_VISIBLE_DEVICES'] = os.environ['CUDA_VISIBLE_DEVICES']
-    if FLAGS.model != 'UNet':
-        sys.exit("Error: --model %s is not available on the HIP engine yet (only --model UNet); "
-                 "see DESIGN.md section 7." % FLAGS.model)
+    if FLAGS.model == 'Temporal-UNet':
+        sys.exit("Error: --model Temporal-UNet is not available on the HIP engine (see DESIGN.md section 7).")
+    from ukbb_cardiac_amd.arch import KIND_UNET_LSTM
     from ukbb_cardiac_amd.engine import Session
     with Session(FLAGS.model_path, device=FLAGS.device) as sess:
+        is_lstm = sess.engine.arch.kind == KIND_UNET_LSTM
+        if is_lstm != (FLAGS.model == 'UNet-LSTM'):
+            sys.exit('Error: --model %s but %s holds a %s model.' % (FLAGS.model, FLAGS.model_path, sess.engine.arch.name))
         print('Start evaluating on the test set ...')
 
         def forward(batch):
             prob, pred = sess.run(['prob:0', 'pred:0'], feed_dict={'image:0': batch, 'training:0': False})
             return {'prob': prob, 'pred': pred}
-        run(FLAGS, forward)
+
+        def cine_forward(frames, weight_R, weight_r):
+            return sess.engine.run_cine(frames, weight_R, weight_r)[0]
+        run(FLAGS, forward, cine_forward=cine_forward)
 
 
 if __name__ == '__main__':

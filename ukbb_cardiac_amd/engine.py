@@ -90,6 +90,58 @@ class Engine:
                                        C.c_void_p(pred_ptr or None), C.c_void_p(stream or None))
         _lib.check(rc, 'ukbb_fcn_forward')
 
+    # -- UNet-LSTM (aortic default model) ---------------------------------------------
+    def run_seq(self, image: np.ndarray, want_logits=False, want_prob=True, want_pred=True):
+        """The reference's ``sess.run('prob:0', {'image:0': image_idx})`` for the UNet-LSTM graph
+        (common/deploy_network_ao.py:171-172): image float32 [N,T,H,W,1] (or [N,T,H,W]) with T = arch.n_step
+        -> 'prob' [N,T,H,W,C], 'pred' [N,T,H,W], optionally 'logits'.  Host arrays; staged through torch tensors."""
+        import torch
+        x = np.ascontiguousarray(image, dtype=np.float32)
+        if x.ndim == 5:
+            x = x[..., 0]
+        if x.ndim != 4 or x.shape[1] != self.arch.n_step:
+            raise ValueError('image must be [N,%d,H,W,1], got shape %s' % (self.arch.n_step, image.shape))
+        n, t, h, w = x.shape
+        c = self.arch.n_class
+        dev = torch.device('cuda', self.device)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        xd = torch.from_numpy(x).to(dev)
+        lg = torch.empty((n, t, h, w, c), dtype=torch.float32, device=dev) if want_logits else None
+        pr = torch.empty((n, t, h, w, c), dtype=torch.float32, device=dev) if (want_prob or True) else None
+        pd = torch.empty((n, t, h, w), dtype=torch.int32, device=dev) if want_pred else None
+        rc = _lib.lib.ukbb_fcn_forward_seq(self._h, C.c_void_p(xd.data_ptr()), n, h, w,
+                                           C.c_void_p(lg.data_ptr() if lg is not None else None),
+                                           C.c_void_p(pr.data_ptr()), C.c_void_p(pd.data_ptr() if pd is not None else None),
+                                           C.c_void_p(stream or None))
+        _lib.check(rc, 'ukbb_fcn_forward_seq')
+        out: Dict[str, np.ndarray] = {}
+        if want_logits:
+            out['logits'] = lg.cpu().numpy()
+        if want_prob:
+            out['prob'] = pr.cpu().numpy()
+        if want_pred:
+            out['pred'] = pd.cpu().numpy()
+        return out
+
+    def run_cine(self, frames: np.ndarray, weight_R: int = 5, weight_r: float = 0.1):
+        """One slice position of the 'UNet-LSTM' branch of common/deploy_network_ao.py:129-183,189: frames float32
+        [F,H,W] (normalised, padded) -> (prob [F,H,W,C] float32, pred [F,H,W] int32), circular windows tiled on
+        the device; the U-Net features of each frame are computed once."""
+        import torch
+        x = np.ascontiguousarray(frames, dtype=np.float32)
+        if x.ndim != 3:
+            raise ValueError('frames must be [F,H,W], got shape %s' % (frames.shape,))
+        f, h, w = x.shape
+        dev = torch.device('cuda', self.device)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        xd = torch.from_numpy(x).to(dev)
+        pr = torch.empty((f, h, w, self.arch.n_class), dtype=torch.float32, device=dev)
+        pd = torch.empty((f, h, w), dtype=torch.int32, device=dev)
+        rc = _lib.lib.ukbb_fcn_forward_cine(self._h, C.c_void_p(xd.data_ptr()), f, h, w, int(weight_R), float(weight_r),
+                                            C.c_void_p(pr.data_ptr()), C.c_void_p(pd.data_ptr()), C.c_void_p(stream or None))
+        _lib.check(rc, 'ukbb_fcn_forward_cine')
+        return pr.cpu().numpy(), pd.cpu().numpy()
+
     def set_precision(self, precision: str):
         """'fp32' (default) or 'bf16' (bf16 MFMA inputs, fp32 accumulate; BASELINE config 5)."""
         code = {'fp32': 0, 'bf16': 1}[precision]

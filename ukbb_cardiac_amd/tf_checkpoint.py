@@ -35,7 +35,7 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
-from .arch import KIND_FCN, KIND_UNET, MODELS, ModelArch
+from .arch import KIND_FCN, KIND_UNET, KIND_UNET_LSTM, MODELS, ModelArch
 
 TABLE_MAGIC = 0xdb4775248b80fb57
 FOOTER_LEN = 48
@@ -331,6 +331,15 @@ def variable_names(arch: ModelArch) -> "OrderedDict[str, Dict[str, str]]":
         return '%s/%s' % (scope, _numbered(base, k))
 
     for s in arch.layer_specs():
+        if s.name in ('lstm_fw', 'lstm_bw'):
+            # tf.contrib.rnn.Conv2DLSTMCell under variable_scope('LSTM') / ('forward' | 'backward')
+            # (network_ao.py:270-295) [TF-recall: the cell's default scope name and its `kernel` / `biases` names]
+            base = 'LSTM/%s/conv_lstm_cell' % ('forward' if s.name == 'lstm_fw' else 'backward')
+            out[s.name] = {'kernel': base + '/kernel', 'bias': base + '/biases'}
+            continue
+        if s.name == 'lstm_out':
+            out[s.name] = {'kernel': 'LSTM/output/conv2d/kernel', 'bias': 'LSTM/output/conv2d/bias'}   # :298-309
+            continue
         if s.name == 'logits':
             scope = 'UNet/conv_out'
         elif s.name.startswith('conv'):
@@ -363,11 +372,20 @@ def infer_arch(reader: CheckpointReader) -> ModelArch:
             n_filter.append(reader.shape('UNet/conv%d/conv2d/kernel' % l)[3])
             n_block.append(k)
             l += 1
-        if not n_filter or 'UNet/conv_out/conv2d/kernel' not in names:
+        lstm = 'LSTM/forward/conv_lstm_cell/kernel' in names
+        if not n_filter or (not lstm and 'UNet/conv_out/conv2d/kernel' not in names):
             raise CheckpointError('UNet checkpoint without the expected UNet/conv{l}/conv2d variables')
-        n_class = reader.shape('UNet/conv_out/conv2d/kernel')[3]
-        cand = ModelArch('UNet_custom', KIND_UNET, n_class, n_level=len(n_filter), n_filter=tuple(n_filter),
-                         n_block=tuple(n_block))
+        if lstm:
+            # the unrolled step count is not recoverable from the variables: the released model is trained with a
+            # 9-frame window (model name ...tw9_h16_bidir..., deploy_network_ao.py:36-38,130)
+            n_hidden = reader.shape('LSTM/forward/conv_lstm_cell/kernel')[3] // 4
+            cand = ModelArch('UNet-LSTM_custom', KIND_UNET_LSTM, reader.shape('LSTM/output/conv2d/kernel')[3],
+                             n_level=len(n_filter), n_filter=tuple(n_filter), n_block=tuple(n_block),
+                             same_dim=n_hidden, fc=9)
+        else:
+            n_class = reader.shape('UNet/conv_out/conv2d/kernel')[3]
+            cand = ModelArch('UNet_custom', KIND_UNET, n_class, n_level=len(n_filter), n_filter=tuple(n_filter),
+                             n_block=tuple(n_block))
     else:
         shapes = []
         k = 0
