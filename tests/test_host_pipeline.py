@@ -177,8 +177,14 @@ def test_aortic_deploy(tmp_path):
     want = np.argmax(np.stack([(norm < -0.2), (np.abs(norm) <= 0.2), (norm > 0.2)], -1), -1).astype(np.int32)
     assert np.array_equal(seg.data, want)
     F2, _ = DA.define_flags().parse(['--data_dir', str(tmp_path)])          # default model UNet-LSTM
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):                                          # ... needs the windowed forward
         DA.run(F2, stub_forward, log=lambda *_: None)
+    F3, _ = DA.define_flags().parse(['--data_dir', str(tmp_path), '--model', 'Temporal-UNet'])
+    with pytest.raises(NotImplementedError):
+        DA.run(F3, stub_forward, log=lambda *_: None)
+    F4, _ = DA.define_flags().parse(['--data_dir', str(tmp_path), '--time_step', '2'])
+    with pytest.raises(NotImplementedError):
+        DA.run(F4, stub_forward, log=lambda *_: None, cine_forward=lambda *a: None)
 
 
 def test_product_path_does_not_import_oracle():
