@@ -29,6 +29,7 @@ namespace ukbb {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // ReLU as one v_max_i32 on the bit pattern (fmaxf on an MFMA result compiles to two v_max_f32).
@@ -356,103 +357,98 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
         const int tid = threadIdx.x - 256;
         const int c4 = tid % C4, pix0 = tid / C4;
         int item = blockIdx.x, ch = 0;
-        int goff[NIT];
-        f32x4 xr[NIT], wr[NWT];
-        const float *wsrc = nullptr;
-        auto decode = [&]() {
-            const int grp = item / per_group, rest = item - grp * per_group;
-            const int n = rest / tiles, t = rest - n * tiles;
-            const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
-            const int iy0 = ty * TH * STRIDE - a.pad_y, ix0 = tx * TW * STRIDE - a.pad_x;
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int pix = pix0 + it * PSTEP;
-                const int iy = pix / IW, ix = pix % IW;
-                const int gy = iy0 + iy, gx = ix0 + ix;
-                const bool ok = pix < HP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-                goff[it] = ok ? ((n * a.H + gy) * a.W + gx) : -1;
-            }
-            wsrc = a.wpk + (size_t)grp * nchunk * (NCBL * SLAB);
-        };
-        auto load_w = [&]() {
-            const float *wp = wsrc + (size_t)ch * (NCBL * SLAB);
-#pragma unroll
-            for (int it = 0; it < NWT; ++it)
-                wr[it] = *reinterpret_cast<const f32x4 *>((it * 256 + tid < WF4) ? wp + 4 * (it * 256 + tid) : a.wpk);
-        };
-        auto store_w = [&](int b) {
-            float *ws = lds + b * BUF + HP * XS;
-#pragma unroll
-            for (int it = 0; it < NWT; ++it)
-                if (it * 256 + tid < WF4) *reinterpret_cast<f32x4 *>(ws + it * 1024 + 4 * tid) = wr[it];
-        };
-        auto store_x = [&](int b) {
-            float *xs = lds + b * BUF;
-            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int pix = pix0 + it * PSTEP;
-                if (pix < HP) *reinterpret_cast<f32x4 *>(xs + pix * XS + 4 * c4) = goff[it] < 0 ? zero4 : xr[it];
-            }
-        };
-
         if constexpr (FIRST) {
             // ---- fused first layer: raw 1-channel tile (halo of the halo) -> LDS -> conv0_0 -> xs ----
             // Stage k == item k of this workgroup (one chunk).  In the iteration after barrier #s the
             // producers (a) turn raw tile s+1 (LDS) into the KC-channel halo tile of stage s+1,
             // (b) park raw tile s+2 (registers, loaded one iteration ago) in LDS, (c) request raw tile s+3.
+            // VALU-lean like the other producers (every VALU instruction here is time taken from the MFMA
+            // waves): conv0_0 as packed FMAs (18 v_pk_fma_f32 per pixel quad), ReLU as one v_max_i32,
+            // per-thread LDS / global offsets computed once, raw pixels outside the image as out-of-range
+            // buffer loads, and the halo-validity select only in tiles that touch the image border.
             float *raw = lds + 2 * BUF;                        // [2][RP]
-            float w0q[9][4], b0q[4];
+            f32x2 w0p[9][2], b0p[2];
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const f32x4 w = *reinterpret_cast<const f32x4 *>(a.first_w + t * KC + 4 * c4);
-                w0q[t][0] = w[0]; w0q[t][1] = w[1]; w0q[t][2] = w[2]; w0q[t][3] = w[3];
+                w0p[t][0] = f32x2{w[0], w[1]}; w0p[t][1] = f32x2{w[2], w[3]};
             }
             {
                 const f32x4 b = *reinterpret_cast<const f32x4 *>(a.first_b + 4 * c4);
-                b0q[0] = b[0]; b0q[1] = b[1]; b0q[2] = b[2]; b0q[3] = b[3];
+                b0p[0] = f32x2{b[0], b[1]}; b0p[1] = f32x2{b[2], b[3]};
             }
-            float rr[NRAW];
-            bool rok[NRAW];
-            auto raw_load = [&](int it_item) {              // global -> registers (unconditional, clamped)
-                const int rest = it_item % per_group;
-                const int n = rest / tiles, t = rest - n * tiles;
-                const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
-                const int ry0 = ty * TH - a.pad_y - 1, rx0 = tx * TW - a.pad_x - 1;
+            int hy[NIT], hx[NIT], roff[NIT];                   // halo coordinates of this thread's pixels, raw-tile offsets
 #pragma unroll
-                for (int k = 0; k < NRAW; ++k) {
-                    const int idx = tid + 256 * k;
-                    const int ry = idx / RW, rx = idx - ry * RW;
-                    const int gy = ry0 + ry, gx = rx0 + rx;
-                    rok[k] = idx < RP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-                    rr[k] = a.in0[rok[k] ? ((size_t)(n * a.H + gy) * a.W + gx) : 0];
+            for (int it = 0; it < NIT; ++it) {
+                const int pix = pix0 + it * PSTEP;
+                hy[it] = pix / IW; hx[it] = pix - hy[it] * IW;
+                roff[it] = pix < HP ? hy[it] * RW + hx[it] : 0;
+            }
+            int ry_[NRAW], rx_[NRAW];
+            unsigned rvo[NRAW];
+#pragma unroll
+            for (int k = 0; k < NRAW; ++k) {
+                const int idx = tid + 256 * k;
+                ry_[k] = idx / RW; rx_[k] = idx - ry_[k] * RW;
+                rvo[k] = idx < RP ? (unsigned)(ry_[k] * a.W + rx_[k]) * 4u : 0x80000000u;
+            }
+            unsigned rr[NRAW];
+            int n_ = 0, hy0_ = 0, hx0_ = 0;                    // image and halo-tile origin of `item`
+            auto locate = [&](int it_item) {
+                const int rest = it_item % per_group;
+                n_ = rest / tiles;
+                const int t = rest - n_ * tiles;
+                const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+                hy0_ = ty * TH - a.pad_y; hx0_ = tx * TW - a.pad_x;
+            };
+            auto raw_load = [&](int it_item) {                 // global -> registers
+                locate(it_item);
+                const int ry0 = hy0_ - 1, rx0 = hx0_ - 1;
+                const float *src = a.in0 + ((long long)(n_ * a.H + ry0) * a.W + rx0);
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, 0x7fffffff, 0x00020000);
+                const int ylo = ry0 < 0 ? -ry0 : 0, yhi = a.H - ry0 < RH ? a.H - ry0 : RH;
+                const int xlo = rx0 < 0 ? -rx0 : 0, xhi = a.W - rx0 < RW ? a.W - rx0 : RW;
+                if (ylo == 0 && xlo == 0 && yhi == RH && xhi == RW) {
+#pragma unroll
+                    for (int k = 0; k < NRAW; ++k) rr[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, rvo[k], 0, 0);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NRAW; ++k) {
+                        const bool ok = (unsigned)(ry_[k] - ylo) < (unsigned)(yhi - ylo) && (unsigned)(rx_[k] - xlo) < (unsigned)(xhi - xlo);
+                        rr[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, ok ? rvo[k] : 0x80000000u, 0, 0);
+                    }
                 }
             };
             auto raw_store = [&](int b) {
 #pragma unroll
-                for (int k = 0; k < NRAW; ++k) {
-                    const int idx = tid + 256 * k;
-                    if (idx < RP) raw[b * RP + idx] = rok[k] ? rr[k] : 0.f;
-                }
+                for (int k = 0; k < NRAW; ++k)
+                    if (tid + 256 * k < RP) reinterpret_cast<unsigned *>(raw)[b * RP + tid + 256 * k] = rr[k];
             };
-            auto first_layer = [&](int braw) {              // raw tile (LDS) -> xr[] = relu(conv0_0 + b)
+            float *const xs_w = lds + pix0 * XS + 4 * c4;
+            auto first_layer = [&](int braw, int bx, int it_item) {   // raw tile (LDS) -> relu(conv0_0 + b) -> xs[bx]
+                locate(it_item);
+                // halo pixels outside the image are conv0_1's zero padding, not conv0_0 of padded input
+                const int ylo = hy0_ < 0 ? -hy0_ : 0, yhi = a.H - hy0_ < IH ? a.H - hy0_ : IH;
+                const int xlo = hx0_ < 0 ? -hx0_ : 0, xhi = a.W - hx0_ < IW ? a.W - hx0_ : IW;
+                const bool interior = ylo == 0 && xlo == 0 && yhi == IH && xhi == IW;
                 const float *rt = raw + braw * RP;
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
-                    const int pix = pix0 + it * PSTEP;
-                    const int iy = pix / IW, ix = pix % IW;
-                    const float *rp = rt + (pix < HP ? iy * RW + ix : 0);
-                    float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+                    const float *rp = rt + roff[it];
+                    f32x2 acc0 = b0p[0], acc1 = b0p[1];         // bias first: one rounding order, the same as the stand-alone kernel
 #pragma unroll
                     for (int t = 0; t < 9; ++t) {
                         const float v = rp[(t / 3) * RW + (t % 3)];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc4[j] = fmaf(v, w0q[t][j], acc4[j]);
+                        const f32x2 vv = {v, v};
+                        acc0 = __builtin_elementwise_fma(vv, w0p[t][0], acc0);
+                        acc1 = __builtin_elementwise_fma(vv, w0p[t][1], acc1);
                     }
-                    f32x4 r;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) r[j] = fmaxf(acc4[j] + b0q[j], 0.f);
-                    xr[it] = r;
+                    f32x4 r = {relu_bits(acc0[0]), relu_bits(acc0[1]), relu_bits(acc1[0]), relu_bits(acc1[1])};
+                    if (!interior) {
+                        const bool ok = (unsigned)(hy[it] - ylo) < (unsigned)(yhi - ylo) && (unsigned)(hx[it] - xlo) < (unsigned)(xhi - xlo);
+                        if (!ok) r = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                    if (pix0 + it * PSTEP < HP) *reinterpret_cast<f32x4 *>(xs_w + bx * BUF + it * PSTEP * XS) = r;
                 }
             };
             const int step = gridDim.x;
@@ -463,18 +459,29 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
             }
             // single Cout group (enforced by the launcher): this conv's weights are the same for every
             // item, so they are staged ONCE into both buffers instead of once per stage
-            decode(); load_w(); store_w(0); store_w(1);
+            {
+                const float *wp = a.wpk + (size_t)(item / per_group) * nchunk * (NCBL * SLAB);
+#pragma unroll
+                for (int it = 0; it < NWT; ++it) {
+                    const int i4 = it * 256 + tid;
+                    if (i4 < WF4) {
+                        const f32x4 w = *reinterpret_cast<const f32x4 *>(wp + 4 * i4);
+                        *reinterpret_cast<f32x4 *>(lds + HP * XS + 4 * i4) = w;
+                        *reinterpret_cast<f32x4 *>(lds + BUF + HP * XS + 4 * i4) = w;
+                    }
+                }
+            }
             __syncthreads();                                   // extra barrier: R(0) visible to all producers
             if (nstages > 0) {
-                first_layer(0); store_x(0);                    // stage 0 complete
+                first_layer(0, 0, item);                       // stage 0 complete
                 if (nstages > 1) raw_store(1);
                 if (nstages > 2) raw_load(item + 2 * step);
             }
             for (int s = 0; s < nstages; ++s) {
                 __syncthreads();                               // barrier #s
                 if (s + 1 < nstages) {
-                    item += step; decode();
-                    first_layer((s + 1) & 1); store_x((s + 1) & 1);
+                    item += step;
+                    first_layer((s + 1) & 1, (s + 1) & 1, item);
                     if (s + 2 < nstages) raw_store(s & 1);     // R(s+2) replaces R(s)
                     if (s + 3 < nstages) raw_load(item + 2 * step);
                 }
