@@ -113,13 +113,17 @@ __global__ __launch_bounds__(256) void sqg_kernel(const SqgArgs a) {
         const bool valid = q < a.npix;
         const float *xp = a.x + (valid ? q : a.npix - 1) * CIN + 4 * g;
         f32x16 S = bias_tile(a.b_s, g);
-        // k-step (j,i) pairs channels 8j+i (lanes 0-31) and 8j+4+i (lanes 32-63)
-#pragma unroll 4
+        // k-step (j,i) pairs channels 8j+i (lanes 0-31) and 8j+4+i (lanes 32-63).
+        // Levels 3-4 are small (1-2 blocks per wave): all of the block's feature loads are issued before
+        // the first MFMA so their latency is paid once, not once per group of k-steps.
+        f32x4 xv[CIN / 8];
+#pragma unroll
+        for (int j = 0; j < CIN / 8; ++j) xv[j] = ldg4(xp + 8 * j);
+#pragma unroll
         for (int j = 0; j < CIN / 8; ++j) {
-            const f32x4 xv = ldg4(xp + 8 * j);
             const f32x4 wv = ldg4(a.w_s + (j * 64 + lane) * 4);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) S = MFMA32(wv[i], xv[i], S);
+            for (int i = 0; i < 4; ++i) S = MFMA32(wv[i], xv[j][i], S);
         }
         relu16(S);
         f32x16 G0, G1;

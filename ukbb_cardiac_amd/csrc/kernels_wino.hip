@@ -276,8 +276,9 @@ __global__ __launch_bounds__(512, 2) void wino_pc_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int i = 0; i < AD; ++i) aq[i] = ld4(wbase + i * 64 * 4);
             }
-            auto chunk = [&](auto firstc, int ch) {
+            auto chunk = [&](auto firstc, auto halfc, int ch) {
                 constexpr bool FIRST = decltype(firstc)::value;
+                constexpr bool TWO = TBW == 2 && !decltype(halfc)::value;   // second 16-tile block holds real tiles
                 STAMP(c0)
                 __syncthreads();                        // barrier #s
                 STAMP(c1)
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(512, 2) void wino_pc_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int i = 0; i < BA; ++i) {
                     b0[i] = ld4(vs + i * NT * WXS);
-                    if constexpr (TBW == 2) b1[i] = ld4(vs + i * NT * WXS + 16 * WXS);
+                    if constexpr (TWO) b1[i] = ld4(vs + i * NT * WXS + 16 * WXS);
                 }
                 unroll_k<16>([&](auto kc) {
                     constexpr int k = decltype(kc)::value;
@@ -297,19 +298,19 @@ __global__ __launch_bounds__(512, 2) void wino_pc_kernel(const ConvArgs a) {
                     else                       aq[k % AD] = ld4(wn + (k + AD - 16) * 64 * 4);
                     if constexpr (k + BA < 16) {        // B operands of k+BA in flight during the MFMAs of k
                         b0[(k + BA) % BR] = ld4(vs + (k + BA) * NT * WXS);
-                        if constexpr (TBW == 2) b1[(k + BA) % BR] = ld4(vs + (k + BA) * NT * WXS + 16 * WXS);
+                        if constexpr (TWO) b1[(k + BA) % BR] = ld4(vs + (k + BA) * NT * WXS + 16 * WXS);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (FIRST) {
                         const f32x4 c0v = k == 5 ? bias : f32x4{0.f, 0.f, 0.f, 0.f};
                         acc[k][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], b0[k % BR][0], c0v, 0, 0, 0);
-                        if constexpr (TBW == 2)
+                        if constexpr (TWO)
                             acc[k][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], b1[k % BR][0], c0v, 0, 0, 0);
                     }
 #pragma unroll
                     for (int i = FIRST ? 1 : 0; i < 4; ++i) {
                         acc[k][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], b0[k % BR][i], acc[k][0], 0, 0, 0);
-                        if constexpr (TBW == 2)
+                        if constexpr (TWO)
                             acc[k][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], b1[k % BR][i], acc[k][1], 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -318,9 +319,18 @@ __global__ __launch_bounds__(512, 2) void wino_pc_kernel(const ConvArgs a) {
                 STAMP_DO(cw += c1 - c0; cc += c2 - c1;)
                 ++s;
             };
-            chunk(std::true_type{}, 0);
+            // A region whose lower two tile rows lie entirely below the image (12-row maps: rows 8-11 of the second
+            // region) has no real tile in its second 16-tile block: skip that block's MFMAs and output transform.
+            const bool half = TBW == 2 && ry * 2 * TRY + TRY >= a.Ho;
+            if (half) {
+                chunk(std::true_type{}, std::true_type{}, 0);
 #pragma unroll 1
-            for (int ch = 1; ch < nchunk; ++ch) chunk(std::false_type{}, ch);
+                for (int ch = 1; ch < nchunk; ++ch) chunk(std::false_type{}, std::true_type{}, ch);
+            } else {
+                chunk(std::true_type{}, std::false_type{}, 0);
+#pragma unroll 1
+                for (int ch = 1; ch < nchunk; ++ch) chunk(std::false_type{}, std::false_type{}, ch);
+            }
             STAMP(c2)
             // ---- output transform Y = A^T M A, bias, ReLU, NHWC stores -----------------------------
             // The packed adds below are inline asm, which the compiler's hazard recogniser does not treat as a
@@ -328,6 +338,7 @@ __global__ __launch_bounds__(512, 2) void wino_pc_kernel(const ConvArgs a) {
             asm volatile("s_nop 15" ::: "memory");
 #pragma unroll
             for (int tb = 0; tb < TBW; ++tb) {
+                if (tb == 1 && half) break;
                 const int q = (tb0 + tb) * 16 + t16;
                 const int oy = (ry * TRY + q / TRX) * 2, ox = (rx * TRX + q % TRX) * 2;
                 f32x4 t0[4], t1[4];
