@@ -82,7 +82,7 @@ struct DevBuf {
     }
 };
 
-enum OpKind { OP_FIRST, OP_CONV, OP_HEAD, OP_TCONV, OP_LOGITS, OP_SQG };
+enum OpKind { OP_FIRST, OP_CONV, OP_HEAD, OP_TCONV, OP_LOGITS, OP_SQG, OP_SQG_MULTI };
 
 struct Op {                    // one kernel launch of the plan
     OpKind kind;
@@ -92,6 +92,7 @@ struct Op {                    // one kernel launch of the plan
     int in0 = -1, in1 = -1;    // activation buffer ids (-1: network input / none)
     int out = -1;
     int sq[4] = {-1, -1, -1, -1};   // OP_HEAD: squeezed maps of levels 1..4
+    int mlayer[3] = {-1, -1, -1}, min_[3] = {-1, -1, -1}, mout[3] = {-1, -1, -1}, mh[3] = {0, 0, 0}, mw[3] = {0, 0, 0};   // OP_SQG_MULTI: levels 2..4
     bool fused_first = false;       // OP_CONV: conv0_0 (C_in = 1) evaluated by this kernel's producers
     bool on_side = false;           // launched on the handle's side stream (fork/join by events)
     int H = 0, W = 0, Ho = 0, Wo = 0, stride = 1, pad_y = 0, pad_x = 0;
@@ -464,6 +465,7 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
     // encoder (network.py:179-189 / network_ao.py:31-41)
     int cur = -1, ch = 1, cw = 1;
     std::vector<int> level_out(a.n_level), lh(a.n_level), lw(a.n_level), sqg_out(a.n_level, -1);
+    Op multi;
     int hh = H, ww = W;
     for (int l = 0; l < a.n_level; ++l) {
         for (int i = 0; i < a.n_block[l]; ++i) {
@@ -509,8 +511,18 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
             // resolution and is accounted to the head (so the per-layer sums equal Appendix A)
             op.macs_per_image = (double)lh[l] * lw[l] * a.n_filter[l] * a.same_dim;
             op.mfma_macs_per_image = (double)lh[l] * lw[l] * (a.n_filter[l] * a.same_dim + a.same_dim * a.fc);
-            h->ops.push_back(op);
             sqg_out[l] = op.out;
+            // levels 2-4 of the standard filter pyramid go out as ONE launch after level 4 (sqg_multi_kernel)
+            const bool merge = !h->use_side && a.n_level == 5 && a.n_filter[2] == 64 && a.n_filter[3] == 128 && a.n_filter[4] == 256;
+            if (merge && l >= 2) {
+                if (l == 2) { multi = Op(); multi.kind = OP_SQG_MULTI; multi.name = "sqg2-4"; multi.macs_per_image = 0; multi.mfma_macs_per_image = 0; }
+                multi.mlayer[l - 2] = op.layer; multi.min_[l - 2] = op.in0; multi.mout[l - 2] = op.out;
+                multi.mh[l - 2] = lh[l]; multi.mw[l - 2] = lw[l];
+                multi.macs_per_image += op.macs_per_image; multi.mfma_macs_per_image += op.mfma_macs_per_image;
+                if (l == 4) h->ops.push_back(multi);
+            } else {
+                h->ops.push_back(op);
+            }
         }
     }
     (void)ch; (void)cw;
@@ -699,6 +711,21 @@ int run_plan(ukbb_fcn_handle *h, const float *image, int n, float *logits, float
                 sa.out = h->act[op.out]->p;
                 sa.npix = (long long)n * op.H * op.W; sa.cin = L.cin;
                 e = launch_sqg(sa, s);
+                break;
+            }
+            case OP_SQG_MULTI: {
+                SqgArgs sa[3];
+                for (int j = 0; j < 3; ++j) {
+                    const HostLayer &L = h->layers[op.mlayer[j]];
+                    const std::string ls = std::to_string(j + 2);
+                    sa[j] = SqgArgs{};
+                    sa[j].x = h->act[op.min_[j]]->p;
+                    sa[j].w_s = dev_ptr(h, "sqg" + ls + "/w_s"); sa[j].b_s = dev_ptr(h, L.name + "/bias");
+                    sa[j].w_g = dev_ptr(h, "sqg" + ls + "/w_g");
+                    sa[j].out = h->act[op.mout[j]]->p;
+                    sa[j].npix = (long long)n * op.mh[j] * op.mw[j]; sa[j].cin = L.cin;
+                }
+                e = launch_sqg_multi(sa[0], sa[1], sa[2], s);
                 break;
             }
             case OP_HEAD: {

@@ -104,11 +104,11 @@ __device__ __forceinline__ void chain_32to32(const float *wp, int lane, const f3
 // One wave per 32 consecutive pixels of the flattened [N*H_l*W_l] map; no LDS.
 // ---------------------------------------------------------------------------
 template <int CIN>
-__global__ __launch_bounds__(256) void sqg_kernel(const SqgArgs a) {
+__device__ __forceinline__ void sqg_body(const SqgArgs &a, int vblock, int vgrid) {
     const int lane = threadIdx.x & 63;
     const int p = lane & 31, g = lane >> 5;
     const long long nblk = (a.npix + 31) >> 5;
-    for (long long blk = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); blk < nblk; blk += (long long)gridDim.x * 4) {
+    for (long long blk = (long long)vblock * 4 + (threadIdx.x >> 6); blk < nblk; blk += (long long)vgrid * 4) {
         const long long q = blk * 32 + p;
         const bool valid = q < a.npix;
         const float *xp = a.x + (valid ? q : a.npix - 1) * CIN + 4 * g;
@@ -150,12 +150,15 @@ __global__ __launch_bounds__(256) void sqg_kernel(const SqgArgs a) {
 // block before it starts the MFMA chains of the current one: loads, MFMAs and stores of different
 // blocks overlap inside a wave instead of relying on occupancy alone.
 template <int CIN>
-__global__ __launch_bounds__(256) void sqg_stream_kernel(const SqgArgs a) {
+__global__ __launch_bounds__(256) void sqg_kernel(const SqgArgs a) { sqg_body<CIN>(a, blockIdx.x, gridDim.x); }
+
+template <int CIN>
+__device__ __forceinline__ void sqg_stream_body(const SqgArgs &a, int vblock, int vgrid) {
     constexpr int NJ = CIN / 8;
     const int lane = threadIdx.x & 63;
     const int p = lane & 31, g = lane >> 5;
     const long long nblk = (a.npix + 31) >> 5;
-    const long long step = (long long)gridDim.x * 4;
+    const long long step = (long long)vgrid * 4;
     f32x4 ws[NJ], wa[4], wb[4];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) ws[j] = ldg4(a.w_s + (j * 64 + lane) * 4);
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(256) void sqg_stream_kernel(const SqgArgs a) {
     }
     const f32x16 bias = bias_tile(a.b_s, g);
     auto row = [&](long long blk) { const long long q = blk * 32 + p; return a.x + (q < a.npix ? q : a.npix - 1) * CIN + 4 * g; };
-    long long blk = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    long long blk = (long long)vblock * 4 + (threadIdx.x >> 6);
     f32x4 xn[NJ];
     if (blk < nblk) {
         const float *xp = row(blk);
@@ -212,6 +215,34 @@ __global__ __launch_bounds__(256) void sqg_stream_kernel(const SqgArgs a) {
             }
         }
     }
+}
+
+template <int CIN>
+__global__ __launch_bounds__(256) void sqg_stream_kernel(const SqgArgs a) { sqg_stream_body<CIN>(a, blockIdx.x, gridDim.x); }
+
+// Levels 2-4 in ONE launch (C_in = 64, 128, 256): together they are a tenth of level 1's work, and three
+// separate launches were dominated by launch ramp and tail (13-25 us each for 2-9 us of work).
+__global__ __launch_bounds__(256) void sqg_multi_kernel(const SqgMultiArgs m) {
+    const int b = blockIdx.x;
+    if (b < m.nb[0]) sqg_stream_body<64>(m.lv[0], b, m.nb[0]);
+    else if (b < m.nb[0] + m.nb[1]) sqg_body<128>(m.lv[1], b - m.nb[0], m.nb[1]);
+    else sqg_body<256>(m.lv[2], b - m.nb[0] - m.nb[1], m.nb[2]);
+}
+
+hipError_t launch_sqg_multi(const SqgArgs &l2, const SqgArgs &l3, const SqgArgs &l4, hipStream_t s) {
+    if (l2.cin != 64 || l3.cin != 128 || l4.cin != 256) return hipErrorInvalidValue;
+    SqgMultiArgs m;
+    const SqgArgs *lv[3] = {&l2, &l3, &l4};
+    int total = 0;
+    for (int i = 0; i < 3; ++i) {
+        m.lv[i] = *lv[i];
+        long long wg = ((lv[i]->npix + 31) / 32 + 3) / 4;
+        if (wg > 2048) wg = 2048;
+        m.nb[i] = (int)wg;
+        total += m.nb[i];
+    }
+    hipLaunchKernelGGL(sqg_multi_kernel, dim3((unsigned)total), dim3(256), 0, s, m);
+    return hipGetLastError();
 }
 
 hipError_t launch_sqg(const SqgArgs &a, hipStream_t s) {
