@@ -281,7 +281,7 @@ bool small_batch_tilings() { static const bool on = getenv("UKBB_SMALL_BATCH_TIL
 
 // A tuned tiling is reused for another image size only if its tiles still fit that size well.
 bool tile_fit_ok(const ConvConfig &c, int Ho, int Wo) {
-    const int th = c.pc == 4 ? 8 : c.th, tw = c.pc == 4 ? 16 : c.tw;
+    const int th = c.th, tw = c.tw;
     const double covered = (double)((Ho + th - 1) / th * th) * ((Wo + tw - 1) / tw * tw);
     // Winograd kept its lead over the direct tilings down to 61 % region fill (12x13 maps, r01 sweep)
     return (double)Ho * Wo >= (c.pc == 4 ? 0.5 : 0.8) * covered;
@@ -304,8 +304,25 @@ bool cfg_valid(const ConvConfig &c, int ks, int stride, int c0, int c1, int cout
     return !(cout % group || c0 % c.kc || c1 % c.kc);
 }
 
+// Winograd regions are 8x16 (ids 300/301) or 16x8 pixels (302/303): take the orientation with fewer regions.
+int wino_orient(int id, int Ho, int Wo) {
+    if (id < 300 || id > 303) return id;
+    const int base = 300 + (id & 1);
+    const long long r_8x16 = (long long)((Ho + 7) / 8) * ((Wo + 15) / 16), r_16x8 = (long long)((Ho + 15) / 16) * ((Wo + 7) / 8);
+    return r_16x8 < r_8x16 ? base + 2 : base;
+}
+
+int choose_cfg_raw(const std::string &layer, int ks, int stride, int c0, int c1, int cout, int Ho, int Wo, int N,
+                   bool fused_first, bool want_bf16);
+
 int choose_cfg(const std::string &layer, int ks, int stride, int c0, int c1, int cout, int Ho, int Wo, int N,
                bool fused_first = false, bool want_bf16 = false) {
+    const int id = choose_cfg_raw(layer, ks, stride, c0, c1, cout, Ho, Wo, N, fused_first, want_bf16);
+    return override_cfg(layer) >= 0 ? id : wino_orient(id, Ho, Wo);
+}
+
+int choose_cfg_raw(const std::string &layer, int ks, int stride, int c0, int c1, int cout, int Ho, int Wo, int N,
+                   bool fused_first, bool want_bf16) {
     if (want_bf16 && !fused_first) {          // bf16 tilings first; fall back to fp32 where none fits (e.g. Cout = 16)
             double best = 1e300; int best_id = -1;
         for (int i = 0; i < num_conv_configs(); ++i) {

@@ -63,7 +63,8 @@ size_t pack_conv_weights_bf16(const float *w, int ks, int cin, int cout, int ncb
 // thread-local error string behind ukbb_fcn_last_error() (engine.cpp)
 void set_error(const char *fmt, ...);
 
-hipError_t launch_wino(const ConvArgs &a, int ncb /*16-channel blocks per item: 4 or 2*/, hipStream_t s);
+hipError_t launch_wino(const ConvArgs &a, int ncb /*16-channel blocks per item: 4 or 2*/, int tile_rows /*4: 8x16-pixel regions, 8: 16x8*/,
+                       hipStream_t s);
 size_t pack_wino_weights(const float *w /*[3][3][cin][cout] folded*/, int cin, int cout, int ncb, float *dst /*16*cin*cout*/);
 int wino_lds_bytes();
 

@@ -803,7 +803,9 @@ static const ConvConfig g_cfgs[] = {UKBB_CONV_CONFIGS(UKBB_CFG_ENTRY) UKBB_PC_CO
                                     UKBB_PCF_CONFIGS(UKBB_PCF_ENTRY) UKBB_BF_CONFIGS(UKBB_BF_ENTRY)
                                     // Winograd F(2x2,3x3): region 4x8 tiles (8x16 px), 64 Cout per item, KC 16
                                     {300, 3, 1, 16, 8, 16, 16, 4, 1, 1, 112640, 4, "winogradF2x2_3x3_t8x16_kc16_cout64"},
-                                    {301, 3, 1, 16, 8, 16, 16, 2, 1, 1, 112640, 4, "winogradF2x2_3x3_t8x16_kc16_cout32"}};
+                                    {301, 3, 1, 16, 8, 16, 16, 2, 1, 1, 112640, 4, "winogradF2x2_3x3_t8x16_kc16_cout32"},
+                                    {302, 3, 1, 16, 16, 8, 16, 4, 1, 1, 112640, 4, "winogradF2x2_3x3_t16x8_kc16_cout64"},
+                                    {303, 3, 1, 16, 16, 8, 16, 2, 1, 1, 112640, 4, "winogradF2x2_3x3_t16x8_kc16_cout32"}};
 
 int num_conv_configs() { return (int)(sizeof(g_cfgs) / sizeof(g_cfgs[0])); }
 const ConvConfig &conv_config(int i) { return g_cfgs[i]; }
@@ -813,7 +815,7 @@ hipError_t launch_conv(int cfg_id, const ConvArgs &a, hipStream_t s) {
     for (const auto &e : g_cfgs) if (e.id == cfg_id) c = &e;
     if (!c) return hipErrorInvalidValue;
     const int group = c->mb * c->cb * c->wm;
-    if (c->pc == 4) return launch_wino(a, c->wm, s);
+    if (c->pc == 4) return launch_wino(a, c->wm, c->th / 2, s);
     if (a.in0_map) return hipErrorInvalidValue;       // image remapping exists in the Winograd kernel only
     if (c->pc == 2) {
         if (!a.first_w || !a.first_b || a.Cout != group) return hipErrorInvalidValue;

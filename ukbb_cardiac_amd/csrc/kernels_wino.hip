@@ -34,9 +34,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int TRY = 4, TRX = 8, NT = TRY * TRX;       // Winograd tiles per region (32 = two MFMA N blocks)
+constexpr int NT = 32;                                // Winograd tiles per region (two MFMA N blocks): 4 x 8 or 8 x 4 tiles
 constexpr int WKC = 16, WXS = WKC + 4;                // channels per stage, LDS pixel stride (floats)
-constexpr int WIH = 2 * TRY + 2, WIW = 2 * TRX + 2, WHP = WIH * WIW;   // raw halo tile 10 x 18
+constexpr int WHP = 180;                              // raw halo tile: 10 x 18 or 18 x 10 pixels
 constexpr int NITX = (WHP * (WKC / 4) + 255) / 256;   // staging passes of the 256 producer threads (3)
 constexpr int XSZ = NITX * (256 / (WKC / 4)) * WXS;   // floats per XS buffer: padded to 192 pixels, no tail guard
 constexpr int L_XS = 0;                               // [2][XSZ]
@@ -88,9 +88,13 @@ __device__ unsigned long long g_wstamps[8];
 // NCB = blocks of 16 output channels per item.  NCB = 4: consumer wave w owns channel block w and both
 // 16-tile halves of the region (128 MFMAs per stage); NCB = 2 (layers with 32 output channels):
 // wave w owns channel block w & 1 and tile half w >> 1 (64 MFMAs per stage).
-template <int NCB>
+// TRY x (32 / TRY) tiles per region: 4 x 8 (8 x 16 pixels) or 8 x 4 (16 x 8 pixels) -- whichever wastes less of
+// the map (48 x 52: 24 regions of 8 x 16 at 81 % fill, or 21 of 16 x 8 at 93 %).
+template <int NCB, int TRY>
 __global__ __launch_bounds__(512, 2) void wino_pc_kernel(const ConvArgs a) {
     constexpr int WNCBL = NCB, TBW = NCB == 4 ? 2 : 1;
+    constexpr int TRX = NT / TRY, WIH = 2 * TRY + 2, WIW = 2 * TRX + 2;
+    static_assert(WIH * WIW == WHP && WIH + WIW < 31, "halo tile / mask layout");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int cin = a.C0 + a.C1;
     const int nchunk = cin / WKC;
@@ -375,15 +379,16 @@ __global__ __launch_bounds__(512, 2) void wino_pc_kernel(const ConvArgs a) {
 
 int wino_lds_bytes() { return WINO_LDS_FLOATS * 4; }
 
-template <int NCB>
+template <int NCB, int TRY>
 static hipError_t launch_wino_t(const ConvArgs &a, hipStream_t s) {
+    constexpr int TRX = NT / TRY;
     if (a.Cout % (16 * NCB) || (a.C0 + a.C1) % WKC || a.C0 % WKC || a.up2) return hipErrorInvalidValue;
     static const int n_cu = [] { int v = 256; hipDeviceProp_t p; int d = 0;
                                  if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) v = p.multiProcessorCount;
                                  return v; }();
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_pc_kernel<NCB>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_pc_kernel<NCB, TRY>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, WINO_LDS_FLOATS * 4);
         if (e != hipSuccess) return e;
         attr_done = true;
@@ -396,7 +401,7 @@ static hipError_t launch_wino_t(const ConvArgs &a, hipStream_t s) {
     unsigned long long z[8] = {0};
     if (on) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wstamps), z, 64);
 #endif
-    hipLaunchKernelGGL(wino_pc_kernel<NCB>, grid, dim3(512), WINO_LDS_FLOATS * 4, s, a);
+    hipLaunchKernelGGL((wino_pc_kernel<NCB, TRY>), grid, dim3(512), WINO_LDS_FLOATS * 4, s, a);
 #ifdef UKBB_WINO_STAMPS
     if (on) {
         unsigned long long h[8];
@@ -410,8 +415,10 @@ static hipError_t launch_wino_t(const ConvArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_wino(const ConvArgs &a, int ncb, hipStream_t s) {
-    return ncb == 4 ? launch_wino_t<4>(a, s) : ncb == 2 ? launch_wino_t<2>(a, s) : hipErrorInvalidValue;
+hipError_t launch_wino(const ConvArgs &a, int ncb, int tile_rows, hipStream_t s) {
+    if (ncb == 4) return tile_rows == 8 ? launch_wino_t<4, 8>(a, s) : launch_wino_t<4, 4>(a, s);
+    if (ncb == 2) return tile_rows == 8 ? launch_wino_t<2, 8>(a, s) : launch_wino_t<2, 4>(a, s);
+    return hipErrorInvalidValue;
 }
 
 size_t pack_wino_weights(const float *w, int cin, int cout, int ncb, float *dst) {
