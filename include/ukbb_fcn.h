@@ -118,7 +118,8 @@ int ukbb_fcn_forward_host(ukbb_fcn_handle *h, const float *image, int n, int hei
  * Reference call (common/deploy_network_ao.py:171-172):
  *   prob_idx = sess.run('prob:0', {'image:0': image_idx [N,T,X,Y,1], 'training:0': False})  -> [N,T,X,Y,C]
  * forward_seq is that call: n_seq sequences of T = arch.fc frames each, frame (s, t) at image + (s*T + t)*H*W;
- * outputs in the same [N][T] order (any of logits / prob / pred may be NULL).  Device pointers, asynchronous. */
+ * outputs in the same [N][T] order (any of logits / prob / pred may be NULL).  Device pointers; asynchronous on
+ * `stream` except for the first call with a new n_seq (one blocking upload of the window index table). */
 int ukbb_fcn_forward_seq(ukbb_fcn_handle *h, const float *image, int n_seq, int height, int width,
                          float *logits, float *prob, int32_t *pred, void *stream);
 

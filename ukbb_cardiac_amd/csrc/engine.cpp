@@ -130,6 +130,7 @@ struct ukbb_fcn_handle {
     int lstm_cfg_fw = -1, lstm_cfg_bw = -1;
     const float *lstm_wpk_fw = nullptr, *lstm_wpk_bw = nullptr;
     DevBuf lstm_gates, lstm_h, lstm_c, lstm_probw, lstm_aux;   // lstm_aux: int maps / orders / double weights (raw bytes)
+    long long lstm_aux_key = -1;              // which tables lstm_aux holds (shape-keyed, uploaded once per shape)
 
     // side stream for kernels that only feed the head (sqg_l): fork after level l, join before the head
     hipStream_t side = nullptr;
@@ -1036,9 +1037,13 @@ int ukbb_fcn_forward_seq(ukbb_fcn_handle *h, const float *image, int n_seq, int 
     std::vector<int> map((size_t)T * n_seq);
     for (int k = 0; k < T; ++k)
         for (int w = 0; w < n_seq; ++w) map[(size_t)k * n_seq + w] = w * T + k;
-    HIP_TRY(h->lstm_aux.ensure((map.size() * sizeof(int) + 3) / 4), UKBB_ENOMEM);
-    HIP_TRY(hipMemcpyAsync(h->lstm_aux.p, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice, s), UKBB_EDEVICE);
-    HIP_TRY(hipStreamSynchronize(s), UKBB_EDEVICE);                          // `map` is pageable host memory
+    const long long key = ((long long)n_seq << 8) | T;                       // tables depend on (n_seq, T) only
+    if (h->lstm_aux_key != key) {                                            // first call for this shape: upload (blocking)
+        HIP_TRY(hipStreamSynchronize(s), UKBB_EDEVICE);                      // nothing in flight may still read the old tables
+        HIP_TRY(h->lstm_aux.ensure((map.size() * sizeof(int) + 3) / 4), UKBB_ENOMEM);
+        HIP_TRY(hipMemcpy(h->lstm_aux.p, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice), UKBB_EDEVICE);
+        h->lstm_aux_key = key;
+    }
     float *out = prob;
     if (!out) {                                                              // the cell kernel needs an accumulator
         HIP_TRY(h->lstm_probw.ensure((size_t)n_seq * T * HW * C), UKBB_ENOMEM);
@@ -1081,13 +1086,20 @@ int ukbb_fcn_forward_cine(ukbb_fcn_handle *h, const float *image, int n_frames, 
     const size_t b_map = map.size() * sizeof(int), b_ord = order.size() * sizeof(int);
     const size_t off_ord = (b_map + 7) / 8 * 8, off_wk = (off_ord + b_ord + 7) / 8 * 8, off_ws = off_wk + T * sizeof(double);
     const size_t total = off_ws + F * sizeof(double);
-    HIP_TRY(h->lstm_aux.ensure((total + 3) / 4), UKBB_ENOMEM);
+    long long wr_bits;
+    memcpy(&wr_bits, &weight_r, sizeof wr_bits);
+    const long long key = ((((long long)F << 8) | T) * 1000003ll) ^ wr_bits ^ (1ll << 62);   // cine tables: (F, T, weight_r)
+    if (h->lstm_aux_key != key) {                                            // first call for this shape: upload (blocking)
+        HIP_TRY(hipStreamSynchronize(s), UKBB_EDEVICE);
+        HIP_TRY(h->lstm_aux.ensure((total + 3) / 4), UKBB_ENOMEM);
+        char *aux0 = reinterpret_cast<char *>(h->lstm_aux.p);
+        HIP_TRY(hipMemcpy(aux0, map.data(), b_map, hipMemcpyHostToDevice), UKBB_EDEVICE);
+        HIP_TRY(hipMemcpy(aux0 + off_ord, order.data(), b_ord, hipMemcpyHostToDevice), UKBB_EDEVICE);
+        HIP_TRY(hipMemcpy(aux0 + off_wk, wk.data(), T * sizeof(double), hipMemcpyHostToDevice), UKBB_EDEVICE);
+        HIP_TRY(hipMemcpy(aux0 + off_ws, wsum.data(), F * sizeof(double), hipMemcpyHostToDevice), UKBB_EDEVICE);
+        h->lstm_aux_key = key;
+    }
     char *aux = reinterpret_cast<char *>(h->lstm_aux.p);
-    HIP_TRY(hipMemcpyAsync(aux, map.data(), b_map, hipMemcpyHostToDevice, s), UKBB_EDEVICE);
-    HIP_TRY(hipMemcpyAsync(aux + off_ord, order.data(), b_ord, hipMemcpyHostToDevice, s), UKBB_EDEVICE);
-    HIP_TRY(hipMemcpyAsync(aux + off_wk, wk.data(), T * sizeof(double), hipMemcpyHostToDevice, s), UKBB_EDEVICE);
-    HIP_TRY(hipMemcpyAsync(aux + off_ws, wsum.data(), F * sizeof(double), hipMemcpyHostToDevice, s), UKBB_EDEVICE);
-    HIP_TRY(hipStreamSynchronize(s), UKBB_EDEVICE);                          // tables are pageable host memory
     HIP_TRY(h->lstm_probw.ensure((size_t)T * F * HW * C), UKBB_ENOMEM);
     rc = run_bilstm(h, h->act[h->feat_buf]->p, reinterpret_cast<const int *>(aux), F, height, width,
                     h->lstm_probw.p, (long long)F * HW * C, (long long)HW * C, nullptr, nullptr, s);
