@@ -24,7 +24,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 F
 BATCH, H, W = 64, 192, 208
 
 
-def cpu_baseline(arch, params, target_seconds=20.0):
+def cpu_baseline(arch, params, target_seconds=10.0):
     """C restatement of the reference graph (oracle/fcn_oracle.c, OpenMP) timed
     on this host's cores on a bounded sample of the same workload."""
     import numpy as np
