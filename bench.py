@@ -24,29 +24,82 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 F
 BATCH, H, W = 64, 192, 208
 
 
-def cpu_baseline(arch, params, target_seconds=12.0):
-    """C restatement of the reference graph (oracle/fcn_oracle.c, OpenMP) timed
-    on this host's cores on a bounded sample of the same workload."""
-    import numpy as np
+def kernel_source_sha():
+    """Fingerprint of the kernel + engine sources: a committed PMC traffic file is only quoted when it was
+    collected from the same sources (tools/pmc_traffic.py stamps it)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'ukbb_cardiac_amd', 'csrc')
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.h', '.cpp')):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(path, kernel, batch):
+    """HBM bytes per launch of `kernel` from a rocprofv3 --pmc summary (tools/pmc_traffic.py), or (None, why).
+    A file is quoted only if it says it was collected from these very kernel sources at this batch size."""
+    import glob
+    cands = [path] if path else sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')), reverse=True)
+    sha = kernel_source_sha()
+    for c in cands:
+        try:
+            tj = json.load(open(c))
+        except Exception:
+            continue
+        if tj.get('kernel_source_sha') != sha or tj.get('batch', BATCH) != batch:
+            continue
+        hit = tj.get('engine_kernels', {}).get(kernel)
+        if hit:
+            return hit['hbm_bytes'], '%s (%s, separate rocprofv3 --pmc passes of this build, kernel_source_sha %s)' % (
+                os.path.relpath(c, ROOT), hit.get('gpu_kernel', kernel), sha)
+    return None, 'no PMC traffic file matches kernel_source_sha %s (collect with tools/run_pmc.sh)' % sha
+
+
+def _timed(fn, slices_per_call, target_seconds, max_calls):
+    fn()                                                               # warm-up: thread pool, allocator, page-in
+    calls = 0
+    t0 = time.perf_counter()
+    while True:
+        fn()
+        calls += 1
+        dt = time.perf_counter() - t0
+        if dt >= target_seconds or calls >= max_calls:
+            return slices_per_call * calls / dt, slices_per_call * calls, dt
+
+
+def cpu_baseline(arch, params, target_seconds=6.0):
+    """The CPU leg SURVEY.md 8(d) specifies, on this host's cores, on a bounded sample of the same workload:
+    the torch-CPU restatement of the reference graph (oracle/torch_oracle.py: conv / batch_norm / relu op by op,
+    fp32, torch.set_num_threads(all)) -- the stand-in for the reference's TF-CPU deploy_network.py, which cannot be
+    installed here -- timed (a) at the bench batch N = 64 and (b) in the reference's own call pattern, one
+    sess.run per frame with N = 10 slices (deploy_network.py:103-111); plus (c) the plain-C OpenMP port
+    (oracle/fcn_oracle.c) as a second figure."""
+    import torch
     from oracle import c_oracle
+    from oracle.torch_oracle import TorchFCN
     from ukbb_cardiac_amd.phantom import uniform_slices
     from ukbb_cardiac_amd.weights import pack_flat
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    net = TorchFCN(params, arch)
+    img64 = uniform_slices(BATCH, H, W, seed=1)
+    img10 = img64[:10]
+    r64, n64, t64 = _timed(lambda: net(img64), BATCH, target_seconds, 50)
+    r10, n10, t10 = _timed(lambda: net(img10), 10, target_seconds, 50)          # 50 calls = one 500-slice subject
     flat = pack_flat(arch, params)
-    img = uniform_slices(8, H, W, seed=1)
-    c_oracle.forward(arch, flat, img, want_logits=False)               # warm-up: thread pool, buffer pool, page-in
-    chunks = 0
-    t0 = time.perf_counter()
-    while True:                                                        # time-bounded sample: >= target_seconds, <= 400 batches
-        c_oracle.forward(arch, flat, img, want_logits=False)
-        chunks += 1
-        dt = time.perf_counter() - t0
-        if dt >= target_seconds or chunks >= 400:
-            break
-    n = 8 * chunks
-    return {'value': n / dt, 'unit': 'slices/s', 'cores': c_oracle.num_threads(), 'kind': 'port',
-            'sample': '%d slices of %dx%d (batches of 8) through oracle/fcn_oracle.c (fp32, OpenMP, unfused '
-                      'restatement of common/network.py build_FCN; TensorFlow itself is not installable here), '
-                      '%.1f s' % (n, H, W, dt)}
+    img8 = img64[:8]
+    rc, nc, tc = _timed(lambda: c_oracle.forward(arch, flat, img8, want_logits=False), 8, target_seconds, 400)
+    return {'value': round(r64, 2), 'unit': 'slices/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d slices of %dx%d in batches of %d through oracle/torch_oracle.py TorchFCN (torch %s CPU, fp32, '
+                      '%d threads; op-by-op restatement of common/network.py build_FCN standing in for the reference\'s '
+                      'TF-CPU graph, TensorFlow is not installable here), %.1f s' % (n64, H, W, BATCH, torch.__version__, cores, t64),
+            'reference_call_pattern': {'value': round(r10, 2), 'unit': 'slices/s',
+                                       'sample': '%d sess.run-shaped calls of N=10 slices (deploy_network.py:103-111: one call '
+                                                 'per frame, 50 per subject), same torch-CPU graph, %.1f s' % (n10 // 10, t10)},
+            'c_port': {'value': round(rc, 2), 'unit': 'slices/s', 'cores': c_oracle.num_threads(),
+                       'sample': '%d slices (batches of 8) through oracle/fcn_oracle.c (plain C, OpenMP, unfused), %.1f s' % (nc, tc)}}
 
 
 def main():
@@ -56,6 +109,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=BATCH)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--pmc-traffic', default=None,
+                    help='JSON written by tools/pmc_traffic.py (rocprofv3 --pmc passes of this build); default: the newest '
+                         'profiles/r*_pmc_traffic.json whose kernel_source_sha matches the sources in this tree')
     ap.add_argument('--no-kernel-events', action='store_true',
                     help='do not bracket kernels with HIP events in the timed region (roofline becomes null)')
     args = ap.parse_args()
@@ -143,41 +199,42 @@ def main():
         dom_avg = ms[dom] / max(cnt[dom], 1)          # measured inside the timed region
         avg = list(warm_avg)
         tf = lambda mac, t_ms: 2.0 * mac / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0
-        ach = tf(macs[dom], dom_avg)
-        traffic, traffic_src = None, None
-        try:        # HBM bytes per launch of the dominant kernel, from the committed rocprofv3 --pmc passes
-            tj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
-            if names[dom] == 'head' and n == BATCH:
-                for kname, v in tj['kernels'].items():
-                    if kname.startswith('fcn_head'):
-                        traffic, traffic_src = v['hbm_bytes'], 'profiles/r01_pmc_traffic.json (%s)' % kname
-        except Exception:
-            pass
-        roofline = {'bound': 'mfma', 'kernel': names[dom], 'achieved': round(ach, 2),
-                    'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+        issued = tf(xmacs[dom], dom_avg)              # multiplies this kernel really sends to the matrix pipe
+        credited = tf(macs[dom], dom_avg)             # reference-graph FLOPs attributed to it
+        traffic, traffic_src = pmc_traffic(args.pmc_traffic, names[dom], n)
+        roofline = {'bound': 'mfma', 'kernel': names[dom], 'achieved': round(issued, 2),
+                    'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(issued / PEAK_FP32_MFMA_TFLOPS, 4),
                     'traffic': traffic, 'traffic_source': traffic_src,
                     'avg_launch_us': round(dom_avg * 1e3, 2), 'launches_timed': int(cnt[dom]),
-                    'algorithmic_flop_per_launch': 2.0 * macs[dom],
-                    # 'achieved' credits the reference graph's FLOPs; the kernel issues fewer
-                    # multiplies (head: only the level-0 slice of the 160->64 conv at full resolution)
-                    'mfma_issued_flop_per_launch': 2.0 * xmacs[dom],
-                    'mfma_issued_frac': round(tf(xmacs[dom], dom_avg) / PEAK_FP32_MFMA_TFLOPS, 4)}
+                    # achieved / frac count the FLOPs the launch EXECUTES on the matrix pipe (= SQ_INSTS_MFMA x FLOP per
+                    # instruction in profiles/): the head runs only the level-0 slice of the 160->64 conv at full
+                    # resolution, the other four slices run at low resolution inside the sqg kernels (and are counted
+                    # there), Winograd layers run 16/36 of the direct multiplies.
+                    'flop_per_launch': 2.0 * xmacs[dom],
+                    # the same launch priced with the FLOPs of the reference graph's layers it replaces (can exceed 1;
+                    # not a utilisation)
+                    'effective_frac_reference_graph': round(credited / PEAK_FP32_MFMA_TFLOPS, 4),
+                    'reference_graph_flop_per_launch': 2.0 * macs[dom]}
         is3 = [nm.startswith('conv') and nm != 'conv0_0' for nm in names]
         t3 = sum(a for a, f in zip(avg, is3) if f)
         mac3 = sum(m for m, f in zip(macs, is3) if f)
         xmac3 = sum(m for m, f in zip(xmacs, is3) if f)
         tall = sum(avg)
         detail = {
-            'note': 'per-kernel survey from an untimed pass with all kernels bracketed by HIP events; frac = algorithmic (reference graph) FLOPs / peak, mfma_issued_frac = multiplies actually issued to the matrix pipe / peak (Winograd layers and the head run fewer than the reference graph)',
-            'conv3x3_mfma_stack': {'tflops': round(tf(mac3, t3), 2), 'frac': round(tf(mac3, t3) / PEAK_FP32_MFMA_TFLOPS, 4),
-                                   'mfma_issued_frac': round(tf(xmac3, t3) / PEAK_FP32_MFMA_TFLOPS, 4),
+            'note': 'per-kernel survey from an untimed pass with all kernels bracketed by HIP events; frac = FLOPs the kernel '
+                    'executes on the matrix pipe / peak (the utilisation); effective_frac_reference_graph = FLOPs of the '
+                    'reference-graph layers it replaces / peak (Winograd layers and the head execute fewer multiplies than '
+                    'the reference graph, so this one can exceed 1)',
+            'conv3x3_mfma_stack': {'tflops': round(tf(xmac3, t3), 2), 'frac': round(tf(xmac3, t3) / PEAK_FP32_MFMA_TFLOPS, 4),
+                                   'effective_frac_reference_graph': round(tf(mac3, t3) / PEAK_FP32_MFMA_TFLOPS, 4),
                                    'us_per_step': round(t3 * 1e3, 1)},
-            'all_kernels': {'tflops': round(tf(sum(macs), tall), 2),
-                            'frac': round(tf(sum(macs), tall) / PEAK_FP32_MFMA_TFLOPS, 4),
-                            'mfma_issued_frac': round(tf(sum(xmacs), tall) / PEAK_FP32_MFMA_TFLOPS, 4), 'us_per_step': round(tall * 1e3, 1)},
+            'all_kernels': {'tflops': round(tf(sum(xmacs), tall), 2),
+                            'frac': round(tf(sum(xmacs), tall) / PEAK_FP32_MFMA_TFLOPS, 4),
+                            'effective_frac_reference_graph': round(tf(sum(macs), tall) / PEAK_FP32_MFMA_TFLOPS, 4),
+                            'us_per_step': round(tall * 1e3, 1)},
             'per_kernel_us': {nm: round(a * 1e3, 1) for nm, a in zip(names, avg)},
-            'per_kernel_frac': {nm: round(tf(m, a) / PEAK_FP32_MFMA_TFLOPS, 3) for nm, m, a in zip(names, macs, avg)},
-            'per_kernel_mfma_issued_frac': {nm: round(tf(m, a) / PEAK_FP32_MFMA_TFLOPS, 3) for nm, m, a in zip(names, xmacs, avg)},
+            'per_kernel_frac': {nm: round(tf(m, a) / PEAK_FP32_MFMA_TFLOPS, 3) for nm, m, a in zip(names, xmacs, avg)},
+            'per_kernel_effective_frac_reference_graph': {nm: round(tf(m, a) / PEAK_FP32_MFMA_TFLOPS, 3) for nm, m, a in zip(names, macs, avg)},
         }
 
     if rank == 0:
@@ -193,8 +250,9 @@ def main():
                                    'per GPU resident in HBM, int32 label map out (BASELINE.json configs[1])' % n,
                        'slices_per_gpu_per_step': n, 'height': H, 'width': W, 'weights': 'synthetic seed 1234',
                        'parallelism': 'batch split x%d, no collectives' % world},
-            'e2e_tflops_algorithmic': round(value * flops_per_slice / 1e12, 2),
-            'e2e_frac_of_fp32_mfma_peak': round(value * flops_per_slice / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world), 4),
+            # whole step priced with the reference graph's 3.0965 GFLOP per slice: "effective", not a utilisation
+            'e2e_effective_tflops_reference_graph': round(value * flops_per_slice / 1e12, 2),
+            'e2e_effective_frac_reference_graph': round(value * flops_per_slice / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world), 4),
             'roofline': roofline,
         }
         if detail:

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define UKBB_FCN_ABI_VERSION 1
+#define UKBB_FCN_ABI_VERSION 2
 #define UKBB_FCN_MAX_LEVEL 8
 
 #define UKBB_OK 0
@@ -124,14 +124,18 @@ int ukbb_fcn_forward_seq(ukbb_fcn_handle *h, const float *image, int n_seq, int 
                          float *logits, float *prob, int32_t *pred, void *stream);
 
 /* The whole 'UNet-LSTM' branch of the reference's per-subject loop (common/deploy_network_ao.py:129-183,189)
- * for one slice position: n_frames cine frames at image[f], every frame is the centre of one circular window of
- * T frames (time_step = 1), window probabilities are tiled with the weights (1 - |k - rad|/weight_R)^weight_r
- * exactly as the reference accumulates them (float32 accumulator updated through float64, same order), then
- * prob /= weight and pred = argmax.  The U-Net features of a frame are computed once instead of once per
- * window (T times in the reference); results are identical because the U-Net acts per frame.
- * Requires 2*weight_R - 1 == arch.fc and n_frames >= arch.fc.  prob [n_frames][H][W][C], pred [n_frames][H][W]. */
+ * for one slice position: n_frames cine frames at image[f]; frames range(0, n_frames, time_step) are each the
+ * centre of one circular window of T frames (--time_step, :26,147), window probabilities are tiled with the
+ * weights (1 - |k - rad|/weight_R)^weight_r exactly as the reference accumulates them (float32 accumulator
+ * updated through float64, same order), then prob /= weight and pred = argmax.  The U-Net features of a frame
+ * are computed once instead of once per window (T times in the reference); results are identical because the
+ * U-Net acts per frame.  Reference corner cases reproduced: a frame no window reaches (time_step > window)
+ * gets prob = NaN (0/0) and pred 0; with n_frames < T a frame that occurs twice in one window receives only
+ * its LAST occurrence (numpy's `a[idx] += b` does not accumulate duplicates).
+ * Requires 2*weight_R - 1 == arch.fc, time_step >= 1 and n_frames >= (T-1)/2 (below that the reference itself
+ * raises IndexError).  prob [n_frames][H][W][C], pred [n_frames][H][W]. */
 int ukbb_fcn_forward_cine(ukbb_fcn_handle *h, const float *image, int n_frames, int height, int width,
-                          int weight_R, double weight_r, float *prob, int32_t *pred, void *stream);
+                          int weight_R, double weight_r, int time_step, float *prob, int32_t *pred, void *stream);
 
 /* ---- device-side pre/post-processing of the deploy loop ----------------
  * Stateless; device pointers; asynchronous on `stream` unless stated.  They take the host numpy work

@@ -404,6 +404,39 @@ def deploy_sequence(image, forward, seq_name='sa', seg4=False):
     return pred, orig_image, 0, pick_es_frame(pred, seq_name, seg4)
 
 
+def deploy_frame(image, forward):
+    """ED/ES mode of common/deploy_network.py:163-200 on one in-memory (X,Y[,Z]) frame: 2-D frames gain a Z axis
+    (:172-173), rescale_intensity (:179), centred zero pad to multiples of 16 (:185-188), (X2,Y2,Z) -> (Z,X2,Y2,1)
+    float32 (:191-192), ``forward(image[N,H,W,1]) -> pred[N,H,W] int32`` for the sess.run (:195-196), transpose +
+    crop (:199-200).  The result keeps TF's int32."""
+    X, Y = image.shape[:2]
+    if image.ndim == 2:
+        image = np.expand_dims(image, axis=2)
+    image = rescale_intensity(image, (1, 99))
+    X2, Y2, x_pre, x_post, y_pre, y_post = pad_to_multiple(X, Y)
+    image = np.pad(image, ((x_pre, x_post), (y_pre, y_post), (0, 0)), 'constant')
+    image = np.transpose(image, axes=(2, 0, 1)).astype(np.float32)
+    image = np.expand_dims(image, axis=-1)
+    pred = forward(image)
+    pred = np.transpose(pred, axes=(1, 2, 0))
+    return pred[x_pre:x_pre + X, y_pre:y_pre + Y]
+
+
+def aortic_deploy_frame(image, forward, z_score=True):
+    """ED/ES mode of common/deploy_network_ao.py:222-258: z-score (or rescale) normalisation (:233-236), pad to
+    multiples of 16 -- not to the fixed 256 of the sequence mode -- (:240-243), (X,Y,Z) -> (Z,X2,Y2,1) float32
+    (:247-249), ``forward`` for sess.run(['prob:0','pred:0']) (:253-254), transpose + crop (:257-258)."""
+    X, Y = image.shape[:2]
+    image = normalise_intensity(image, 10.0) if z_score else rescale_intensity(image, (1.0, 99.0))
+    X2, Y2, x_pre, x_post, y_pre, y_post = pad_to_multiple(X, Y)
+    image = np.pad(image, ((x_pre, x_post), (y_pre, y_post), (0, 0)), 'constant')
+    image = np.transpose(image, axes=(2, 0, 1)).astype(np.float32)
+    image = np.expand_dims(image, axis=-1)
+    pred = forward(image)
+    pred = np.transpose(pred, axes=(1, 2, 0))
+    return pred[x_pre:x_pre + X, y_pre:y_pre + Y]
+
+
 def aortic_window_weights(weight_R=5, weight_r=0.1):
     """common/deploy_network_ao.py:130-144."""
     time_window = weight_R * 2 - 1

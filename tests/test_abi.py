@@ -23,7 +23,8 @@ def test_every_declared_symbol_is_exported():
     for n in names:
         assert hasattr(_lib.lib, n), 'libukbb_fcn.so does not export %s' % n
     assert sorted(_lib.EXPORTS) == names
-    assert _lib.lib.ukbb_fcn_abi_version() == 1
+    hdr = open(os.path.join(ROOT, 'include', 'ukbb_fcn.h')).read()
+    assert _lib.lib.ukbb_fcn_abi_version() == int(re.search(r'#define UKBB_FCN_ABI_VERSION (\d+)', hdr).group(1)) == _lib.ABI_VERSION
 
 
 def test_weight_count_matches_python_arch():

@@ -1,0 +1,166 @@
+"""The drop-in scripts on the real engine (no stub forward): ED/ES mode of both deploy scripts against the
+oracle-driven restatement of the same loops, the per-GPU launcher with two worker processes on the one visible
+GPU (BASELINE config 4's path), and INTEGRATION.md's HipSession stub executed verbatim."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle, fcn_oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _model(tmp_path, name):
+    from ukbb_cardiac_amd.arch import MODELS
+    from ukbb_cardiac_amd.weights import pack_flat, save_blob, synthetic_params
+    arch = MODELS[name]
+    params = synthetic_params(arch, 1234)
+    mp = str(tmp_path / name)
+    save_blob(mp + '.ukbbw', arch, params)
+    return arch, params, pack_flat(arch, params), mp
+
+
+def _volume(shape, seed):
+    return (1000.0 * np.random.default_rng(seed).gamma(2.0, 1.0, size=shape)).astype(np.float32)
+
+
+def _labels_match(got, want, max_ties=2):
+    """Two fp32 evaluations of the same graph (HIP engine, C oracle) may differ only at numerical ties of the top two
+    logits: a handful of isolated pixels at most."""
+    assert got.shape == want.shape
+    assert int((got != want).sum()) <= max_ties, '%d label mismatches' % int((got != want).sum())
+
+
+# ---- ED/ES mode, common/deploy_network.py:152-216 -----------------------------------------------------
+@pytest.mark.parametrize('seq,model,seg4,shape', [('sa', 'FCN_sa', False, (162, 204, 3)), ('la_4ch', 'FCN_la_4ch_seg4', True, (150, 171)),
+                                                 ('la_2ch', 'FCN_la_2ch', False, (160, 208, 1))])
+def test_ed_es_mode_on_engine(tmp_path, seq, model, seg4, shape):
+    from ukbb_cardiac_amd import deploy_network, nifti
+    arch, params, flat, mp = _model(tmp_path, model)
+    d = tmp_path / 'data' / 'subj1'
+    d.mkdir(parents=True)
+    aff = np.diag([1.8, 1.8, 10.0, 1.0])
+    pixdim = np.array([1, 1.8, 1.8, 10.0, 1, 0, 0, 0], np.float32)
+    vols = {fr: _volume(shape, seed) for fr, seed in (('ED', 11), ('ES', 12))}
+    for fr, v in vols.items():
+        nifti.save(v, str(d / ('%s_%s.nii.gz' % (seq, fr))), aff, pixdim)
+    (tmp_path / 'data' / 'subj0_incomplete').mkdir()
+    nifti.save(vols['ED'], str(tmp_path / 'data' / 'subj0_incomplete' / ('%s_ED.nii.gz' % seq)), aff)   # ES missing -> skipped (:156-161)
+    argv = ['--seq_name', seq, '--data_dir', str(tmp_path / 'data'), '--model_path', mp, '--noprocess_seq'] + (['--seg4'] if seg4 else [])
+    deploy_network.main(argv)
+    pre = 'seg4' if seg4 else 'seg'
+    assert not os.path.exists(str(tmp_path / 'data' / 'subj0_incomplete' / ('%s_%s_ED.nii.gz' % (pre, seq))))
+    assert not os.path.exists(str(d / ('%s_%s.nii.gz' % (pre, seq))))           # no sequence output in this mode
+    for fr, v in vols.items():
+        seg = nifti.load(str(d / ('%s_%s_%s.nii.gz' % (pre, seq, fr))))
+        want = O.deploy_frame(v.copy(), lambda b: c_oracle.forward(arch, flat, b, want_logits=False)[2])
+        assert seg.data.dtype == np.int32                                        # TF's int32 straight to disk (:199-216)
+        assert seg.data.shape == (shape if len(shape) == 3 else shape + (1,))
+        _labels_match(seg.data, want)
+        assert np.array_equal(seg.header['pixdim'], pixdim) and np.allclose(seg.affine, aff)
+        assert len(np.unique(seg.data)) > 1
+
+
+# ---- aortic ED/ES mode, common/deploy_network_ao.py:201-269 (frame-wise U-Net) -------------------------
+def test_aortic_unet_ed_es_mode_on_engine(tmp_path):
+    from ukbb_cardiac_amd import deploy_network_ao, nifti
+    arch, params, flat, mp = _model(tmp_path, 'UNet_ao')
+    d = tmp_path / 'data' / 'a1'
+    d.mkdir(parents=True)
+    aff = np.diag([1.6, 1.6, 6.0, 1.0])
+    pixdim = np.array([1, 1.6, 1.6, 6.0, 1, 0, 0, 0], np.float32)
+    vols = {fr: _volume((170, 150, 1), seed) for fr, seed in (('ED', 21), ('ES', 22))}
+    for fr, v in vols.items():
+        nifti.save(v, str(d / ('ao_%s.nii.gz' % fr)), aff, pixdim)
+    deploy_network_ao.main(['--seq_name', 'ao', '--data_dir', str(tmp_path / 'data'), '--model_path', mp, '--model', 'UNet',
+                            '--noprocess_seq'])
+    for fr, v in vols.items():
+        seg = nifti.load(str(d / ('seg_ao_%s.nii.gz' % fr)))
+        want = O.aortic_deploy_frame(v.copy(), lambda b: c_oracle.forward(arch, flat, b, want_logits=False)[2])
+        assert seg.data.dtype == np.int32 and seg.data.shape == (170, 150, 1)    # padded to x16 (176x160), not to 256 (:240-243)
+        _labels_match(seg.data, want)
+        assert np.array_equal(seg.header['pixdim'], pixdim)
+    # the rescale (no z-score) branch, :235-236
+    for fr in ('ED', 'ES'):
+        os.remove(str(d / ('seg_ao_%s.nii.gz' % fr)))
+    deploy_network_ao.main(['--seq_name', 'ao', '--data_dir', str(tmp_path / 'data'), '--model_path', mp, '--model', 'UNet',
+                            '--noprocess_seq', '--noz_score'])
+    seg = nifti.load(str(d / 'seg_ao_ED.nii.gz'))
+    want = O.aortic_deploy_frame(vols['ED'].copy(), lambda b: c_oracle.forward(arch, flat, b, want_logits=False)[2], z_score=False)
+    _labels_match(seg.data, want)
+
+
+# ---- BASELINE config 4's path: the per-GPU launcher, two worker processes on the one visible GPU -------
+def _run(cmd, **kw):
+    env = dict(os.environ)
+    env['PYTHONPATH'] = ROOT + os.pathsep + env.get('PYTHONPATH', '')
+    return subprocess.run([sys.executable] + cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                          timeout=600, **kw)
+
+
+def test_two_shards_on_one_gpu_equal_single_process(tmp_path):
+    """`python -m ukbb_cardiac_amd.shard --gpus 1 --shards_per_gpu 2 -- deploy_network.py ...` over 8 synthetic
+    subjects: every subject segmented exactly once, outputs byte-identical to a single-process run over a copy of
+    the cohort, and a rerun finds everything done (deploy_network.py:62-67)."""
+    import shutil
+    from ukbb_cardiac_amd import nifti
+    arch, params, flat, mp = _model(tmp_path, 'FCN_sa')
+    a, b = tmp_path / 'cohort_sharded', tmp_path / 'cohort_single'
+    a.mkdir()
+    aff = np.diag([1.8, 1.8, 10.0, 1.0])
+    pixdim = np.array([1, 1.8, 1.8, 10.0, 0.03, 0, 0, 0], np.float32)
+    for i in range(8):
+        (a / ('subj%02d' % i)).mkdir()
+        nifti.save(_volume((100 + 4 * (i % 3), 120, 3, 5), 50 + i), str(a / ('subj%02d' % i) / 'sa.nii.gz'), aff, pixdim)
+    shutil.copytree(str(a), str(b))
+    script = os.path.join(ROOT, 'ukbb_cardiac_amd', 'deploy_network.py')
+    flags = ['--seq_name', 'sa', '--model_path', mp]
+    r = _run(['-m', 'ukbb_cardiac_amd.shard', '--gpus', '1', '--shards_per_gpu', '2', '--', script] + flags + ['--data_dir', str(a)])
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert r.stdout.count('Segmenting full sequence') == 8                       # each subject once, over both workers
+    s = _run([script] + flags + ['--data_dir', str(b)])
+    assert s.returncode == 0, s.stdout[-3000:]
+    names = ['seg_sa.nii.gz', 'sa_ED.nii.gz', 'sa_ES.nii.gz', 'seg_sa_ED.nii.gz', 'seg_sa_ES.nii.gz']
+    for i in range(8):
+        for nm in names:
+            pa, pb = a / ('subj%02d' % i) / nm, b / ('subj%02d' % i) / nm
+            assert pa.exists() and pa.read_bytes() == pb.read_bytes(), (i, nm)
+    stamp = {str(p): os.stat(str(p)).st_mtime_ns for p in a.rglob('*.nii.gz')}
+    r2 = _run(['-m', 'ukbb_cardiac_amd.shard', '--gpus', '1', '--shards_per_gpu', '2', '--', script] + flags + ['--data_dir', str(a)])
+    assert r2.returncode == 0 and 'Segmenting' not in r2.stdout                  # rerun is a no-op
+    assert stamp == {str(p): os.stat(str(p)).st_mtime_ns for p in a.rglob('*.nii.gz')}
+    # a worker that dies must fail the launcher: shard 1 is pointed at a model file that does not exist
+    (a / 'subj01' / 'seg_sa.nii.gz').unlink()
+    bad = _run(['-m', 'ukbb_cardiac_amd.shard', '--gpus', '1', '--shards_per_gpu', '2', '--', script, '--seq_name', 'sa',
+                '--model_path', str(tmp_path / 'missing_model'), '--data_dir', str(a)])
+    assert bad.returncode != 0 and 'shard' in bad.stdout
+
+
+# ---- the stub a reference maintainer would paste, executed as written ---------
+def test_integration_md_hipsession_snippet(tmp_path):
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    blocks = re.findall(r'```python\n(.*?)```', text, re.S)
+    stub = [b for b in blocks if 'class HipSession' in b]
+    assert len(stub) == 1
+    ns = {}
+    exec(compile(stub[0], 'INTEGRATION.md', 'exec'), ns)                          # verbatim
+    arch, params, flat, mp = _model(tmp_path, 'FCN_sa')
+    from ukbb_cardiac_amd import _lib
+    from ukbb_cardiac_amd.phantom import cine_phantom
+    img = cine_phantom(3, 64, 80, seed=5)
+    with ns['HipSession'](mp, lib=_lib.LIB_PATH) as sess:                         # the reference's call, deploy_network.py:110-111
+        prob, pred = sess.run(['prob:0', 'pred:0'], feed_dict={'image:0': img, 'training:0': False})
+        only = sess.run('pred:0', feed_dict={'image:0': img, 'training:0': False})
+    lg, pr, pd = c_oracle.forward(arch, flat, img, want_prob=True)
+    assert pred.dtype == np.int32 and pred.shape == (3, 64, 80) and prob.shape == (3, 64, 80, 4)
+    assert np.array_equal(only, pred)
+    _labels_match(pred, pd)
+    assert np.abs(prob - pr).max() <= 1e-4
+    with pytest.raises(RuntimeError):
+        with ns['HipSession'](mp, lib=_lib.LIB_PATH) as sess:
+            sess.run('pred:0', feed_dict={'image:0': np.zeros((1, 30, 32, 1), np.float32)})   # not a multiple of 16

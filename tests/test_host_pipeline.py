@@ -182,9 +182,19 @@ def test_aortic_deploy(tmp_path):
     F3, _ = DA.define_flags().parse(['--data_dir', str(tmp_path), '--model', 'Temporal-UNet'])
     with pytest.raises(NotImplementedError):
         DA.run(F3, stub_forward, log=lambda *_: None)
-    F4, _ = DA.define_flags().parse(['--data_dir', str(tmp_path), '--time_step', '2'])
-    with pytest.raises(NotImplementedError):
+    F4, _ = DA.define_flags().parse(['--data_dir', str(tmp_path), '--time_step', '0'])
+    with pytest.raises(ValueError):
         DA.run(F4, stub_forward, log=lambda *_: None, cine_forward=lambda *a: None)
+    # --time_step reaches the windowed forward (deploy_network_ao.py:26,147)
+    seen = []
+
+    def cine(frames, weight_R, weight_r, time_step=1):
+        seen.append((frames.shape, weight_R, weight_r, time_step))
+        return np.zeros(frames.shape + (3,), np.float32)
+    os.remove(str(d / 'seg_ao.nii.gz'))
+    F5, _ = DA.define_flags().parse(['--data_dir', str(tmp_path), '--time_step', '3', '--weight_R', '5'])
+    DA.run(F5, stub_forward, log=lambda *_: None, cine_forward=cine)
+    assert seen == [((6, 256, 256), 5, 0.1, 3)]
 
 
 def test_product_path_does_not_import_oracle():

@@ -72,13 +72,70 @@ def test_forward_cine_equals_reference_tiling_of_window_calls(model):
     np.testing.assert_array_equal(pred, np.argmax(want, -1).astype(np.int32))
 
 
+def _reference_tiling(eng, frames, time_step, weight_R=5, weight_r=0.1):
+    """deploy_network_ao.py:129-183 verbatim in numpy (fancy-indexed `+=`, float64 weights, `prob /= weight`) on an
+    un-padded (X,Y,1,T) volume, with this engine's forward_seq standing for sess.run."""
+    F, H, W = frames.shape
+    image = np.transpose(frames, (1, 2, 0))[:, :, None, :]                    # (X, Y, Z=1, T)
+    K = 2 * weight_R - 1
+    prob = np.zeros((H, W, 1, F, 3), np.float32)
+    weight = np.zeros((1, 1, 1, F, 1))
+    w = np.reshape(O.aortic_window_weights(weight_R, weight_r), (1, 1, 1, K, 1))
+    for t in range(0, F, time_step):
+        idx = O.aortic_window_indices(t, F, weight_R)
+        image_idx = np.transpose(image[:, :, :, idx], axes=(2, 3, 0, 1)).astype(np.float32)[..., None]
+        prob_idx = np.transpose(eng.run_seq(image_idx)['prob'], axes=(2, 3, 0, 1, 4))
+        prob[:, :, :, idx] += prob_idx * w
+        weight[:, :, :, idx] += w
+    with np.errstate(invalid='ignore', divide='ignore'):
+        prob /= weight
+    return np.transpose(prob[:, :, 0], (2, 0, 1, 3))                          # [F,H,W,C]
+
+
+@pytest.mark.parametrize('F,time_step', [(13, 2), (13, 3), (20, 7), (12, 10), (25, 12), (8, 1), (6, 1), (5, 2), (4, 1)])
+def test_forward_cine_time_step_and_short_cines(model, F, time_step):
+    """--time_step (deploy_network_ao.py:26,147): window centres range(0, T, time_step).  Frames no window reaches
+    divide 0/0 -> NaN probabilities and label 0, exactly as numpy gives the reference; cines shorter than the window
+    (duplicate indices inside one window) follow numpy's last-write-wins `a[idx] += b`."""
+    arch, params, eng = model
+    frames = np.random.default_rng(100 * F + time_step).standard_normal((F, 32, 32)).astype(np.float32)
+    prob, pred = eng.run_cine(frames, time_step=time_step)
+    want = _reference_tiling(eng, frames, time_step)
+    np.testing.assert_array_equal(prob, want)                                 # NaNs compare equal here
+    np.testing.assert_array_equal(pred, np.argmax(want, -1).astype(np.int32))
+    uncovered = np.isnan(want).any(axis=(1, 2, 3))
+    if (F, time_step) in ((12, 10), (25, 12)):
+        assert uncovered.any() and (pred[uncovered] == 0).all()
+    if time_step <= 9 and F >= 9:
+        assert not uncovered.any()
+
+
+def test_forward_seq_256_vs_oracle(model):
+    """The fixed aortic network input size (256 x 256, deploy_network_ao.py:105): one 9-frame window through the U-Net
+    + bidirectional ConvLSTM against the fp64 numpy restatement (network_ao.py:255-399)."""
+    arch, params, eng = model
+    from ukbb_cardiac_amd.phantom import cine_phantom
+    x = ((cine_phantom(9, 256, 256, seed=71) - 0.3) / 0.25).astype(np.float32)[None]       # [1,9,256,256,1], z-score-like range
+    out = eng.run_seq(x, want_logits=True)
+    ref = O.unet_lstm(x, params, arch.n_hidden, n_block=arch.n_block, dtype=np.float64)
+    scale = np.abs(ref).max()
+    err = np.abs(out['logits'] - ref).max()
+    assert err <= LOGIT_RTOL * scale, 'logits err %.3e vs scale %.3e' % (err, scale)
+    bad = out['pred'] != O.argmax_pred(ref)
+    assert np.all(O.top2_margin(ref)[bad] < 1e-4) and bad.sum() <= 8
+    assert np.abs(out['prob'] - O.softmax(ref)).max() < 1e-4
+    assert len(np.unique(out['pred'])) > 1
+
+
 def test_errors(model):
     from ukbb_cardiac_amd import _lib
     arch, params, eng = model
     with pytest.raises(_lib.UkbbFcnError, match='sequences'):
         eng.run(np.zeros((1, 32, 32, 1), np.float32))
-    with pytest.raises(_lib.UkbbFcnError, match='at least'):
-        eng.run_cine(np.zeros((5, 32, 32), np.float32))
+    with pytest.raises(_lib.UkbbFcnError, match='at least'):                # the reference raises IndexError here
+        eng.run_cine(np.zeros((3, 32, 32), np.float32))
+    with pytest.raises(_lib.UkbbFcnError, match='time_step'):
+        eng.run_cine(np.zeros((12, 32, 32), np.float32), time_step=0)
     with pytest.raises(_lib.UkbbFcnError, match='window'):
         eng.run_cine(np.zeros((12, 32, 32), np.float32), weight_R=4)
 

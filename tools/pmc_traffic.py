@@ -6,7 +6,13 @@ FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half the bytes o
 reads (MI355X_MICROARCH.md, HBM section), hence hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024."""
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+# GPU kernels that are exactly one launch of the engine's plan (bench.py looks its dominant kernel up by plan name)
+ENGINE_NAMES = (('fcn_head', 'head'), ('sqg_stream', 'sqg1'), ('sqg_multi', 'sqg2-4'))
 
 
 def main(path):
@@ -14,7 +20,10 @@ def main(path):
                     '--no-kernel-events --steps 3 --warmup 1` (tools/run_pmc.sh: FETCH_SIZE and WRITE_SIZE collected in '
                     'separate passes, never with --kernel-trace). Units are KB; on gfx950 FETCH_SIZE reports half the '
                     'bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM) so hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.',
-           'kernels': {}}
+           'kernels': {}, 'engine_kernels': {}}
+    from bench import BATCH, kernel_source_sha
+    out['kernel_source_sha'] = kernel_source_sha()       # bench.py quotes this file only for the same kernel sources
+    out['batch'] = BATCH
     with open(path) as fh:
         for row in csv.DictReader(fh):
             try:
@@ -22,6 +31,9 @@ def main(path):
             except (KeyError, ValueError):
                 continue
             out['kernels'][row['kernel']] = {'fetch_size_kb': f, 'write_size_kb': w, 'hbm_bytes': (2 * f + w) * 1024}
+            for prefix, plan_name in ENGINE_NAMES:
+                if row['kernel'].startswith(prefix):
+                    out['engine_kernels'][plan_name] = {'gpu_kernel': row['kernel'], 'hbm_bytes': (2 * f + w) * 1024}
     json.dump(out, sys.stdout, indent=1)
 
 

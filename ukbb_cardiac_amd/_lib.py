@@ -12,7 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libukbb_fcn.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_LEVEL = 8
 
 # every symbol include/ukbb_fcn.h declares
@@ -83,7 +83,7 @@ def _load():
     lib.ukbb_fcn_set_timing_kernel.argtypes = [vp, C.c_int]
     lib.ukbb_fcn_set_precision.argtypes = [vp, C.c_int]
     lib.ukbb_fcn_forward_seq.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
-    lib.ukbb_fcn_forward_cine.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, vp, vp, vp]
+    lib.ukbb_fcn_forward_cine.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp, vp, vp]
     lib.ukbb_fcn_select_kth.argtypes = [vp, C.c_size_t, C.POINTER(C.c_uint64), C.c_int, f32p, vp]
     lib.ukbb_fcn_rescale_pack.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                           C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]

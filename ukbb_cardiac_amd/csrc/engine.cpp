@@ -1054,41 +1054,56 @@ int ukbb_fcn_forward_seq(ukbb_fcn_handle *h, const float *image, int n_seq, int 
 }
 
 int ukbb_fcn_forward_cine(ukbb_fcn_handle *h, const float *image, int n_frames, int height, int width,
-                          int weight_R, double weight_r, float *prob, int32_t *pred, void *stream) {
+                          int weight_R, double weight_r, int time_step, float *prob, int32_t *pred, void *stream) {
     int rc = lstm_common_checks(h, image, "forward_cine");
     if (rc) return rc;
     const int T = h->arch.fc, C = h->arch.n_class, F = n_frames;
     if (!prob) { set_err("forward_cine: prob must not be NULL"); return UKBB_EINVAL; }
     if (2 * weight_R - 1 != T) { set_err("forward_cine: time window 2*weight_R-1 = %d, the model is unrolled for %d steps", 2 * weight_R - 1, T); return UKBB_EINVAL; }
-    if (F < T) { set_err("forward_cine: %d frames, need at least the window length %d", F, T); return UKBB_EINVAL; }
+    if (time_step < 1) { set_err("forward_cine: time_step must be >= 1 (got %d)", time_step); return UKBB_EINVAL; }
+    const int rad = (T - 1) / 2;
+    // the reference wraps a window index once only (i < 0: i + T; i >= T: i - T, deploy_network_ao.py:151-157):
+    // with fewer than rad frames the wrapped index is still out of range and numpy raises IndexError
+    if (F < rad || F < 1) { set_err("forward_cine: %d frames, the circular window of radius %d needs at least %d (the reference raises IndexError)", F, rad, rad > 1 ? rad : 1); return UKBB_EINVAL; }
     rc = prepare(h, F, height, width);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     rc = run_plan(h, image, F, nullptr, nullptr, nullptr, s);               // each frame's U-Net features, once
     if (rc) return rc;
     const size_t HW = (size_t)height * width;
-    const int rad = (T - 1) / 2;
+    const int Wn = (F + time_step - 1) / time_step;                         // window centres range(0, F, time_step) (:147)
     // host-side tables: window maps (deploy_network_ao.py:147-158), weights (:134-144), per-frame order + weight sums
-    std::vector<int> map((size_t)T * F), order((size_t)F * T);
+    std::vector<int> map((size_t)T * Wn), order((size_t)F * T, -1);
     std::vector<double> wk(T), wsum(F, 0.0);
     for (int k = 0; k < T; ++k) {
         const int d = k > rad ? k - rad : rad - k;
         wk[k] = d <= weight_R ? pow(1.0 - (double)d / weight_R, weight_r) : 0.0;
-        for (int w = 0; w < F; ++w) map[(size_t)k * F + w] = ((w - rad + k) % F + F) % F;
+        for (int w = 0; w < Wn; ++w) {
+            int i = w * time_step - rad + k;
+            if (i < 0) i += F; else if (i >= F) i -= F;
+            map[(size_t)k * Wn + w] = i;
+        }
     }
-    std::vector<int> cnt(F, 0);
-    for (int t = 0; t < F; ++t)                                             // the reference's loop over window centres
-        for (int k = 0; k < T; ++k) {
-            const int f = map[(size_t)k * F + t];
-            order[(size_t)f * T + cnt[f]++] = t * T + k;
+    // `prob[..., idx] += p * w` with fancy indexing (:179-180) is prob[idx] = prob[idx] + p*w: when a frame occurs
+    // more than once in a window's idx (only if F < T) the LAST occurrence wins instead of accumulating
+    // (SURVEY.md App. C.7); same for `weight[..., idx] += w`.  So per window a frame receives at most one term.
+    std::vector<int> cnt(F, 0), last(F);
+    for (int w = 0; w < Wn; ++w) {                                          // the reference's loop over window centres
+        std::fill(last.begin(), last.end(), -1);
+        for (int k = 0; k < T; ++k) last[map[(size_t)k * Wn + w]] = k;
+        for (int k = 0; k < T; ++k) {                                       // frames in idx order; the order across frames is irrelevant
+            const int f = map[(size_t)k * Wn + w];
+            if (last[f] != k) continue;
+            order[(size_t)f * T + cnt[f]++] = w * T + k;
             wsum[f] += wk[k];
         }
+    }
     const size_t b_map = map.size() * sizeof(int), b_ord = order.size() * sizeof(int);
     const size_t off_ord = (b_map + 7) / 8 * 8, off_wk = (off_ord + b_ord + 7) / 8 * 8, off_ws = off_wk + T * sizeof(double);
     const size_t total = off_ws + F * sizeof(double);
     long long wr_bits;
     memcpy(&wr_bits, &weight_r, sizeof wr_bits);
-    const long long key = ((((long long)F << 8) | T) * 1000003ll) ^ wr_bits ^ (1ll << 62);   // cine tables: (F, T, weight_r)
+    const long long key = (((((long long)F << 8) | T) * 1000003ll + time_step) * 1000003ll) ^ wr_bits ^ (1ll << 62);   // cine tables: (F, T, time_step, weight_r)
     if (h->lstm_aux_key != key) {                                            // first call for this shape: upload (blocking)
         HIP_TRY(hipStreamSynchronize(s), UKBB_EDEVICE);
         HIP_TRY(h->lstm_aux.ensure((total + 3) / 4), UKBB_ENOMEM);
@@ -1100,14 +1115,14 @@ int ukbb_fcn_forward_cine(ukbb_fcn_handle *h, const float *image, int n_frames, 
         h->lstm_aux_key = key;
     }
     char *aux = reinterpret_cast<char *>(h->lstm_aux.p);
-    HIP_TRY(h->lstm_probw.ensure((size_t)T * F * HW * C), UKBB_ENOMEM);
-    rc = run_bilstm(h, h->act[h->feat_buf]->p, reinterpret_cast<const int *>(aux), F, height, width,
-                    h->lstm_probw.p, (long long)F * HW * C, (long long)HW * C, nullptr, nullptr, s);
+    HIP_TRY(h->lstm_probw.ensure((size_t)T * Wn * HW * C), UKBB_ENOMEM);
+    rc = run_bilstm(h, h->act[h->feat_buf]->p, reinterpret_cast<const int *>(aux), Wn, height, width,
+                    h->lstm_probw.p, (long long)Wn * HW * C, (long long)HW * C, nullptr, nullptr, s);
     if (rc) return rc;
     LstmTileArgs ta{};
     ta.probw = h->lstm_probw.p; ta.order = reinterpret_cast<const int *>(aux + off_ord);
     ta.wk = reinterpret_cast<const double *>(aux + off_wk); ta.wsum = reinterpret_cast<const double *>(aux + off_ws);
-    ta.prob = prob; ta.pred = pred; ta.F = F; ta.K = T; ta.Wn = F; ta.HW = (int)HW; ta.C = C;
+    ta.prob = prob; ta.pred = pred; ta.F = F; ta.K = T; ta.Wn = Wn; ta.HW = (int)HW; ta.C = C;
     hipError_t e = launch_lstm_tile(ta, s);
     if (e != hipSuccess) { set_err("tiling kernel launch failed: %s", hipGetErrorString(e)); return UKBB_EDEVICE; }
     return UKBB_OK;

@@ -159,7 +159,7 @@ hipError_t launch_lstm_cell(const LstmCellArgs &a, hipStream_t s);
 
 struct LstmTileArgs {       // weighted tiling of the window probabilities, deploy_network_ao.py:176-183
     const float *probw;     // [K][Wn][HW][C] window probabilities (K = window length, Wn = F windows, centre t = w)
-    const int *order;       // [F][K] for frame f: the K contributing (window w, position k) pairs packed w*K + k,
+    const int *order;       // [F][K] for frame f: the <= K contributing (window w, position k) pairs packed w*K + k (-1 ends the list),
                             //        sorted the way the reference's loop over t adds them
     const double *wk;       // [K] window weights
     const double *wsum;     // [F] accumulated weight per frame

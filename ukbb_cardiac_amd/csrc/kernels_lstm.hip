@@ -93,7 +93,8 @@ __global__ __launch_bounds__(256) void lstm_cell_kernel(const LstmCellArgs a) {
     }
 }
 
-// prob[f] = (sum over the K windows containing f, in the reference's order, of probw * w_k) / wsum[f]
+// prob[f] = (sum over the <= K windows containing f, in the reference's order, of probw * w_k) / wsum[f]
+//   a frame no window reaches (time_step > window) has wsum = 0: 0/0 = NaN and argmax 0, as numpy gives the reference
 //   reference arithmetic: prob is float32, `prob[..., idx] += prob_idx * w` runs in float64 and is cast back
 //   per addition; `prob /= weight` likewise (deploy_network_ao.py:176-183).
 template <int NCLS>
@@ -107,6 +108,7 @@ __global__ __launch_bounds__(256) void lstm_tile_kernel(const LstmTileArgs a) {
         for (int k = 0; k < NCLS; ++k) acc[k] = 0.f;
         for (int j = 0; j < a.K; ++j) {
             const int wk_ = a.order[f * a.K + j];
+            if (wk_ < 0) break;                                             // fewer than K windows reach this frame (time_step > 1, F < K)
             const int w = wk_ / a.K, k = wk_ - w * a.K;
             const float *p = a.probw + (((long long)k * a.Wn + w) * a.HW + pix) * NCLS;
             const double wt = a.wk[k];

@@ -28,7 +28,7 @@ if __package__ in (None, ''):
 
 from ukbb_cardiac_amd import nifti, pipeline                       # noqa: E402
 from ukbb_cardiac_amd.flags import FlagError, FlagSet              # noqa: E402
-from ukbb_cardiac_amd.shard import shard_from_env, subjects_for_shard   # noqa: E402
+from ukbb_cardiac_amd.shard import default_device, shard_from_env, subjects_for_shard   # noqa: E402
 
 
 def define_flags():
@@ -42,7 +42,8 @@ def define_flags():
     fs.DEFINE_boolean('save_seg', True, 'Save segmentation.')
     fs.DEFINE_boolean('seg4', False, 'Segment all the 4 chambers in long-axis 4 chamber view.')
     env_idx, env_cnt = shard_from_env()
-    fs.DEFINE_integer('device', 0, 'HIP device ordinal (after HIP_VISIBLE_DEVICES).')
+    fs.DEFINE_integer('device', default_device(), 'HIP device ordinal (after HIP_VISIBLE_DEVICES); defaults to '
+                      'LOCAL_RANK under torch.distributed.run.')
     fs.DEFINE_integer('batch_slices', 128, 'Slices per forward call.')
     fs.DEFINE_boolean('device_preproc', True, 'Percentile rescale, padding, transposes and label counting on the GPU '
                       '(float32 sequences; results identical to the host path).')

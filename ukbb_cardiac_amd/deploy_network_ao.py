@@ -6,7 +6,7 @@ Command line as in ``demo_pipeline.py:116-117``.  Implemented: ``--model UNet``
 (frame-wise 2-D U-Net, ``deploy_network_ao.py:111-128``) in sequence and ED/ES
 mode, and the reference's default ``--model UNet-LSTM`` (U-Net features +
 bidirectional ConvLSTM over circular 9-frame windows with weighted tiling,
-``:129-183``) in sequence mode with ``--time_step 1``.  ``Temporal-UNet`` is not
+``:129-183``) in sequence mode, any ``--time_step``.  ``Temporal-UNet`` is not
 built and is refused with a clear message rather than silently replaced.
 
 Output: ``seg_ao.nii.gz`` int32 with the input's affine and pixdim (``:189-196``).
@@ -22,7 +22,7 @@ if __package__ in (None, ''):
 
 from ukbb_cardiac_amd import nifti, pipeline                       # noqa: E402
 from ukbb_cardiac_amd.flags import FlagError, FlagSet              # noqa: E402
-from ukbb_cardiac_amd.shard import shard_from_env, subjects_for_shard   # noqa: E402
+from ukbb_cardiac_amd.shard import default_device, shard_from_env, subjects_for_shard   # noqa: E402
 
 
 def define_flags():
@@ -40,7 +40,8 @@ def define_flags():
     fs.DEFINE_integer('weight_R', 5, 'Radius of the weighting window.')
     fs.DEFINE_float('weight_r', 0.1, 'Power of weight for the seq2seq loss. 0: uniform; 1: linear; 2: square.')
     env_idx, env_cnt = shard_from_env()
-    fs.DEFINE_integer('device', 0, 'HIP device ordinal (after HIP_VISIBLE_DEVICES).')
+    fs.DEFINE_integer('device', default_device(), 'HIP device ordinal (after HIP_VISIBLE_DEVICES); defaults to '
+                      'LOCAL_RANK under torch.distributed.run.')
     fs.DEFINE_integer('batch_slices', 64, 'Slices per forward call.')
     fs.DEFINE_integer('num_shards', env_cnt, 'Number of workers sharing data_dir.')
     fs.DEFINE_integer('shard_index', env_idx, 'This worker: subjects i with i % num_shards == shard_index.')
@@ -54,9 +55,9 @@ def run(FLAGS, forward, log=print, cine_forward=None):
     if FLAGS.model == 'UNet-LSTM':
         if cine_forward is None:
             raise ValueError('--model UNet-LSTM needs a UNet-LSTM model (cine_forward)')
-        if FLAGS.time_step != 1:
-            raise NotImplementedError('--time_step %d: only the default 1 is supported (other steps leave frames '
-                                      'uncovered when they do not divide the window)' % FLAGS.time_step)
+        if FLAGS.time_step < 1:
+            raise ValueError('--time_step %d: range(0, T, time_step) needs a positive step '
+                             '(common/deploy_network_ao.py:147)' % FLAGS.time_step)
     start_time = time.time()
     data_list = subjects_for_shard(sorted(os.listdir(FLAGS.data_dir)), FLAGS.shard_index, FLAGS.num_shards)
     processed = []
@@ -78,7 +79,8 @@ def run(FLAGS, forward, log=print, cine_forward=None):
             log('  Segmenting full sequence ...')
             t0 = time.time()
             if FLAGS.model == 'UNet-LSTM':
-                prob = pipeline.aortic_lstm_prob_sequence(image, cine_forward, FLAGS.z_score, FLAGS.weight_R, FLAGS.weight_r)
+                prob = pipeline.aortic_lstm_prob_sequence(image, cine_forward, FLAGS.z_score, FLAGS.weight_R, FLAGS.weight_r,
+                                                          time_step=FLAGS.time_step)
             else:
                 prob = pipeline.aortic_prob_sequence(image, forward, FLAGS.z_score, FLAGS.batch_slices)
             pred = np.argmax(prob, axis=-1).astype(np.int32)          # host argmax, as :189
@@ -136,8 +138,8 @@ def main(argv=None):
             prob, pred = sess.run(['prob:0', 'pred:0'], feed_dict={'image:0': batch, 'training:0': False})
             return {'prob': prob, 'pred': pred}
 
-        def cine_forward(frames, weight_R, weight_r):
-            return sess.engine.run_cine(frames, weight_R, weight_r)[0]
+        def cine_forward(frames, weight_R, weight_r, time_step=1):
+            return sess.engine.run_cine(frames, weight_R, weight_r, time_step)[0]
         run(FLAGS, forward, cine_forward=cine_forward)
 
 

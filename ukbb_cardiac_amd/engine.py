@@ -123,10 +123,10 @@ class Engine:
             out['pred'] = pd.cpu().numpy()
         return out
 
-    def run_cine(self, frames: np.ndarray, weight_R: int = 5, weight_r: float = 0.1):
+    def run_cine(self, frames: np.ndarray, weight_R: int = 5, weight_r: float = 0.1, time_step: int = 1):
         """One slice position of the 'UNet-LSTM' branch of common/deploy_network_ao.py:129-183,189: frames float32
-        [F,H,W] (normalised, padded) -> (prob [F,H,W,C] float32, pred [F,H,W] int32), circular windows tiled on
-        the device; the U-Net features of each frame are computed once."""
+        [F,H,W] (normalised, padded) -> (prob [F,H,W,C] float32, pred [F,H,W] int32), circular windows centred
+        on frames range(0, F, time_step) tiled on the device; the U-Net features of each frame are computed once."""
         import torch
         x = np.ascontiguousarray(frames, dtype=np.float32)
         if x.ndim != 3:
@@ -137,7 +137,7 @@ class Engine:
         xd = torch.from_numpy(x).to(dev)
         pr = torch.empty((f, h, w, self.arch.n_class), dtype=torch.float32, device=dev)
         pd = torch.empty((f, h, w), dtype=torch.int32, device=dev)
-        rc = _lib.lib.ukbb_fcn_forward_cine(self._h, C.c_void_p(xd.data_ptr()), f, h, w, int(weight_R), float(weight_r),
+        rc = _lib.lib.ukbb_fcn_forward_cine(self._h, C.c_void_p(xd.data_ptr()), f, h, w, int(weight_R), float(weight_r), int(time_step),
                                             C.c_void_p(pr.data_ptr()), C.c_void_p(pd.data_ptr()), C.c_void_p(stream or None))
         _lib.check(rc, 'ukbb_fcn_forward_cine')
         return pr.cpu().numpy(), pd.cpu().numpy()

@@ -39,8 +39,32 @@ class NiftiImage:
         return self.data
 
 
+GZIP_LEVEL = 1        # nibabel's Opener default (default_compresslevel = 1): the files the reference writes use it
+
+
+class _GzWriter:
+    """gzip stream without file name and timestamp in its header: the same volume always gives the same bytes, so
+    outputs of different workers / reruns can be compared with cmp."""
+
+    def __init__(self, path):
+        self._raw = open(path, 'wb')
+        self._gz = gzip.GzipFile(filename='', mode='wb', compresslevel=GZIP_LEVEL, fileobj=self._raw, mtime=0)
+
+    def write(self, b):
+        return self._gz.write(b)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self._gz.close()
+        self._raw.close()
+
+
 def _open(path, mode):
-    return gzip.open(path, mode) if str(path).endswith('.gz') else open(path, mode)
+    if not str(path).endswith('.gz'):
+        return open(path, mode)
+    return _GzWriter(path) if 'w' in mode else gzip.open(path, mode)
 
 
 def _quat_affine(b, c, d, qx, qy, qz, pixdim):

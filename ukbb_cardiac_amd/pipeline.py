@@ -115,10 +115,11 @@ def aortic_segment_frame(image, forward, z_score=True, batch_slices=128):
     return np.transpose(lab, (1, 2, 0))[x_pre:x_pre + X, y_pre:y_pre + Y].astype(np.int32)
 
 
-def aortic_lstm_prob_sequence(image, cine_forward, z_score=True, weight_R=5, weight_r=0.1, n_class=3):
+def aortic_lstm_prob_sequence(image, cine_forward, z_score=True, weight_R=5, weight_r=0.1, n_class=3, time_step=1):
     """'UNet-LSTM' branch of deploy_network_ao.py:92-107,129-183: (X,Y,Z,T) aortic cine -> float32 probabilities
-    (X,Y,Z,T,n_class).  ``cine_forward(frames[F,256,256]) -> prob[F,256,256,C]`` performs the circular
-    9-frame windows and their weighted tiling for one slice position (``Engine.run_cine``: the U-Net features of
+    (X,Y,Z,T,n_class).  ``cine_forward(frames[F,256,256], weight_R, weight_r[, time_step]) -> prob[F,256,256,C]``
+    performs the circular 9-frame windows centred on frames range(0, T, time_step) (:147) and their weighted tiling
+    for one slice position (``Engine.run_cine``: the U-Net features of
     a frame are computed once instead of once per window, results identical)."""
     X, Y, Z, T = image.shape
     norm = normalise_intensity(image, 10.0) if z_score else rescale_intensity(image, (1.0, 99.0))
@@ -127,6 +128,6 @@ def aortic_lstm_prob_sequence(image, cine_forward, z_score=True, weight_R=5, wei
     prob = np.zeros((X, Y, Z, T, n_class), dtype=np.float32)
     for z in range(Z):                                   # the reference batches Z inside sess.run; slices are independent
         frames = np.transpose(padded[:, :, z, :], (2, 0, 1)).astype(np.float32)
-        pr = cine_forward(frames, weight_R, weight_r)
+        pr = cine_forward(frames, weight_R, weight_r) if time_step == 1 else cine_forward(frames, weight_R, weight_r, time_step)
         prob[:, :, z] = np.transpose(pr, (1, 2, 0, 3))[x_pre:x_pre + X, y_pre:y_pre + Y]
     return prob
