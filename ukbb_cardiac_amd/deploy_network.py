@@ -86,7 +86,7 @@ def run(FLAGS, forward, log=print, engine=None):
             t0 = time.time()
             on_device = engine is not None and getattr(FLAGS, 'device_preproc', False) and image.dtype == np.float32
             if on_device:
-                from . import device_pipeline
+                from ukbb_cardiac_amd import device_pipeline
                 pred, aux = device_pipeline.segment_sequence_device(image, engine, FLAGS.batch_slices, return_aux=True)
             else:
                 pred = pipeline.segment_sequence(image, forward, FLAGS.batch_slices)   # clips `image` in place
