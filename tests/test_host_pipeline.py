@@ -242,3 +242,73 @@ def test_aortic_lstm_sequence_vs_oracle_loop():
     want = O.aortic_lstm_prob_sequence(normalise_intensity(image.copy(), 10.0), forward_seq)
     assert got.shape == (X, Y, Z, T, 3) and got.dtype == np.float32
     np.testing.assert_array_equal(got, want)
+
+
+def test_rescale_numpy1_casting_is_float32_arithmetic_within_one_ulp():
+    """numpy 1.x (the reference's era) keeps float32_array - float64_scalar in float32; numpy 2 (this image,
+    the goldens) computes in float64.  The opt-in variant reproduces the former; both clip identically."""
+    from ukbb_cardiac_amd.image_utils import rescale_intensity
+    v = make_volume((40, 36, 3, 4), 9)
+    a, b = v.copy(), v.copy()
+    r2 = rescale_intensity(a, (1, 99))
+    r1 = rescale_intensity(b, (1, 99), numpy1_casting=True)
+    assert r1.dtype == np.float32 and r2.dtype == np.float64 and np.array_equal(a, b)
+    lo, hi = np.percentile(v, (1, 99))
+    want = (b.astype(np.float32) - np.float32(lo)) / np.float32(hi - lo)      # all-float32 evaluation
+    assert np.array_equal(r1, want)
+    d = np.abs(r1.astype(np.float64) - r2.astype(np.float32))
+    assert d.max() <= 2 * np.spacing(np.float32(1.0)) and (r1 != r2.astype(np.float32)).any()
+    # the deploy loop accepts the switch and then stays on the host path
+    p2 = pipeline.segment_sequence(v.copy(), stub_forward, numpy1_casting=True)
+    assert p2.shape == v.shape
+
+
+# NIfTI-1 header layout (nifti1.h of the NIfTI-1.1 standard): name -> (byte offset, struct format).  nibabel, which every
+# evaluation script of the reference uses to read our outputs (short_axis/eval_ventricular_volume.py:40-52,
+# aortic/eval_aortic_area.py:52-66), parses exactly this table; it is absent from this image, so the files are pinned
+# against the standard itself.
+NIFTI1_FIELDS = {
+    'sizeof_hdr': (0, '<i'), 'dim_info': (39, '<b'), 'dim': (40, '<8h'), 'intent_code': (68, '<h'), 'datatype': (70, '<h'),
+    'bitpix': (72, '<h'), 'slice_start': (74, '<h'), 'pixdim': (76, '<8f'), 'vox_offset': (108, '<f'), 'scl_slope': (112, '<f'),
+    'scl_inter': (116, '<f'), 'slice_end': (120, '<h'), 'slice_code': (122, '<b'), 'xyzt_units': (123, '<b'),
+    'cal_max': (124, '<f'), 'cal_min': (128, '<f'), 'descrip': (148, '<80s'), 'aux_file': (228, '<24s'),
+    'qform_code': (252, '<h'), 'sform_code': (254, '<h'), 'quatern_b': (256, '<f'), 'qoffset_x': (268, '<f'),
+    'srow_x': (280, '<4f'), 'srow_y': (296, '<4f'), 'srow_z': (312, '<4f'), 'intent_name': (328, '<16s'), 'magic': (344, '<4s'),
+}
+NIFTI1_DATATYPES = {np.uint8: (2, 8), np.int16: (4, 16), np.int32: (8, 32), np.float32: (16, 32), np.float64: (64, 64)}
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.int32, np.float32, np.uint8, np.int16])
+def test_nifti_header_matches_the_nifti1_field_table(tmp_path, dtype):
+    """The three label-map flavours the deploy scripts write (float64 sequence volumes, int32 ED/ES + aortic,
+    float32 image frames) field by field against the standard's table."""
+    data = (np.arange(5 * 4 * 3 * 2).reshape(5, 4, 3, 2) % 4).astype(dtype)
+    affine = np.array([[-1.8, 0.0, 0.1, 90.0], [0.0, 1.8, 0.2, -80.0], [0.05, 0.0, 10.0, 12.0], [0, 0, 0, 1]])
+    pixdim = np.array([-1, 1.8, 1.8, 10.0, 0.03, 0, 0, 0], np.float32)
+    p = str(tmp_path / 'f.nii.gz')
+    nifti.save(data, p, affine, pixdim)
+    raw = gzip.open(p, 'rb').read()
+    f = {k: struct.unpack_from(fmt, raw, off) for k, (off, fmt) in NIFTI1_FIELDS.items()}
+    assert f['sizeof_hdr'] == (348,) and f['magic'] == (b'n+1\x00',)            # single-file NIfTI-1
+    assert f['dim'] == (4, 5, 4, 3, 2, 1, 1, 1)                                   # unused dims are 1, as the standard asks
+    assert (f['datatype'][0], f['bitpix'][0]) == NIFTI1_DATATYPES[dtype]
+    assert f['vox_offset'] == (352.0,) and len(raw) == 352 + data.nbytes          # 348 + 4 extension-flag bytes, all zero
+    assert raw[348:352] == b'\x00\x00\x00\x00'
+    assert np.allclose(f['pixdim'], pixdim)                                       # the reference copies the input's pixdim (:142)
+    assert f['scl_slope'] == (1.0,) and f['scl_inter'] == (0.0,)                  # stored values are the values
+    assert f['sform_code'] == (2,) and f['qform_code'] == (0,)                    # nibabel's Nifti1Image(data, affine): sform 'aligned', qform 'unknown'
+    assert np.allclose(f['srow_x'] + f['srow_y'] + f['srow_z'], affine[:3].ravel(), atol=1e-6)
+    assert f['intent_code'] == (0,) and f['slice_code'] == (0,) and f['dim_info'] == (0,)
+    vox = np.frombuffer(raw, np.dtype(dtype).newbyteorder('<'), offset=352).reshape(data.shape, order='F')   # x fastest
+    assert np.array_equal(vox, data)
+    # and the reader takes the same table: a header assembled from the table alone round-trips
+    hdr = bytearray(348)
+    for k, v in (('sizeof_hdr', (348,)), ('dim', (3, 2, 3, 4, 1, 1, 1, 1)), ('datatype', (16,)), ('bitpix', (32,)),
+                 ('pixdim', (1, 2, 3, 4, 0, 0, 0, 0)), ('vox_offset', (352,)), ('scl_slope', (0.0,)), ('sform_code', (1,)),
+                 ('srow_x', (2, 0, 0, -5)), ('srow_y', (0, 3, 0, -6)), ('srow_z', (0, 0, 4, -7)), ('magic', (b'n+1\x00',))):
+        struct.pack_into(NIFTI1_FIELDS[k][1], hdr, NIFTI1_FIELDS[k][0], *v)
+    vol = np.arange(24, dtype=np.float32).reshape(2, 3, 4)
+    q = str(tmp_path / 'g.nii')
+    open(q, 'wb').write(bytes(hdr) + b'\0' * 4 + vol.tobytes(order='F'))
+    im = nifti.load(q)
+    assert np.array_equal(im.data, vol) and np.allclose(im.affine, [[2, 0, 0, -5], [0, 3, 0, -6], [0, 0, 4, -7], [0, 0, 0, 1]])

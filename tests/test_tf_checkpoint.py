@@ -127,3 +127,29 @@ def test_missing_variable_and_wrong_shape(tmp_path):
     with pytest.raises(tfc.CheckpointError):                              # a 4-class checkpoint asked to be a 2-class model
         write_checkpoint(prefix, _tf_tensors(arch, params, with_slots=False), tensor_crc=False)
         tfc.checkpoint_to_params(prefix, MODELS['FCN_la_2ch'])
+
+
+@pytest.mark.parametrize('cell', ['conv_lstm_cell', 'conv_2d_lstm_cell', 'Conv2DLSTMCell'])
+def test_lstm_cell_scope_is_matched_not_assumed(tmp_path, cell):
+    """network_ao.py:277,290 instantiate tf.contrib.rnn.Conv2DLSTMCell; which scope name its variables get depends on
+    the TF 1.x release (`conv_lstm_cell` vs `conv_2d_lstm_cell`).  The importer takes whatever single scope sits below
+    LSTM/<direction>/ with a kernel + biases, and is not confused by optimizer slots of those variables."""
+    arch = MODELS['UNet-LSTM_ao']
+    params = synthetic_params(arch, 11)
+    t = _tf_tensors(arch, params)
+    for old in [n for n in t if '/conv_lstm_cell/' in n]:
+        t[old.replace('/conv_lstm_cell/', '/%s/' % cell)] = t.pop(old)
+    for d in ('forward', 'backward'):
+        for v in ('kernel', 'biases'):
+            t['LSTM/%s/%s/%s/Adam' % (d, cell, v)] = np.zeros_like(t['LSTM/%s/%s/%s' % (d, cell, v)])
+    prefix = str(tmp_path / 'UNet-LSTM_ao')
+    write_checkpoint(prefix, t, tensor_crc=False)
+    arch2, params2 = tfc.checkpoint_to_params(prefix)
+    assert arch2 == arch
+    np.testing.assert_array_equal(pack_flat(arch2, params2), pack_flat(arch, params))
+    # two candidate cells in one direction: refuse rather than guess
+    t['LSTM/forward/other_cell/kernel'] = t['LSTM/forward/%s/kernel' % cell]
+    t['LSTM/forward/other_cell/biases'] = t['LSTM/forward/%s/biases' % cell]
+    write_checkpoint(prefix, t, tensor_crc=False)
+    with pytest.raises(tfc.CheckpointError, match='one cell scope'):
+        tfc.checkpoint_to_params(prefix)

@@ -47,6 +47,8 @@ def define_flags():
     fs.DEFINE_integer('batch_slices', 128, 'Slices per forward call.')
     fs.DEFINE_boolean('device_preproc', True, 'Percentile rescale, padding, transposes and label counting on the GPU '
                       '(float32 sequences; results identical to the host path).')
+    fs.DEFINE_boolean('numpy1_casting', False, 'Rescale intensities with the float32 arithmetic numpy 1.x used when the reference '
+                      'was written (1 ulp from numpy 2; host pre-processing only; INTEGRATION.md section 5).')
     fs.DEFINE_integer('num_shards', env_cnt, 'Number of workers sharing data_dir.')
     fs.DEFINE_integer('shard_index', env_idx, 'This worker: subjects i with i % num_shards == shard_index.')
     return fs
@@ -84,12 +86,13 @@ def run(FLAGS, forward, log=print, engine=None):
                 continue
             log('  Segmenting full sequence ...')
             t0 = time.time()
-            on_device = engine is not None and getattr(FLAGS, 'device_preproc', False) and image.dtype == np.float32
+            np1 = bool(getattr(FLAGS, 'numpy1_casting', False))
+            on_device = engine is not None and getattr(FLAGS, 'device_preproc', False) and image.dtype == np.float32 and not np1
             if on_device:
                 from ukbb_cardiac_amd import device_pipeline
                 pred, aux = device_pipeline.segment_sequence_device(image, engine, FLAGS.batch_slices, return_aux=True)
             else:
-                pred = pipeline.segment_sequence(image, forward, FLAGS.batch_slices)   # clips `image` in place
+                pred = pipeline.segment_sequence(image, forward, FLAGS.batch_slices, np1)   # clips `image` in place
             seg_time = time.time() - t0
             log('  Segmentation time = {:3f}s'.format(seg_time))
             table_time.append(seg_time)
@@ -120,7 +123,7 @@ def run(FLAGS, forward, log=print, engine=None):
                 image = nim.get_data()
                 log('  Segmenting {} frame ...'.format(fr))
                 t0 = time.time()
-                pred = pipeline.segment_frame(image, forward, FLAGS.batch_slices)
+                pred = pipeline.segment_frame(image, forward, FLAGS.batch_slices, bool(getattr(FLAGS, 'numpy1_casting', False)))
                 seg_time = time.time() - t0
                 log('  Segmentation time = {:3f}s'.format(seg_time))
                 table_time.append(seg_time)

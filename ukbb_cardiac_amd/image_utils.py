@@ -9,9 +9,18 @@ function bodies) pin bit-for-bit.
 import numpy as np
 
 
-def rescale_intensity(image, thres=(1.0, 99.0)):
+def rescale_intensity(image, thres=(1.0, 99.0), numpy1_casting=False):
     """Clip to the [thres[0], thres[1]] percentiles of the WHOLE array and map
     to [0, 1].
+
+    ``numpy1_casting``: the reference was written for numpy 1.x, whose value-based
+    casting keeps ``float32_array - float64_scalar`` in float32 (the scalar is
+    rounded to float32 first) and divides by the float64 difference of the two
+    percentile scalars rounded to float32.  numpy >= 2 (NEP 50, this image, and
+    what the committed goldens pin) does the same arithmetic in float64 and
+    rounds once, which can differ by 1 ulp in the network input.  Set it to
+    compare label maps against a run of the real TF / numpy-1.x deployment
+    (INTEGRATION.md section 5); the result is then float32.
 
     Quirks kept on purpose: the clip is applied IN
     PLACE to the caller's array (the reference's ``image2 = image`` aliases it,
@@ -24,6 +33,8 @@ def rescale_intensity(image, thres=(1.0, 99.0)):
     image[image < val_l] = val_l
     image[image > val_h] = val_h
     lo, hi = np.float64(val_l), np.float64(val_h)
+    if numpy1_casting:
+        return (image.astype(np.float32) - np.float32(lo)) / np.float32(hi - lo)
     return (image.astype(np.float32).astype(np.float64) - lo) / (hi - lo)
 
 

@@ -46,14 +46,14 @@ def _run_slices(slices, forward, batch_slices, want):
     return {k: np.concatenate(v, axis=0) if len(v) > 1 else v[0] for k, v in outs.items()}
 
 
-def segment_sequence(image, forward, batch_slices=128):
+def segment_sequence(image, forward, batch_slices=128, numpy1_casting=False):
     """(X,Y,Z,T) volume -> float64 label volume of the same shape
     (deploy_network.py:86-116; the float64 dtype is the reference's, :92).
     ``image`` is clipped IN PLACE by rescale_intensity, as in the reference."""
     if image.ndim != 4:
         raise ValueError('expected a 4-D (X,Y,Z,T) sequence, got shape %s' % (image.shape,))
     X, Y, Z, T = image.shape
-    scaled = rescale_intensity(image, (1, 99))
+    scaled = rescale_intensity(image, (1, 99), numpy1_casting)
     X2, Y2, x_pre, x_post, y_pre, y_post = pad_amounts(X, Y)
     padded = np.pad(scaled, ((x_pre, x_post), (y_pre, y_post), (0, 0), (0, 0)), 'constant')
     slices = np.transpose(padded, (3, 2, 0, 1)).reshape(T * Z, X2, Y2).astype(np.float32)
@@ -64,12 +64,12 @@ def segment_sequence(image, forward, batch_slices=128):
     return pred
 
 
-def segment_frame(image, forward, batch_slices=128):
+def segment_frame(image, forward, batch_slices=128, numpy1_casting=False):
     """(X,Y[,Z]) ED or ES frame -> int32 label volume (deploy_network.py:171-200)."""
     if image.ndim == 2:
         image = np.expand_dims(image, axis=2)
     X, Y = image.shape[:2]
-    scaled = rescale_intensity(image, (1, 99))
+    scaled = rescale_intensity(image, (1, 99), numpy1_casting)
     X2, Y2, x_pre, x_post, y_pre, y_post = pad_amounts(X, Y)
     padded = np.pad(scaled, ((x_pre, x_post), (y_pre, y_post), (0, 0)), 'constant')
     slices = np.transpose(padded, (2, 0, 1)).astype(np.float32)

@@ -29,6 +29,7 @@ in every scope **[TF-recall]**.  Optimizer slots (``.../Adam``, ``.../Adam_1``, 
 and ``global_step`` are ignored.
 """
 import os
+import re
 import struct
 from collections import OrderedDict
 from typing import Dict, List, Optional, Tuple
@@ -307,8 +308,31 @@ def _numbered(base: str, k: int) -> str:
 _BN_KEYS = (('gamma', 'gamma'), ('beta', 'beta'), ('mean', 'moving_mean'), ('var', 'moving_variance'))
 
 
-def variable_names(arch: ModelArch) -> "OrderedDict[str, Dict[str, str]]":
-    """layer name (arch.layer_specs order) -> {'kernel': tf name, 'gamma': ..., ...}."""
+_LSTM_VAR = re.compile(r'^LSTM/(forward|backward)/([^/]+)/(kernel|biases|bias)$')
+LSTM_CELL_DEFAULT = 'conv_lstm_cell'
+
+
+def lstm_cell_variables(names, direction: str) -> Dict[str, str]:
+    """{'kernel': ..., 'bias': ...} of the ConvLSTM cell created under variable_scope('LSTM') / (direction)
+    (network_ao.py:270-295).  The cell's own scope is whatever name TF gave the cell object -- ``conv_lstm_cell`` for
+    ConvLSTMCell, ``conv_2d_lstm_cell`` for the Conv2DLSTMCell subclass the reference instantiates (:277,:290), depending
+    on the TF 1.x release -- so it is matched, not assumed: the single scope below LSTM/<direction>/ that holds a
+    ``kernel`` and a ``biases`` (or ``bias``) variable.  Optimizer slots (``.../kernel/Adam``) have one more path
+    component and never match."""
+    found: Dict[str, Dict[str, str]] = {}
+    for n in names:
+        m = _LSTM_VAR.match(n)
+        if m and m.group(1) == direction:
+            found.setdefault(m.group(2), {})['kernel' if m.group(3) == 'kernel' else 'bias'] = n
+    full = {cell: d for cell, d in found.items() if 'kernel' in d and 'bias' in d}
+    if len(full) != 1:
+        raise CheckpointError('LSTM/%s: expected one cell scope with kernel + biases, found %s' % (direction, sorted(found) or 'none'))
+    return next(iter(full.values()))
+
+
+def variable_names(arch: ModelArch, available=None) -> "OrderedDict[str, Dict[str, str]]":
+    """layer name (arch.layer_specs order) -> {'kernel': tf name, 'gamma': ..., ...}.  ``available`` (the names in a
+    checkpoint) lets the ConvLSTM cell scope be matched instead of assumed."""
     out: "OrderedDict[str, Dict[str, str]]" = OrderedDict()
     if arch.kind == KIND_FCN:
         nconv = nbn = 0
@@ -333,9 +357,13 @@ def variable_names(arch: ModelArch) -> "OrderedDict[str, Dict[str, str]]":
     for s in arch.layer_specs():
         if s.name in ('lstm_fw', 'lstm_bw'):
             # tf.contrib.rnn.Conv2DLSTMCell under variable_scope('LSTM') / ('forward' | 'backward')
-            # (network_ao.py:270-295) [TF-recall: the cell's default scope name and its `kernel` / `biases` names]
-            base = 'LSTM/%s/conv_lstm_cell' % ('forward' if s.name == 'lstm_fw' else 'backward')
-            out[s.name] = {'kernel': base + '/kernel', 'bias': base + '/biases'}
+            # (network_ao.py:270-295) [TF-recall: the cell's scope name and its `kernel` / `biases` names]
+            direction = 'forward' if s.name == 'lstm_fw' else 'backward'
+            if available is not None:
+                out[s.name] = lstm_cell_variables(available, direction)
+            else:
+                base = 'LSTM/%s/%s' % (direction, LSTM_CELL_DEFAULT)
+                out[s.name] = {'kernel': base + '/kernel', 'bias': base + '/biases'}
             continue
         if s.name == 'lstm_out':
             out[s.name] = {'kernel': 'LSTM/output/conv2d/kernel', 'bias': 'LSTM/output/conv2d/bias'}   # :298-309
@@ -372,13 +400,13 @@ def infer_arch(reader: CheckpointReader) -> ModelArch:
             n_filter.append(reader.shape('UNet/conv%d/conv2d/kernel' % l)[3])
             n_block.append(k)
             l += 1
-        lstm = 'LSTM/forward/conv_lstm_cell/kernel' in names
+        lstm = any(_LSTM_VAR.match(n) for n in names)
         if not n_filter or (not lstm and 'UNet/conv_out/conv2d/kernel' not in names):
             raise CheckpointError('UNet checkpoint without the expected UNet/conv{l}/conv2d variables')
         if lstm:
             # the unrolled step count is not recoverable from the variables: the released model is trained with a
             # 9-frame window (model name ...tw9_h16_bidir..., deploy_network_ao.py:36-38,130)
-            n_hidden = reader.shape('LSTM/forward/conv_lstm_cell/kernel')[3] // 4
+            n_hidden = reader.shape(lstm_cell_variables(names, 'forward')['kernel'])[3] // 4
             cand = ModelArch('UNet-LSTM_custom', KIND_UNET_LSTM, reader.shape('LSTM/output/conv2d/kernel')[3],
                              n_level=len(n_filter), n_filter=tuple(n_filter), n_block=tuple(n_block),
                              same_dim=n_hidden, fc=9)
@@ -424,7 +452,7 @@ def checkpoint_to_params(prefix: str, arch: Optional[ModelArch] = None, verify_c
         arch = infer_arch(reader)
     params = {}
     specs = {s.name: s for s in arch.layer_specs()}
-    for layer, names in variable_names(arch).items():
+    for layer, names in variable_names(arch, reader.names()).items():
         p = {}
         for key, tfname in names.items():
             t = reader.get_tensor(tfname, verify_crc).astype(np.float32)
