@@ -265,10 +265,10 @@ int override_cfg(const std::string &layer) {
 // type reuse the entry (e.g. the long-axis models at 176x208).
 struct Tuned { int ks, stride, cin, cout, cfg; };
 const Tuned g_tuned_large[] = {
-    {3, 1, 16, 16, 11}, {3, 2, 16, 32, 123},  {3, 1, 32, 32, 301},
-    {3, 2, 32, 64, 124},  {3, 1, 64, 64, 300},  {3, 2, 64, 128, 22},
-    {3, 1, 128, 128, 300},  {3, 2, 128, 256, 24}, {3, 1, 256, 256, 300},
-};
+    {3, 1, 16, 16, 11}, {3, 2, 16, 32, 120},  {3, 1, 32, 32, 301},
+    {3, 2, 32, 64, 124},  {3, 1, 64, 64, 300},  {3, 2, 64, 128, 124},
+    {3, 1, 128, 128, 300},  {3, 2, 128, 256, 124}, {3, 1, 256, 256, 300},
+};      // r02: the stride-2 layers moved to the producer/consumer kernel once its loads ran two stages ahead (profiles/r02_notes.md)
 const Tuned g_tuned_small[] = {
     {3, 1, 16, 16, 11}, {3, 2, 16, 32, 29},  {3, 1, 32, 32, 301},
     {3, 2, 32, 64, 20},  {3, 1, 64, 64, 300},  {3, 2, 64, 128, 123},

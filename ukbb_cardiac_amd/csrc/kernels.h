@@ -29,6 +29,7 @@ struct ConvArgs {
                         // stride-2 transposed conv with C real channels; scatter to out[N,2Ho,2Wo,C]
     const int *in0_map; // optional (Winograd kernel only): image n of the batch reads in0 image in0_map[n]
                         // (ConvLSTM windows share cached U-Net feature frames); in1 / out are not remapped
+    int diag;           // diagnostic builds only (-DUKBB_DIAG, env UKBB_CONV_DIAG): ablation bits of conv_pc_kernel
 };
 
 // One compiled tiling of the conv kernel.
