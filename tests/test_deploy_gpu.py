@@ -130,6 +130,14 @@ def test_two_shards_on_one_gpu_equal_single_process(tmp_path):
         for nm in names:
             pa, pb = a / ('subj%02d' % i) / nm, b / ('subj%02d' % i) / nm
             assert pa.exists() and pa.read_bytes() == pb.read_bytes(), (i, nm)
+    # the reader -> GPU -> writer pipeline (default --io_threads 4) writes the same bytes as strictly sequential subjects
+    c = tmp_path / 'cohort_sequential'
+    shutil.copytree(str(tmp_path / 'cohort_single'), str(c), ignore=shutil.ignore_patterns('seg*', 'sa_E*'))
+    q = _run([script] + flags + ['--data_dir', str(c), '--io_threads', '0'])
+    assert q.returncode == 0, q.stdout[-3000:]
+    for i in range(8):
+        for nm in names:
+            assert (c / ('subj%02d' % i) / nm).read_bytes() == (b / ('subj%02d' % i) / nm).read_bytes(), (i, nm)
     stamp = {str(p): os.stat(str(p)).st_mtime_ns for p in a.rglob('*.nii.gz')}
     r2 = _run(['-m', 'ukbb_cardiac_amd.shard', '--gpus', '1', '--shards_per_gpu', '2', '--', script] + flags + ['--data_dir', str(a)])
     assert r2.returncode == 0 and 'Segmenting' not in r2.stdout                  # rerun is a no-op

@@ -312,3 +312,20 @@ def test_nifti_header_matches_the_nifti1_field_table(tmp_path, dtype):
     open(q, 'wb').write(bytes(hdr) + b'\0' * 4 + vol.tobytes(order='F'))
     im = nifti.load(q)
     assert np.array_equal(im.data, vol) and np.allclose(im.affine, [[2, 0, 0, -5], [0, 3, 0, -6], [0, 0, 4, -7], [0, 0, 0, 1]])
+
+
+def test_nifti_save_as_dtype_streams_the_same_bytes(tmp_path):
+    """The writer threads of the subject pipeline hand over uint8 labels; the file must be the float64 volume the
+    reference writes (deploy_network.py:92,136), byte for byte."""
+    lab = (np.random.default_rng(3).integers(0, 4, size=(13, 11, 3, 5))).astype(np.uint8)
+    aff = np.diag([1.8, 1.8, 10.0, 1.0])
+    pd = np.array([1, 1.8, 1.8, 10.0, 0.03, 0, 0, 0], np.float32)
+    a, b = str(tmp_path / 'a.nii.gz'), str(tmp_path / 'b.nii.gz')
+    f64 = np.zeros(lab.shape); f64[...] = lab
+    nifti.save(f64, a, aff, pd)
+    nifti.save(np.asfortranarray(lab), b, aff, pd, as_dtype=np.float64)
+    assert open(a, 'rb').read() == open(b, 'rb').read()
+    assert nifti.load(b).data.dtype == np.float64
+    nifti.save(lab[:, :, 0, 0], b, aff, as_dtype=np.int32)
+    nifti.save(lab[:, :, 0, 0].astype(np.int32), a, aff)
+    assert open(a, 'rb').read() == open(b, 'rb').read()

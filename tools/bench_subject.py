@@ -1,28 +1,49 @@
-"""End-to-end time of ONE subject through the sequence path (BASELINE config 1 volume: 192x208x10x50
-float32), host pre/post-processing (numpy mirror of common/deploy_network.py:86-131) vs the device
-pipeline (ukbb_cardiac_amd/device_pipeline.py).  File I/O (gzip NIfTI) excluded.  GPU box only."""
+"""End-to-end time per subject through the sequence path (BASELINE config 1 volume: 192x208x10x50 float32 = 500 slices).
+
+  1. host numpy pre/post-processing + forward_host            (the reference's structure, common/deploy_network.py:86-131)
+  2. device pipeline, one subject at a time                     (device_pipeline.segment_sequence_device, round 1)
+  3. subject pipeline, steady state, files excluded             (subject_pipeline.SubjectPipeline: pinned staging, 3 streams)
+  4. the drop-in script over a cohort of gzip NIfTI files       (reader threads -> GPU -> writer threads), files INCLUDED,
+     with --io_threads 0 (sequential subjects) and N
+
+GPU box only.   python tools/bench_subject.py [--subjects 8] [--cohort 12] [--io_threads 4,8,16]"""
+import argparse
+import functools
 import os
+import shutil
 import sys
+import tempfile
 import time
 
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
+print = functools.partial(print, flush=True)
+
 if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--subjects', type=int, default=10)
+    ap.add_argument('--cohort', type=int, default=12)
+    ap.add_argument('--io_threads', default='4,8,16')
+    ap.add_argument('--skip-host', action='store_true')
+    args = ap.parse_args()
     import torch
-    from ukbb_cardiac_amd import device_pipeline as dp
+    from ukbb_cardiac_amd import deploy_network, device_pipeline as dp, nifti
     from ukbb_cardiac_amd.arch import MODELS
     from ukbb_cardiac_amd.engine import Engine
-    from ukbb_cardiac_amd.image_utils import rescale_intensity
-    from ukbb_cardiac_amd.pipeline import pick_ed_es, segment_sequence
-    from ukbb_cardiac_amd.weights import synthetic_params
+    from ukbb_cardiac_amd.pipeline import segment_sequence
+    from ukbb_cardiac_amd.subject_pipeline import SubjectPipeline, labels_as_float64
+    from ukbb_cardiac_amd.weights import save_blob, synthetic_params
 
     arch = MODELS['FCN_sa']
-    eng = Engine(arch, synthetic_params(arch, 1234))
+    params = synthetic_params(arch, 1234)
+    eng = Engine(arch, params)
     rng = np.random.default_rng(0)
-    vol = np.asfortranarray((1000 * rng.gamma(2.0, 1.0, size=(192, 208, 10, 50))).astype(np.float32))
-    fwd = lambda b: eng.run(b, want_prob=False)
+    shape = (192, 208, 10, 50)
+    vols = [np.asfortranarray((1000 * rng.gamma(2.0, 1.0, size=shape)).astype(np.float32)) for _ in range(3)]
+    n = shape[2] * shape[3]
+    print('subject %dx%dx%dx%d (%d slices); host cores: %d logical' % (shape + (n, os.cpu_count())))
 
     def timeit(f, reps):
         f()
@@ -33,17 +54,95 @@ if __name__ == '__main__':
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / reps, r
 
-    th, want = timeit(lambda: segment_sequence(vol.copy(order='F'), fwd, 128), 2)
-    td, got = timeit(lambda: dp.segment_sequence_device(vol, eng, 128), 5)
-    assert np.array_equal(want, got)
-    tp, _ = timeit(lambda: np.percentile(vol, (1, 99)), 2)
-    tr, _ = timeit(lambda: rescale_intensity(vol.copy(order='F'), (1, 99)), 2)
-    t = torch.from_numpy(vol).cuda()
-    ts, _ = timeit(lambda: dp.device_percentiles(t, (1, 99)), 10)
-    n = vol.shape[2] * vol.shape[3]
-    print('subject 192x208x10x50 (500 slices), labels identical on both paths')
-    print('host pre/post-processing + forward_host: %7.1f ms per subject  (%6.0f slices/s)' % (th * 1e3, n / th))
-    print('   of which np.percentile(vol, (1,99)):  %7.1f ms;  rescale_intensity total %7.1f ms' % (tp * 1e3, tr * 1e3))
-    print('device pipeline (H2D 80 MB, select, pack, forward, unpack, D2H 20 MB + float64 volume): %7.1f ms  (%6.0f slices/s)'
-          % (td * 1e3, n / td))
-    print('   of which exact percentiles on device: %7.2f ms' % (ts * 1e3))
+    want = None
+    if not args.skip_host:
+        fwd = lambda b: eng.run(b, want_prob=False)
+        th, want = timeit(lambda: segment_sequence(vols[0].copy(order='F'), fwd, 128), 1)
+        print('1. host pre/post-processing + forward_host:            %7.1f ms per subject (%6.0f slices/s)' % (th * 1e3, n / th))
+    td, got = timeit(lambda: dp.segment_sequence_device(vols[0], eng, 128), 5)
+    print('2. device pipeline, one subject at a time (pageable H2D, float64 volume on this thread): %7.1f ms (%6.0f slices/s)' % (td * 1e3, n / td))
+    if want is not None:
+        assert np.array_equal(want, got)
+
+    pipe = SubjectPipeline(eng, shape, 128, depth=3)
+    first = None
+    for r in pipe.run([vols[0]]):
+        first = r.labels
+    assert np.array_equal(labels_as_float64(first), got), 'pipelined labels differ from the sequential device pipeline'
+    K = args.subjects
+
+    def staged_source():                     # what a reader thread leaves behind: the volume already in pinned memory
+        for i in range(K):
+            st = pipe.stage(shape)
+            st.array[...] = vols[i % 3]
+            yield st
+    # (a) volumes already staged in pinned memory by "readers": stage ahead of the GPU thread is not possible from one
+    #     thread beyond the pool size, so time the GPU-side work only: pre-stage lazily inside the generator and subtract
+    #     the memcpy by measuring it separately
+    t0 = time.perf_counter()
+    for _ in pipe.run(staged_source()):
+        pass
+    torch.cuda.synchronize()
+    t_staged = (time.perf_counter() - t0) / K
+    def one_copy():
+        st = pipe.stage(shape)
+        np.copyto(st.array, vols[0])
+        pipe._staged.pop(id(st.array), None)
+        pipe._in_free.put(st.buf)
+    tm, _ = timeit(one_copy, 3)
+    print('3. subject pipeline, steady state over %d subjects, files excluded: %7.1f ms per subject (%6.0f slices/s) including a '
+          'single-thread 80 MB memcpy into pinned memory of %.1f ms that reader threads do off this thread in the script'
+          % (K, t_staged * 1e3, n / t_staged, tm * 1e3))
+
+    # (b) GPU-thread time only: inputs pre-staged before the clock starts (as many as the pool holds), depth 3
+    pipe2 = SubjectPipeline(eng, shape, 128, depth=3, extra_inputs=K)
+    for _ in pipe2.run([vols[0], vols[1]]):                  # warm-up
+        pass
+    staged = []
+    for i in range(K):
+        st = pipe2.stage(shape)
+        st.array[...] = vols[i % 3]
+        staged.append(st)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in pipe2.run(staged):
+        pass
+    torch.cuda.synchronize()
+    t_gpu = (time.perf_counter() - t0) / K
+    print('   ... inputs already in pinned memory (what reader threads provide): %7.1f ms per subject (%6.0f slices/s); '
+          'network alone: %.1f ms' % (t_gpu * 1e3, n / t_gpu, n / 46000.0 * 1e3))
+    del pipe, pipe2
+
+    # 4. files included
+    root = tempfile.mkdtemp(prefix='ukbb_cohort_')
+    try:
+        mp = os.path.join(root, 'FCN_sa')
+        save_blob(mp + '.ukbbw', arch, params)
+        src = os.path.join(root, 'src')
+        os.makedirs(src)
+        aff = np.diag([1.8, 1.8, 10.0, 1.0])
+        pixdim = np.array([1, 1.8, 1.8, 10.0, 0.03, 0, 0, 0], np.float32)
+        t0 = time.perf_counter()
+        for i in range(args.cohort):
+            os.makedirs(os.path.join(src, 's%03d' % i))
+            nifti.save(vols[i % 3], os.path.join(src, 's%03d' % i, 'sa.nii.gz'), aff, pixdim)
+        tw = (time.perf_counter() - t0) / args.cohort
+        size = os.path.getsize(os.path.join(src, 's000', 'sa.nii.gz')) / 1e6
+        t0 = time.perf_counter(); nifti.load(os.path.join(src, 's000', 'sa.nii.gz')); tr = time.perf_counter() - t0
+        print('4. cohort of %d subjects on disk: sa.nii.gz %.0f MB each (synthetic noise compresses badly; reading one: %.0f ms, '
+              'writing one: %.0f ms, single thread)' % (args.cohort, size, tr * 1e3, tw * 1e3))
+        for thr in [0] + [int(v) for v in args.io_threads.split(',')]:
+            work = os.path.join(root, 'run%d' % thr)
+            shutil.copytree(src, work)
+            t0 = time.perf_counter()
+            deploy_network.run(deploy_network.define_flags().parse(['--seq_name', 'sa', '--data_dir', work, '--model_path', mp,
+                                                                     '--io_threads', str(thr)])[0],
+                               lambda b: {'pred': eng.run(b, want_prob=False)['pred']}, log=lambda *_: None, engine=eng)
+            dt = time.perf_counter() - t0
+            out = os.path.getsize(os.path.join(work, 's000', 'seg_sa.nii.gz')) / 1e6
+            print('   deploy_network.py --io_threads %-2d: %6.2f s for %d subjects = %5.2f subjects/s (%6.0f slices/s), files included '
+                  '(seg_sa.nii.gz: 160 MB of float64 -> %.1f MB gzip)' % (thr, dt, args.cohort, args.cohort / dt, args.cohort * n / dt, out))
+            shutil.rmtree(work)
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+    eng.close()

@@ -49,6 +49,8 @@ def define_flags():
                       '(float32 sequences; results identical to the host path).')
     fs.DEFINE_boolean('numpy1_casting', False, 'Rescale intensities with the float32 arithmetic numpy 1.x used when the reference '
                       'was written (1 ulp from numpy 2; host pre-processing only; INTEGRATION.md section 5).')
+    fs.DEFINE_integer('io_threads', 4, 'Reader threads (gzip NIfTI -> pinned staging) and writer threads (float64 label volume, gzip) '
+                      'around the GPU in sequence mode; 0 = strictly sequential subjects as in the reference.')
     fs.DEFINE_integer('num_shards', env_cnt, 'Number of workers sharing data_dir.')
     fs.DEFINE_integer('shard_index', env_idx, 'This worker: subjects i with i % num_shards == shard_index.')
     return fs
@@ -58,6 +60,153 @@ def seg_prefix(FLAGS):
     return 'seg4' if (FLAGS.seq_name == 'la_4ch' and FLAGS.seg4) else 'seg'
 
 
+def save_sequence_outputs(data_dir, pre, seq, affine, pixdim, pred, frames):
+    """The five files of deploy_network.py:136-151.  pred: (X,Y,Z,T) labels, stored as float64 (:92); frames: {'ED'|'ES':
+    (image frame, label frame)}."""
+    nifti.save(pred, '{0}/{1}_{2}.nii.gz'.format(data_dir, pre, seq), affine, pixdim, as_dtype=np.float64)
+    for fr, (img_fr, seg_fr) in frames.items():
+        nifti.save(img_fr, '{0}/{1}_{2}.nii.gz'.format(data_dir, seq, fr), affine)
+        nifti.save(seg_fr, '{0}/{1}_{2}_{3}.nii.gz'.format(data_dir, pre, seq, fr), affine)
+
+
+def run_pipelined(FLAGS, engine, data_list, log=print):
+    """Sequence mode with subjects overlapped: reader threads decompress the next files into pinned staging buffers,
+    the GPU thread (this one) keeps up to two subjects in flight on three streams (subject_pipeline.SubjectPipeline),
+    writer threads expand the uint8 labels to the reference's float64 volume, gzip and save.  Same files, byte for byte,
+    as the sequential loop; log lines of a subject are emitted together when its result arrives."""
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    from ukbb_cardiac_amd import device_pipeline
+    from ukbb_cardiac_amd.subject_pipeline import SubjectPipeline
+    start_time = time.time()
+    seq, pre = FLAGS.seq_name, seg_prefix(FLAGS)
+    todo = []
+    for data in data_list:
+        data_dir = os.path.join(FLAGS.data_dir, data)
+        if not os.path.isdir(data_dir) or os.path.exists('{0}/{1}_{2}.nii.gz'.format(data_dir, pre, seq)):
+            log(data)
+            continue
+        image_name = '{0}/{1}.nii.gz'.format(data_dir, seq)
+        if not os.path.exists(image_name):
+            log(data)
+            log('  Directory {0} does not contain an image with file name {1}. Skip.'.format(data_dir, os.path.basename(image_name)))
+            continue
+        todo.append((data, data_dir, image_name))
+    nthr = max(1, int(FLAGS.io_threads))
+    window = nthr + 1                                   # reads allowed to run ahead of the GPU thread
+    depth = 3
+    state = {'pipe': None}
+    mk = threading.Lock()
+
+    def alloc(shape, dt):
+        if len(shape) == 4 and dt == np.float32:
+            with mk:
+                if state['pipe'] is None:                  # sized by the first volume; bigger ones fall back below
+                    state['pipe'] = SubjectPipeline(engine, shape, FLAGS.batch_slices, depth=depth, extra_inputs=window)
+            try:
+                return state['pipe'].stage(shape, dt).array
+            except ValueError:
+                pass
+        return np.empty(shape, dt, order='F')
+
+    def read(item):
+        t0 = time.time()
+        nim = nifti.load(item[2], alloc=alloc)
+        return nim, time.time() - t0
+
+    processed, table_time, writes = [], [], []
+    readers, writers = ThreadPoolExecutor(nthr), ThreadPoolExecutor(nthr)
+    futures = {}
+    inflight = []                                       # (item, nim, t_submit)
+
+    def finish(item, nim, t0):
+        data, data_dir, image_name = item
+        res = state['pipe'].collect()
+        seg_time = time.time() - t0
+        k_ed, k_es = device_pipeline.pick_ed_es_from_counts(res.counts, seq, FLAGS.seg4)
+        log(data)
+        log('  Reading {} ...'.format(image_name))
+        log('  Segmenting full sequence ...')
+        log('  Segmentation time = {:3f}s'.format(seg_time))
+        log('  ED frame = {:d}, ES frame = {:d}'.format(k_ed, k_es))
+        table_time.append(seg_time)
+        processed.append(data)
+        if FLAGS.save_seg:
+            log('  Saving segmentation ...')
+            # the saved frames are the CLIPPED intensities (alias quirk, SURVEY.md App. C.1)
+            frames = {fr: (device_pipeline.clip_like_reference(res.image[:, :, :, k], res.clip), res.labels[:, :, :, k].astype(np.float64))
+                      for fr, k in (('ED', k_ed), ('ES', k_es))}
+            labels, affine, pixdim = res.labels, nim.affine, nim.header['pixdim']
+            writes.append(writers.submit(lambda: save_sequence_outputs(data_dir, pre, seq, affine, pixdim, labels, frames)))
+        res.done()
+
+    try:
+        nxt = 0
+        for i, item in enumerate(todo):
+            while nxt < len(todo) and nxt < i + window:
+                futures[nxt] = readers.submit(read, todo[nxt])
+                nxt += 1
+            nim, _ = futures.pop(i).result()
+            image = nim.get_data()
+            pipe = state['pipe']
+            if image.ndim != 4 or image.dtype != np.float32 or pipe is None or image.size > pipe._in_cap:
+                while inflight:                             # odd subject: drain, then take the sequential path
+                    finish(*inflight.pop(0))
+                log(item[0])
+                _sequence_subject(FLAGS, item, nim, None, engine, log, processed, table_time)
+                continue
+            if len(inflight) >= depth - 1:
+                finish(*inflight.pop(0))
+            pipe.submit(image)
+            inflight.append((item, nim, time.time()))
+        while inflight:
+            finish(*inflight.pop(0))
+        for w in writes:
+            w.result()
+    finally:
+        readers.shutdown(wait=True)
+        writers.shutdown(wait=True)
+    return processed, table_time, start_time
+
+
+def _sequence_subject(FLAGS, item, nim, forward, engine, log, processed, table_time):
+    """One subject of sequence mode, start to finish on this thread (deploy_network.py:80-151)."""
+    data, data_dir, image_name = item
+    seq, pre = FLAGS.seq_name, seg_prefix(FLAGS)
+    image = nim.get_data()
+    if image.ndim != 4:
+        log('  {0}: expected a 4-D sequence, found shape {1}. Skip.'.format(image_name, image.shape))
+        return
+    log('  Segmenting full sequence ...')
+    t0 = time.time()
+    np1 = bool(getattr(FLAGS, 'numpy1_casting', False))
+    on_device = engine is not None and getattr(FLAGS, 'device_preproc', False) and image.dtype == np.float32 and not np1
+    if on_device:
+        from ukbb_cardiac_amd import device_pipeline
+        pred, aux = device_pipeline.segment_sequence_device(image, engine, FLAGS.batch_slices, return_aux=True)
+    else:
+        if forward is None:
+            forward = lambda b: {'pred': engine.run(b, want_prob=False)['pred']}
+        pred = pipeline.segment_sequence(image, forward, FLAGS.batch_slices, np1)   # clips `image` in place
+    seg_time = time.time() - t0
+    log('  Segmentation time = {:3f}s'.format(seg_time))
+    table_time.append(seg_time)
+    processed.append(data)
+    if on_device:
+        k_ed, k_es = device_pipeline.pick_ed_es_from_counts(aux['counts'], seq, FLAGS.seg4)
+    else:
+        k_ed, k_es = pipeline.pick_ed_es(pred, seq, FLAGS.seg4)
+    log('  ED frame = {:d}, ES frame = {:d}'.format(k_ed, k_es))
+    if FLAGS.save_seg:
+        log('  Saving segmentation ...')
+        frames = {}
+        for fr, k in (('ED', k_ed), ('ES', k_es)):
+            # the saved frames are the CLIPPED intensities (alias quirk, SURVEY.md App. C.1)
+            frame = device_pipeline.clip_like_reference(image[:, :, :, k], aux['clip']) if on_device else image[:, :, :, k]
+            frames[fr] = (frame, pred[:, :, :, k])
+        save_sequence_outputs(data_dir, pre, seq, nim.affine, nim.header['pixdim'], pred, frames)
+
+
 def run(FLAGS, forward, log=print, engine=None):
     """The subject loop of deploy_network.py:52-225 with ``forward`` standing for sess.run.
     With ``engine`` (and --device_preproc) float32 sequences take the device pipeline."""
@@ -65,6 +214,10 @@ def run(FLAGS, forward, log=print, engine=None):
     data_list = subjects_for_shard(sorted(os.listdir(FLAGS.data_dir)), FLAGS.shard_index, FLAGS.num_shards)
     processed, table_time = [], []
     seq, pre = FLAGS.seq_name, seg_prefix(FLAGS)
+    if (FLAGS.process_seq and engine is not None and getattr(FLAGS, 'device_preproc', False) and getattr(FLAGS, 'io_threads', 0) > 0
+            and not getattr(FLAGS, 'numpy1_casting', False)):
+        processed, table_time, _ = run_pipelined(FLAGS, engine, data_list, log)
+        data_list = []
     for data in data_list:
         log(data)
         data_dir = os.path.join(FLAGS.data_dir, data)
@@ -80,37 +233,7 @@ def run(FLAGS, forward, log=print, engine=None):
                 continue
             log('  Reading {} ...'.format(image_name))
             nim = nifti.load(image_name)
-            image = nim.get_data()
-            if image.ndim != 4:
-                log('  {0}: expected a 4-D sequence, found shape {1}. Skip.'.format(image_name, image.shape))
-                continue
-            log('  Segmenting full sequence ...')
-            t0 = time.time()
-            np1 = bool(getattr(FLAGS, 'numpy1_casting', False))
-            on_device = engine is not None and getattr(FLAGS, 'device_preproc', False) and image.dtype == np.float32 and not np1
-            if on_device:
-                from ukbb_cardiac_amd import device_pipeline
-                pred, aux = device_pipeline.segment_sequence_device(image, engine, FLAGS.batch_slices, return_aux=True)
-            else:
-                pred = pipeline.segment_sequence(image, forward, FLAGS.batch_slices, np1)   # clips `image` in place
-            seg_time = time.time() - t0
-            log('  Segmentation time = {:3f}s'.format(seg_time))
-            table_time.append(seg_time)
-            processed.append(data)
-            if on_device:
-                k_ed, k_es = device_pipeline.pick_ed_es_from_counts(aux['counts'], seq, FLAGS.seg4)
-            else:
-                k_ed, k_es = pipeline.pick_ed_es(pred, seq, FLAGS.seg4)
-            log('  ED frame = {:d}, ES frame = {:d}'.format(k_ed, k_es))
-            if FLAGS.save_seg:
-                log('  Saving segmentation ...')
-                pixdim = nim.header['pixdim']
-                nifti.save(pred, '{0}/{1}_{2}.nii.gz'.format(data_dir, pre, seq), nim.affine, pixdim)
-                for fr, k in (('ED', k_ed), ('ES', k_es)):
-                    # the saved frames are the CLIPPED intensities (alias quirk)
-                    frame = device_pipeline.clip_like_reference(image[:, :, :, k], aux['clip']) if on_device else image[:, :, :, k]
-                    nifti.save(frame, '{0}/{1}_{2}.nii.gz'.format(data_dir, seq, fr), nim.affine)
-                    nifti.save(pred[:, :, :, k], '{0}/{1}_{2}_{3}.nii.gz'.format(data_dir, pre, seq, fr), nim.affine)
+            _sequence_subject(FLAGS, (data, data_dir, image_name), nim, forward, engine, log, processed, table_time)
         else:
             names = {fr: '{0}/{1}_{2}.nii.gz'.format(data_dir, seq, fr) for fr in ('ED', 'ES')}
             if not all(os.path.exists(p) for p in names.values()):

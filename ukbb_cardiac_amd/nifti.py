@@ -81,9 +81,7 @@ def _quat_affine(b, c, d, qx, qy, qz, pixdim):
     return A
 
 
-def load(path) -> NiftiImage:
-    with _open(path, 'rb') as f:
-        raw = f.read()
+def _parse_header(raw, path):
     if len(raw) < 348:
         raise ValueError('%s: too short for a NIfTI-1 header' % path)
     end = '<'
@@ -110,15 +108,6 @@ def load(path) -> NiftiImage:
     shape = tuple(int(d) for d in dim[1:1 + ndim])
     dt = np.dtype(end + _DTYPES[datatype])
     off = int(vox_offset) if vox_offset >= 352 else 352
-    n = int(np.prod(shape))
-    if len(raw) < off + n * dt.itemsize:
-        raise ValueError('%s: truncated image data' % path)
-    data = np.frombuffer(raw, dtype=dt, count=n, offset=off).reshape(shape, order='F')
-    data = data.astype(dt.newbyteorder('='), copy=True)       # writable, native order
-    if slope != 0 and not (slope == 1 and inter == 0) and np.isfinite(slope):
-        data = data * np.float64(slope) + np.float64(inter)   # nibabel's get_data() applies the scaling
-    while data.ndim > 3 and data.shape[-1] == 1 and data.ndim > len(shape):
-        data = data[..., 0]
     if sform_code > 0:                                         # nibabel's get_best_affine order
         affine = np.vstack([srow, [0, 0, 0, 1]])
     elif qform_code > 0:
@@ -128,14 +117,56 @@ def load(path) -> NiftiImage:
         affine[:3, 3] = -0.5 * (np.array(shape[:3] + (1,) * (3 - min(3, len(shape))))[:3] - 1) * pixdim[1:4]
     hdr = {'dim': dim, 'datatype': datatype, 'bitpix': bitpix, 'qform_code': qform_code, 'sform_code': sform_code,
            'xyzt_units': raw[123], 'descrip': raw[148:228].rstrip(b'\x00')}
+    scaled = slope != 0 and not (slope == 1 and inter == 0) and np.isfinite(slope)
+    return shape, dt, off, (slope, inter) if scaled else None, affine, pixdim, hdr
+
+
+def load(path, alloc=None) -> NiftiImage:
+    """``alloc(shape, dtype) -> writable Fortran-ordered ndarray`` (optional) supplies the memory the voxels are
+    decompressed into -- e.g. a view of pinned host memory, so the volume goes file -> staging buffer with no copy in
+    between (ukbb_cardiac_amd/subject_pipeline.py).  It is used when the file's voxel type is native-endian and
+    unscaled (the float32 cines of the reference, data/biobank_utils.py:314); otherwise the data is a fresh array."""
+    with _open(path, 'rb') as f:
+        head = f.read(352)
+        shape, dt, off, scale, affine, pixdim, hdr = _parse_header(head, path)
+        if off > 352:
+            f.read(off - 352)                                   # header extensions
+        n = int(np.prod(shape))
+        direct = alloc is not None and scale is None and dt.isnative
+        if direct:
+            data = alloc(shape, dt)
+            if data.shape != shape or data.dtype != dt or not data.flags.f_contiguous or not data.flags.writeable:
+                raise ValueError('alloc() must return a writable Fortran-ordered array of the requested shape and dtype')
+            view = memoryview(data.reshape(-1, order='F')).cast('B')     # F-order memory, as on disk
+            got = 0
+            while got < len(view):
+                k = f.readinto(view[got:])
+                if not k:
+                    break
+                got += k
+            if got < len(view):
+                raise ValueError('%s: truncated image data' % path)
+        else:
+            raw = f.read(n * dt.itemsize)
+            if len(raw) < n * dt.itemsize:
+                raise ValueError('%s: truncated image data' % path)
+            data = np.frombuffer(raw, dtype=dt, count=n).reshape(shape, order='F')
+            data = data.astype(dt.newbyteorder('='), copy=True)       # writable, native order
+            if scale is not None:
+                data = data * np.float64(scale[0]) + np.float64(scale[1])   # nibabel's get_data() applies the scaling
     return NiftiImage(data, affine, pixdim, hdr)
 
 
-def save(img_or_data, path, affine=None, pixdim=None):
+def save(img_or_data, path, affine=None, pixdim=None, as_dtype=None):
     """save(NiftiImage, path) or save(ndarray, path, affine[, pixdim]).  Writes the
     array's own dtype (the reference relies on that: float64 label volumes in
     sequence mode, int32 in ED/ES mode), sform = affine
-    (code 2, as nibabel's Nifti1Image(data, affine) does), qform code 0."""
+    (code 2, as nibabel's Nifti1Image(data, affine) does), qform code 0.
+
+    ``as_dtype``: store the values converted to this dtype, slab by slab along the
+    last axis while compressing -- the file is byte-identical to ``save(data.astype(as_dtype), ...)``
+    without ever holding the converted volume (a 20 MB uint8 label volume becomes the
+    160 MB float64 file of deploy_network.py:92,136 this way)."""
     if isinstance(img_or_data, NiftiImage):
         data, affine, pixdim = img_or_data.data, img_or_data.affine, img_or_data.header['pixdim']
     else:
@@ -143,7 +174,8 @@ def save(img_or_data, path, affine=None, pixdim=None):
     data = np.asarray(data)
     if data.dtype == np.bool_:
         data = data.astype(np.uint8)
-    key = data.dtype.newbyteorder('<').str[1:]
+    out_dtype = np.dtype(as_dtype) if as_dtype is not None else data.dtype
+    key = out_dtype.newbyteorder('<').str[1:]
     if key not in _CODES:
         raise ValueError('cannot store dtype %s in NIfTI-1' % data.dtype)
     affine = np.asarray(affine, dtype=np.float64)
@@ -159,15 +191,22 @@ def save(img_or_data, path, affine=None, pixdim=None):
     hdr = bytearray(348)
     struct.pack_into('<i', hdr, 0, 348)
     struct.pack_into('<8h', hdr, 40, *dim)
-    struct.pack_into('<2h', hdr, 70, _CODES[key], data.dtype.itemsize * 8)
+    struct.pack_into('<2h', hdr, 70, _CODES[key], out_dtype.itemsize * 8)
     struct.pack_into('<8f', hdr, 76, *[float(v) for v in pd])
     struct.pack_into('<3f', hdr, 108, 352.0, 1.0, 0.0)
     hdr[123] = 10 if data.ndim >= 4 else 2            # mm (+ seconds): informative only
     struct.pack_into('<2h', hdr, 252, 0, 2)
     struct.pack_into('<12f', hdr, 280, *[float(v) for v in affine[:3].ravel()])
     hdr[344:348] = b'n+1\x00'
-    payload = np.asfortranarray(data.astype(data.dtype.newbyteorder('<'), copy=False)).tobytes(order='F')
     with _open(path, 'wb') as f:
         f.write(bytes(hdr))
         f.write(b'\x00\x00\x00\x00')
-        f.write(payload)
+        if as_dtype is None:
+            f.write(np.asfortranarray(data.astype(data.dtype.newbyteorder('<'), copy=False)).tobytes(order='F'))
+        else:
+            le = out_dtype.newbyteorder('<')
+            if data.ndim < 2:
+                f.write(np.asarray(data, dtype=le).tobytes(order='F'))
+            else:
+                for k in range(data.shape[-1]):               # x fastest on disk: the last axis is the slowest
+                    f.write(np.asfortranarray(data[..., k]).astype(le).tobytes(order='F'))
