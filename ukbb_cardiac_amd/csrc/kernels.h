@@ -115,6 +115,7 @@ struct HeadArgs {
     float *prob;             // optional
     int32_t *pred;           // optional [N,H,W]
     int N, H, W, n_class;
+    int diag;                // diagnostic builds only (-DUKBB_DIAG, env UKBB_HEAD_DIAG): ablation bits of fcn_head_pc_kernel
 };
 hipError_t launch_head(const HeadArgs &a, hipStream_t s);
 void pack_sq(const float *w /*[cin][32] folded*/, int cin, float *dst /*cin*32*/);

@@ -787,6 +787,10 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
                         for (int i = 0; i < 4; ++i) biasT[cb][4 * j + i] = bv4[i];
                     }
                 }
+                // Wait for the bias HERE (rare: once per Cout group).  Left to hipcc the wait lands in front of the first
+                // MFMA of EVERY item as s_waitcnt vmcnt(0), which also waits for the previous item's output stores to be
+                // acknowledged by memory -- once per stage for layers whose items are a single stage.
+                __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0), other counters untouched
             }
             Acc acc[CB][PBW];
             auto chunk = [&](auto firstc) {

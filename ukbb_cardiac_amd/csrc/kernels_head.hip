@@ -592,6 +592,9 @@ __global__ __launch_bounds__(768) void fcn_head_pc_kernel(const HeadArgs a) {
         auto gather = [&](auto parc, auto bufc) {       // block 2*pw + PAR of the tile staged in window buffer BUF -> P (32 channels)
             constexpr int PAR = decltype(parc)::value, BUF = decltype(bufc)::value;
             P = bias_tile_lds(lds + L_BO0 + 32 * half, g);
+#ifdef UKBB_DIAG
+            if (a.diag & 1) return;                 // ablation: no gather (hand over the bias tile only)
+#endif
 #pragma unroll
             for (int l = 1; l <= 4; ++l) {
                 const int wn_ = win_n(l);
@@ -694,6 +697,9 @@ __global__ __launch_bounds__(768) void fcn_head_pc_kernel(const HeadArgs a) {
                 for (int i = 0; i < 4; ++i) S = MFMA32(wv1[i], x1[i], S);
             }
             relu16(S);
+#ifdef UKBB_DIAG
+            if (a.diag & 2) { relu16(P0); relu16(P1); if (a.pred) a.pred[q] = (int)P0[0]; continue; }   // ablation: no out0/out1/logits
+#endif
             // ---- out0: handed tile (bias + upsampled levels 1..4) + W0_0 * S ----
             chain_32to64_lds(w_o0, lane, S, P0, P1);
             relu16(P0);
@@ -704,6 +710,9 @@ __global__ __launch_bounds__(768) void fcn_head_pc_kernel(const HeadArgs a) {
             chain_32to64_lds(w_o1 + 2 * 4 * 64 * 4, lane, P1, Q0, Q1);
             relu16(Q0);
             relu16(Q1);
+#ifdef UKBB_DIAG
+            if (a.diag & 4) { if (a.pred) a.pred[q] = (int)(Q0[0] + Q1[0]); continue; }   // ablation: no logits / softmax VALU
+#endif
             // ---- logits / softmax / argmax ----
             // Packed over channel pairs (weights and activations are both consecutive registers), so
             // each class costs 16 v_pk_fma_f32 + 1 add and no operand shuffling.
@@ -792,7 +801,11 @@ static hipError_t launch_head_occ(const HeadArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_head(const HeadArgs &a, hipStream_t s) {
+hipError_t launch_head(const HeadArgs &a_in, hipStream_t s) {
+    HeadArgs a = a_in;
+#ifdef UKBB_DIAG
+    { const char *e = getenv("UKBB_HEAD_DIAG"); a.diag = e ? atoi(e) : 0; }
+#endif
     if ((a.H % HT) || (a.W % HT)) return hipErrorInvalidValue;
     static const int use_pc = [] { const char *e = getenv("UKBB_HEAD_PC"); return e ? atoi(e) : 1; }();   // A/B knob
     if (use_pc) return launch_head_pc(a, s);

@@ -367,6 +367,9 @@ __global__ __launch_bounds__(512, 2) void wino_pc_kernel(const ConvArgs a) {
 #pragma unroll
                             for (int c = 0; c < 4; ++c) v[c] = relu1(v[c]);
                         }
+#ifdef UKBB_WINO_STAMPS
+                        if (a.diag & 32) continue;              // ablation: no output stores
+#endif
                         if (oy + i < a.Ho && ox + j < a.Wo) st4(o00 + i * dy + j * dx, v);
                     }
             }
@@ -415,7 +418,11 @@ static hipError_t launch_wino_t(const ConvArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_wino(const ConvArgs &a, int ncb, int tile_rows, hipStream_t s) {
+hipError_t launch_wino(const ConvArgs &a_in, int ncb, int tile_rows, hipStream_t s) {
+    ConvArgs a = a_in;
+#ifdef UKBB_WINO_STAMPS
+    { const char *e = getenv("UKBB_CONV_DIAG"); a.diag = e ? atoi(e) : 0; }
+#endif
     if (ncb == 4) return tile_rows == 8 ? launch_wino_t<4, 8>(a, s) : launch_wino_t<4, 4>(a, s);
     if (ncb == 2) return tile_rows == 8 ? launch_wino_t<2, 8>(a, s) : launch_wino_t<2, 4>(a, s);
     return hipErrorInvalidValue;
