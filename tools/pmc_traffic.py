@@ -12,7 +12,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 # GPU kernels that are exactly one launch of the engine's plan (bench.py looks its dominant kernel up by plan name)
-ENGINE_NAMES = (('fcn_head', 'head'), ('sqg_stream', 'sqg1'), ('sqg_multi', 'sqg2-4'))
+ENGINE_NAMES = (('fcn_head', 'head'), ('sqg_multi', 'sqg1-4'))
 
 
 def main(path):

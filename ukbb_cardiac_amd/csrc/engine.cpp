@@ -92,7 +92,7 @@ struct Op {                    // one kernel launch of the plan
     int in0 = -1, in1 = -1;    // activation buffer ids (-1: network input / none)
     int out = -1;
     int sq[4] = {-1, -1, -1, -1};   // OP_HEAD: squeezed maps of levels 1..4
-    int mlayer[3] = {-1, -1, -1}, min_[3] = {-1, -1, -1}, mout[3] = {-1, -1, -1}, mh[3] = {0, 0, 0}, mw[3] = {0, 0, 0};   // OP_SQG_MULTI: levels 2..4
+    int mlayer[4] = {-1, -1, -1, -1}, min_[4] = {-1, -1, -1, -1}, mout[4] = {-1, -1, -1, -1}, mh[4] = {0, 0, 0, 0}, mw[4] = {0, 0, 0, 0};   // OP_SQG_MULTI: levels 1..4
     bool fused_first = false;       // OP_CONV: conv0_0 (C_in = 1) evaluated by this kernel's producers
     bool on_side = false;           // launched on the handle's side stream (fork/join by events)
     int H = 0, W = 0, Ho = 0, Wo = 0, stride = 1, pad_y = 0, pad_x = 0;
@@ -484,6 +484,7 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
     int cur = -1, ch = 1, cw = 1;
     std::vector<int> level_out(a.n_level), lh(a.n_level), lw(a.n_level), sqg_out(a.n_level, -1);
     Op multi;
+    multi.kind = OP_FIRST;                         // becomes OP_SQG_MULTI when the first merged level arrives
     int hh = H, ww = W;
     for (int l = 0; l < a.n_level; ++l) {
         for (int i = 0; i < a.n_block[l]; ++i) {
@@ -530,12 +531,13 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
             op.macs_per_image = (double)lh[l] * lw[l] * a.n_filter[l] * a.same_dim;
             op.mfma_macs_per_image = (double)lh[l] * lw[l] * (a.n_filter[l] * a.same_dim + a.same_dim * a.fc);
             sqg_out[l] = op.out;
-            // levels 2-4 of the standard filter pyramid go out as ONE launch after level 4 (sqg_multi_kernel)
-            const bool merge = !h->use_side && a.n_level == 5 && a.n_filter[2] == 64 && a.n_filter[3] == 128 && a.n_filter[4] == 256;
-            if (merge && l >= 2) {
-                if (l == 2) { multi = Op(); multi.kind = OP_SQG_MULTI; multi.name = "sqg2-4"; multi.macs_per_image = 0; multi.mfma_macs_per_image = 0; }
-                multi.mlayer[l - 2] = op.layer; multi.min_[l - 2] = op.in0; multi.mout[l - 2] = op.out;
-                multi.mh[l - 2] = lh[l]; multi.mw[l - 2] = lw[l];
+            // levels 1-4 of the standard filter pyramid go out as ONE launch after level 4 (sqg_multi_kernel)
+            static const bool split1 = getenv("UKBB_SQG1_SEPARATE") != nullptr;    // A/B knob: level 1 as a launch of its own
+            const bool merge = !h->use_side && a.n_level == 5 && a.n_filter[1] == 32 && a.n_filter[2] == 64 && a.n_filter[3] == 128 && a.n_filter[4] == 256;
+            if (merge && l >= 1 && !(split1 && l == 1)) {
+                if (multi.kind != OP_SQG_MULTI) { multi = Op(); multi.kind = OP_SQG_MULTI; multi.name = split1 ? "sqg2-4" : "sqg1-4"; multi.macs_per_image = 0; multi.mfma_macs_per_image = 0; }
+                multi.mlayer[l - 1] = op.layer; multi.min_[l - 1] = op.in0; multi.mout[l - 1] = op.out;
+                multi.mh[l - 1] = lh[l]; multi.mw[l - 1] = lw[l];
                 multi.macs_per_image += op.macs_per_image; multi.mfma_macs_per_image += op.mfma_macs_per_image;
                 if (l == 4) h->ops.push_back(multi);
             } else {
@@ -732,18 +734,20 @@ int run_plan(ukbb_fcn_handle *h, const float *image, int n, float *logits, float
                 break;
             }
             case OP_SQG_MULTI: {
-                SqgArgs sa[3];
-                for (int j = 0; j < 3; ++j) {
-                    const HostLayer &L = h->layers[op.mlayer[j]];
-                    const std::string ls = std::to_string(j + 2);
+                SqgArgs sa[4];
+                for (int j = 0; j < 4; ++j) {
                     sa[j] = SqgArgs{};
+                    sa[j].cin = 32 << j;
+                    if (op.mlayer[j] < 0) continue;              // level handled by a launch of its own: npix = 0 -> no blocks
+                    const HostLayer &L = h->layers[op.mlayer[j]];
+                    const std::string ls = std::to_string(j + 1);
                     sa[j].x = h->act[op.min_[j]]->p;
                     sa[j].w_s = dev_ptr(h, "sqg" + ls + "/w_s"); sa[j].b_s = dev_ptr(h, L.name + "/bias");
                     sa[j].w_g = dev_ptr(h, "sqg" + ls + "/w_g");
                     sa[j].out = h->act[op.mout[j]]->p;
                     sa[j].npix = (long long)n * op.mh[j] * op.mw[j]; sa[j].cin = L.cin;
                 }
-                e = launch_sqg_multi(sa[0], sa[1], sa[2], s);
+                e = launch_sqg_multi(sa, s);
                 break;
             }
             case OP_HEAD: {

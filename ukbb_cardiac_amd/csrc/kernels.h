@@ -97,8 +97,8 @@ struct SqgArgs {
     int cin;
 };
 hipError_t launch_sqg(const SqgArgs &a, hipStream_t s);
-struct SqgMultiArgs { SqgArgs lv[3]; int nb[3]; };   // levels 2, 3, 4 and their virtual grid sizes
-hipError_t launch_sqg_multi(const SqgArgs &l2, const SqgArgs &l3, const SqgArgs &l4, hipStream_t s);
+struct SqgMultiArgs { SqgArgs lv[4]; int nb[4]; };   // levels 1..4 (C_in 32, 64, 128, 256) and their virtual grid sizes
+hipError_t launch_sqg_multi(const SqgArgs lv[4], hipStream_t s);
 
 struct HeadArgs {
     const float *conv0;      // [N,H,W,16] level-0 features

@@ -23,6 +23,7 @@
 #include "kernels.h"
 
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <cstdio>
 #include <vector>
@@ -922,6 +923,7 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
             unsigned long long *o = reinterpret_cast<unsigned long long *>(const_cast<float *>(a.first_w)) + (size_t)blockIdx.x * 16;
             o[0] = __builtin_amdgcn_s_memtime() - st_t0; o[1] = __builtin_amdgcn_s_memrealtime() - st_r0;
             o[2] = st_wait; o[3] = st_mfma; o[4] = st_epi; o[5] = (unsigned long long)nstages;
+            o[6] = st_r0; o[7] = __builtin_amdgcn_s_memrealtime();
         }
 #endif
     }
@@ -1082,6 +1084,13 @@ hipError_t launch_conv(int cfg_id, const ConvArgs &a_in, hipStream_t s) {
             for (int w = 0; w < 1024; ++w) if (h[w * 16]) { ++n; for (int k = 0; k < 16; ++k) m[k] += (double)h[w * 16 + k]; }
             if (!n) return;
             for (int k = 0; k < 16; ++k) m[k] /= n;
+            unsigned long long s0 = ~0ull, s1 = 0, e0 = ~0ull, e1 = 0;
+            for (int w = 0; w < 1024; ++w) if (h[w * 16]) {
+                s0 = std::min(s0, h[w * 16 + 6]); s1 = std::max(s1, h[w * 16 + 6]);
+                e0 = std::min(e0, h[w * 16 + 7]); e1 = std::max(e1, h[w * 16 + 7]);
+            }
+            fprintf(stderr, "[stamps cfg %d] workgroup start spread %.2f us, end spread %.2f us, first start -> last end %.2f us, mean lifetime %.2f us\n",
+                    cfg, (s1 - s0) * 0.01, (e1 - e0) * 0.01, (e1 - s0) * 0.01, m[1] * 0.01);
             fprintf(stderr, "[stamps cfg %d] %d WGs: consumer total %.0f cyc (%.2f GHz), stages %.1f: per stage barrier-wait %.0f, mfma %.0f; epilogue total %.0f | "
                             "producer total %.0f, barrier-wait %.0f per stage, store(+vmcnt wait) %.0f per stage, straight %.0f\n",
                     cfg, n, m[0], m[0] / (m[1] * 10.0) , m[5], m[2] / m[5], m[3] / m[5], m[4], m[8], m[9] / m[5], m[10] / m[5], m[11]);

@@ -220,23 +220,27 @@ __device__ __forceinline__ void sqg_stream_body(const SqgArgs &a, int vblock, in
 template <int CIN>
 __global__ __launch_bounds__(256) void sqg_stream_kernel(const SqgArgs a) { sqg_stream_body<CIN>(a, blockIdx.x, gridDim.x); }
 
-// Levels 2-4 in ONE launch (C_in = 64, 128, 256): together they are a tenth of level 1's work, and three
-// separate launches were dominated by launch ramp and tail (13-25 us each for 2-9 us of work).
+// Levels 1-4 in ONE launch (C_in = 32, 64, 128, 256).  Levels 2-4 together are a tenth of level 1's work and as
+// launches of their own were dominated by launch ramp and tail (13-25 us each for 2-9 us of work); level 1 is a pure
+// HBM stream (82 MB in, 164 MB out at batch 64).  r02: every launch of this network costs ~10 us of fixed time
+// (dispatch + first-load latency + tail, measured as 2 t(N=64) - t(N=128) per kernel), so the four go out together after
+// level 4: the small levels' blocks come first and finish inside the first microseconds of level 1's stream.
 __global__ __launch_bounds__(256) void sqg_multi_kernel(const SqgMultiArgs m) {
     const int b = blockIdx.x;
-    if (b < m.nb[0]) sqg_stream_body<64>(m.lv[0], b, m.nb[0]);
-    else if (b < m.nb[0] + m.nb[1]) sqg_body<128>(m.lv[1], b - m.nb[0], m.nb[1]);
-    else sqg_body<256>(m.lv[2], b - m.nb[0] - m.nb[1], m.nb[2]);
+    const int e1 = m.nb[1], e2 = e1 + m.nb[2], e3 = e2 + m.nb[3];
+    if (b < e1) sqg_stream_body<64>(m.lv[1], b, m.nb[1]);
+    else if (b < e2) sqg_body<128>(m.lv[2], b - e1, m.nb[2]);
+    else if (b < e3) sqg_body<256>(m.lv[3], b - e2, m.nb[3]);
+    else sqg_stream_body<32>(m.lv[0], b - e3, m.nb[0]);
 }
 
-hipError_t launch_sqg_multi(const SqgArgs &l2, const SqgArgs &l3, const SqgArgs &l4, hipStream_t s) {
-    if (l2.cin != 64 || l3.cin != 128 || l4.cin != 256) return hipErrorInvalidValue;
+hipError_t launch_sqg_multi(const SqgArgs lv[4], hipStream_t s) {
+    if (lv[0].cin != 32 || lv[1].cin != 64 || lv[2].cin != 128 || lv[3].cin != 256) return hipErrorInvalidValue;
     SqgMultiArgs m;
-    const SqgArgs *lv[3] = {&l2, &l3, &l4};
     int total = 0;
-    for (int i = 0; i < 3; ++i) {
-        m.lv[i] = *lv[i];
-        long long wg = ((lv[i]->npix + 31) / 32 + 3) / 4;
+    for (int i = 0; i < 4; ++i) {
+        m.lv[i] = lv[i];
+        long long wg = ((lv[i].npix + 31) / 32 + 3) / 4;
         if (wg > 2048) wg = 2048;
         m.nb[i] = (int)wg;
         total += m.nb[i];
