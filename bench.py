@@ -151,6 +151,36 @@ def cpu_baseline():
     return out
 
 
+def inflight_probe(arch, params, x, n, steps):
+    """Reported beside the headline, never as it: the same K steps with TWO batches in flight (two engines = two
+    activation workspaces, two HIP streams, steps alternating).  Each of the ~14 launches of a step pays ~10 us of fixed
+    time (dispatch, per-XCD L2 write-back between dependent kernels, first-load latency, tail; profiles/r02_notes.md);
+    a second stream fills those holes.  The headline stays single-stream so that its per-kernel HIP-event / rocprof
+    durations are those of a kernel that owns the GPU."""
+    import torch
+    from ukbb_cardiac_amd.engine import Engine
+    engs = [Engine(arch, params, device=x.device.index) for _ in range(2)]
+    streams = [torch.cuda.Stream(x.device) for _ in range(2)]
+    preds = [torch.empty((n, H, W), dtype=torch.int32, device=x.device) for _ in range(2)]
+    for e in engs:
+        e.reserve(n, H, W)
+
+    def step(i):
+        engs[i & 1].run_device(x.data_ptr(), n, H, W, pred_ptr=preds[i & 1].data_ptr(), stream=streams[i & 1].cuda_stream)
+    for i in range(4):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    for e in engs:
+        e.close()
+    return {'value': round(n * steps / dt, 1), 'unit': 'slices/s', 'ms_per_step': round(dt / steps * 1e3, 4),
+            'note': 'same workload, two batches in flight on two HIP streams (two workspaces); not the headline'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -163,6 +193,10 @@ def main():
                          'profiles/r*_pmc_traffic.json whose kernel_source_sha matches the sources in this tree')
     ap.add_argument('--no-kernel-events', action='store_true',
                     help='do not bracket kernels with HIP events in the timed region (roofline becomes null)')
+    ap.add_argument('--inflight-probe', action='store_true',
+                    help='after the timed region also measure the same steps with two batches in flight on two streams '
+                         '(extra field two_batches_in_flight; off by default so that a rocprofv3 trace of the default command '
+                         'holds single-stream launches only)')
     ap.add_argument('--cpu-leg', choices=['torch', 'c'], default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_leg:
@@ -309,6 +343,8 @@ def main():
         }
         if detail:
             out['roofline_detail'] = detail
+        if world == 1 and args.inflight_probe:
+            out['two_batches_in_flight'] = inflight_probe(arch, params, x, n, args.steps)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)
