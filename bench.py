@@ -215,11 +215,19 @@ def main():
                      '(WORLD_SIZE is %d)' % (args.gpus, args.gpus, world))
     if not torch.cuda.is_available():
         sys.exit('bench.py needs a GPU: the HIP path has no CPU fallback')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # More ranks than visible GPUs only happens in the 1-GPU rehearsal of the N > 1 launch (tests/test_deploy_gpu.py):
+    # ranks then share devices and synchronise over gloo (RCCL refuses two ranks on one GPU); the line says so.
+    ndev = torch.cuda.device_count()
+    oversub = world > ndev
+    dev_index = local_rank % ndev if oversub else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if oversub:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from ukbb_cardiac_amd.arch import MODELS, fcn_macs_per_slice
     from ukbb_cardiac_amd.engine import Engine
@@ -228,7 +236,7 @@ def main():
 
     arch = MODELS['FCN_sa']
     params = synthetic_params(arch, 1234)
-    eng = Engine(arch, params, device=local_rank)
+    eng = Engine(arch, params, device=dev_index)
     n = args.batch
     x = torch.from_numpy(uniform_slices(n, H, W, seed=1 + rank)).to(dev)
     pred = torch.empty((n, H, W), dtype=torch.int32, device=dev)
@@ -270,7 +278,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if oversub else dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed_max = float(t.item())
@@ -335,7 +343,8 @@ def main():
             'config': {'workload': 'short-axis FCN (FCN_sa, 4 classes) inference, batch=%d synthetic 192x208 slices '
                                    'per GPU resident in HBM, int32 label map out (BASELINE.json configs[1])' % n,
                        'slices_per_gpu_per_step': n, 'height': H, 'width': W, 'weights': 'synthetic seed 1234',
-                       'parallelism': 'batch split x%d, no collectives' % world},
+                       'parallelism': 'batch split x%d, no collectives' % world + (
+                           ' (REHEARSAL: %d ranks share %d GPU(s), gloo barrier; not a scaling measurement)' % (world, ndev) if oversub else '')},
             # whole step priced with the reference graph's 3.0965 GFLOP per slice: "effective", not a utilisation
             'e2e_effective_tflops_reference_graph': round(value * flops_per_slice / 1e12, 2),
             'e2e_effective_frac_reference_graph': round(value * flops_per_slice / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world), 4),

@@ -172,3 +172,27 @@ def test_integration_md_hipsession_snippet(tmp_path):
     with pytest.raises(RuntimeError):
         with ns['HipSession'](mp, lib=_lib.LIB_PATH) as sess:
             sess.run('pred:0', feed_dict={'image:0': np.zeros((1, 30, 32, 1), np.float32)})   # not a multiple of 16
+
+
+# ---- the N > 1 bench launch, rehearsed on the one visible GPU ---------------------------------------------------
+def test_bench_two_rank_launch_rehearsal():
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` exactly as the driver launches it.  With one
+    GPU both ranks share it (gloo barrier instead of RCCL, flagged in the line): what is checked is the launch contract --
+    env-driven ranks, one JSON line from rank 0 only, n_gpus = 2, value = slices of BOTH ranks over the max-over-ranks time."""
+    import json
+    port = 29600 + os.getpid() % 300
+    r = _run(['-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
+              os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2', '--no-cpu-baseline'])
+    assert r.returncode == 0, r.stdout[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['steps'] == 4 and j['scaling'] == 'weak' and j['config']['slices_per_gpu_per_step'] == 64
+    assert abs(j['value'] - 2 * 64 * 4 / (j['ms_per_step'] * 4e-3)) <= 0.01 * j['value']
+    assert 'cpu_baseline' not in j                        # rank 0 at N = 1 only
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert 'REHEARSAL' in j['config']['parallelism']
+    # a mismatch between --gpus and the launched world size is refused
+    bad = _run([os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'])
+    assert bad.returncode != 0 and 'torch.distributed.run' in bad.stdout
