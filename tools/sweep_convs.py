@@ -1,4 +1,5 @@
-"""Time given (layer:cfg) pairs on the bench workload (GPU box):  python tools/sweep_convs.py conv2_0:124,127 conv3_0:124,126 ..."""
+"""Time given (layer:cfg) pairs on the bench workload (GPU box):  python tools/sweep_convs.py conv2_0:124,127 conv3_0:124,126 ...
+   MODEL=UNet_ao SHAPE=100,256,256 selects another model / batch shape."""
 import os
 import sys
 
@@ -9,7 +10,7 @@ if __name__ == '__main__':
     from ukbb_cardiac_amd.arch import MODELS
     from ukbb_cardiac_amd.engine import Engine
     from ukbb_cardiac_amd.weights import synthetic_params
-    arch = MODELS['FCN_sa']
+    arch = MODELS[os.environ.get('MODEL', 'FCN_sa')]
     params = synthetic_params(arch, 1234)
     n, h, w = (int(v) for v in os.environ.get('SHAPE', '64,192,208').split(','))
     x = torch.rand((n, h, w, 1), device='cuda')

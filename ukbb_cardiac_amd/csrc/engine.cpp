@@ -263,16 +263,18 @@ int override_cfg(const std::string &layer) {
 // reference's own per-frame call, deploy_network.py:103-111: there the persistent kernels have fewer work
 // items than CUs, and tilings with smaller channel groups / tiles win).  Other image sizes of the same layer
 // type reuse the entry (e.g. the long-axis models at 176x208).
-struct Tuned { int ks, stride, cin, cout, cfg; };
+struct Tuned { int ks, stride, cin, cout, cfg, alt; };   // alt (or -1): used when cfg's tiles do not divide the map and alt's do
 const Tuned g_tuned_large[] = {
-    {3, 1, 16, 16, 11}, {3, 2, 16, 32, 120},  {3, 1, 32, 32, 301},
-    {3, 2, 32, 64, 124},  {3, 1, 64, 64, 300},  {3, 2, 64, 128, 124},
-    {3, 1, 128, 128, 300},  {3, 2, 128, 256, 124}, {3, 1, 256, 256, 300},
-};      // r02: the stride-2 layers moved to the producer/consumer kernel once its loads ran two stages ahead (profiles/r02_notes.md)
+    {3, 1, 16, 16, 11, -1}, {3, 2, 16, 32, 120, 123},  {3, 1, 32, 32, 301, -1},
+    {3, 2, 32, 64, 124, 123},  {3, 1, 64, 64, 300, -1},  {3, 2, 64, 128, 124, 123},
+    {3, 1, 128, 128, 300, -1},  {3, 2, 128, 256, 124, 123}, {3, 1, 256, 256, 300, -1},
+};      // r02: the stride-2 layers moved to the producer/consumer kernel once its loads ran two stages ahead (profiles/r02_notes.md);
+        // its straight-line producer needs tiles that divide the map: 12x13 tiles for the 192x208 pyramid, 8x16 (123) for the
+        // power-of-two maps of the aortic U-Net (256x256: 148 / 143 / 133 / 136 us instead of 184 / 208 / 159 / 156 at N = 100)
 const Tuned g_tuned_small[] = {
-    {3, 1, 16, 16, 11}, {3, 2, 16, 32, 29},  {3, 1, 32, 32, 301},
-    {3, 2, 32, 64, 20},  {3, 1, 64, 64, 300},  {3, 2, 64, 128, 123},
-    {3, 1, 128, 128, 301},  {3, 2, 128, 256, 26}, {3, 1, 256, 256, 301},
+    {3, 1, 16, 16, 11, -1}, {3, 2, 16, 32, 29, -1},  {3, 1, 32, 32, 301, -1},
+    {3, 2, 32, 64, 20, -1},  {3, 1, 64, 64, 300, -1},  {3, 2, 64, 128, 123, -1},
+    {3, 1, 128, 128, 301, -1},  {3, 2, 128, 256, 26, -1}, {3, 1, 256, 256, 301, -1},
 };
 constexpr int SMALL_BATCH = 16;
 // The small-batch table is opt-in (UKBB_SMALL_BATCH_TILINGS=1; +30 % at N = 10): with it the tiling, and so
@@ -315,6 +317,7 @@ int wino_orient(int id, int Ho, int Wo) {
 
 int choose_cfg_raw(const std::string &layer, int ks, int stride, int c0, int c1, int cout, int Ho, int Wo, int N,
                    bool fused_first, bool want_bf16);
+int find_cfg(int id, ConvConfig &out);
 
 int choose_cfg(const std::string &layer, int ks, int stride, int c0, int c1, int cout, int Ho, int Wo, int N,
                bool fused_first = false, bool want_bf16 = false) {
@@ -350,11 +353,22 @@ int choose_cfg_raw(const std::string &layer, int ks, int stride, int c0, int c1,
         const size_t ntab = small ? sizeof(g_tuned_small) / sizeof(Tuned) : sizeof(g_tuned_large) / sizeof(Tuned);
         for (size_t j = 0; j < ntab; ++j) {
             const Tuned &t = tab[j];
-            if (t.ks == ks && t.stride == stride && t.cin == c0 && t.cout == cout)
-                for (int i = 0; i < num_conv_configs(); ++i)
-                    if (conv_config(i).id == t.cfg && cfg_valid(conv_config(i), ks, stride, c0, c1, cout) &&
-                        tile_fit_ok(conv_config(i), Ho, Wo)) return t.cfg;
+            if (t.ks == ks && t.stride == stride && t.cin == c0 && t.cout == cout) {
+                ConvConfig cm, ca;
+                const bool main_ok = find_cfg(t.cfg, cm) == 0 && cfg_valid(cm, ks, stride, c0, c1, cout) && tile_fit_ok(cm, Ho, Wo);
+                const bool alt_ok = t.alt >= 0 && find_cfg(t.alt, ca) == 0 && cfg_valid(ca, ks, stride, c0, c1, cout) && tile_fit_ok(ca, Ho, Wo);
+                const bool main_div = main_ok && Ho % cm.th == 0 && Wo % cm.tw == 0;
+                if (alt_ok && !main_div && Ho % ca.th == 0 && Wo % ca.tw == 0) return t.alt;
+                if (main_ok) return t.cfg;
+                if (alt_ok) return t.alt;
+            }
         }
+    }
+    if (!fused_first && c1 > 0 && ks == 3 && stride == 1 && cout == 32) {
+        // skip-concat conv of the U-Net's level 1 (network_ao.py:51-53, 32 + 32 -> 32): the two-source Winograd kernel in its
+        // 32-channel form (r02 sweep at 256x256, N = 100: 345 us against 544 for the best direct tiling)
+        ConvConfig cw;
+        if (find_cfg(301, cw) == 0 && cfg_valid(cw, ks, stride, c0, c1, cout) && tile_fit_ok(cw, Ho, Wo)) return 301;
     }
     double best = 1e300;
     int best_id = -1;

@@ -173,6 +173,21 @@ __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM,
 #pragma unroll
             for (int r = 0; r < M::NACC; ++r) acc[cb][pb][r] = 0.f;
 
+    // Sub-pixel form of the 3x3 stride-2 transposed conv (up2 > 0, KS = 2): output phase (py, px) of a Cout block uses
+    // tap (a, b) of the 2x2 window only if (py == 0 || a == 1) && (px == 0 || b == 1) -- 9 of the 16 (tap, phase) pairs;
+    // the other 7 hold zero weights (kernels.h, tconv_as_conv2x2) and their MFMAs are skipped (wave-uniform test).
+    unsigned tapmask[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        tapmask[cb] = 0xffffffffu;
+        if (KS == 2 && a.up2 > 0) {
+            const int ph = ((cbg + cb) * MB) / a.up2, py = ph >> 1, px = ph & 1;
+            tapmask[cb] = 0;
+            for (int t = 0; t < 4; ++t)
+                if ((py == 0 || (t >> 1) == 1) && (px == 0 || (t & 1) == 1)) tapmask[cb] |= 1u << t;
+        }
+    }
+
     const int nchunk = (a.C0 + a.C1) / KC;
     const int iy0 = oy0 * STRIDE - a.pad_y, ix0 = ox0 * STRIDE - a.pad_x;
     const int c4 = tid % C4, pix0 = tid / C4;           // this thread's channel quad / first halo pixel
@@ -257,9 +272,20 @@ __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM,
                     for (int pb = 0; pb < PBW; ++pb)
 #pragma unroll
                         for (int cb = 0; cb < CB; ++cb) {
+                            if (KS == 2 && !((tapmask[cb] >> t) & 1)) continue;
                             const f32x4 af = {av[t & 1][cb][0], av[t & 1][cb][1], av[t & 1][cb][2], av[t & 1][cb][3]};
                             const f32x4 bf = {bv[t & 1][pb][0], bv[t & 1][pb][1], bv[t & 1][pb][2], bv[t & 1][pb][3]};
                             acc[cb][pb] = mfma_bf16(af, bf, acc[cb][pb]);
+                        }
+                } else if constexpr (KS == 2) {
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb)
+                        if ((tapmask[cb] >> t) & 1) {
+#pragma unroll
+                            for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+                                for (int pb = 0; pb < PBW; ++pb)
+                                    acc[cb][pb] = M::run(av[t & 1][cb][s], bv[t & 1][pb][s], acc[cb][pb]);
                         }
                 } else {
 #pragma unroll
