@@ -23,7 +23,7 @@ if __name__ == '__main__':
     pred = torch.empty((F, H, W), dtype=torch.int32, device='cuda')
 
     def step():
-        _lib.check(_lib.lib.ukbb_fcn_forward_cine(eng._h, C.c_void_p(x.data_ptr()), F, H, W, 5, 0.1, C.c_void_p(prob.data_ptr()),
+        _lib.check(_lib.lib.ukbb_fcn_forward_cine(eng._h, C.c_void_p(x.data_ptr()), F, H, W, 5, 0.1, 1, C.c_void_p(prob.data_ptr()),
                                                   C.c_void_p(pred.data_ptr()), None), 'forward_cine')
     for _ in range(2):
         step()
