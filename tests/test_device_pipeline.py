@@ -146,3 +146,44 @@ def test_drop_in_script_writes_identical_files_with_and_without_device_preproc(t
                       ('seg_sa.nii.gz', 'sa_ED.nii.gz', 'sa_ES.nii.gz', 'seg_sa_ED.nii.gz', 'seg_sa_ES.nii.gz')}
     for f in outs['host']:
         assert outs['device'][f] == outs['host'][f], f
+
+
+@pytest.mark.gpu
+def test_subject_pipeline_equals_sequential_device_path():
+    """subject_pipeline.SubjectPipeline (pinned staging pool, copy-in / compute / copy-out streams, several subjects in
+    flight) returns, subject by subject and in order, exactly what the one-at-a-time device path returns: labels, per-frame
+    class counts, clip bounds; staged inputs (what nifti.load(alloc=...) fills) and plain arrays are both accepted."""
+    from ukbb_cardiac_amd.phantom import cine_phantom
+    from ukbb_cardiac_amd.subject_pipeline import SubjectPipeline, labels_as_float64
+    eng = _engine()
+    shapes = [(162, 204, 2, 3), (160, 200, 2, 3), (162, 204, 2, 3), (130, 204, 1, 5), (162, 204, 2, 3)]
+    vols = []
+    for i, (X, Y, Z, T) in enumerate(shapes):
+        v = cine_phantom(Z * T, X, Y, seed=40 + i)[..., 0].reshape(T, Z, X, Y).transpose(2, 3, 1, 0) * (900.0 + 50 * i)
+        vols.append(np.asfortranarray(v.astype(np.float32)))
+    want = [dp.segment_sequence_device(v, eng, batch_slices=5, return_aux=True) for v in vols]
+    pipe = SubjectPipeline(eng, (162, 204, 2, 3), batch_slices=5, depth=3, extra_inputs=2)
+
+    def source():
+        for i, v in enumerate(vols):
+            if i % 2 == 0:
+                st = pipe.stage(v.shape)                   # a reader thread's view: fill the pinned buffer in place
+                st.array[...] = v
+                yield st.array
+            else:
+                yield v                                    # plain array: copied into a pinned buffer by submit()
+    n = 0
+    for res, (w_pred, w_aux) in zip(pipe.run(source()), want):
+        assert res.labels.dtype == np.uint8 and res.labels.shape == w_pred.shape
+        np.testing.assert_array_equal(labels_as_float64(res.labels), w_pred)
+        np.testing.assert_array_equal(res.counts, w_aux['counts'])
+        assert res.clip == w_aux['clip']
+        np.testing.assert_array_equal(res.image, vols[n])  # the staged volume is still there for the ED / ES frames
+        n += 1
+    assert n == len(vols) and pipe.pending() == 0
+    assert pipe._in_free.qsize() == 5                      # every pinned input buffer came back
+    with pytest.raises(ValueError):
+        pipe.stage((400, 400, 10, 50))                     # larger than the staging buffers
+    with pytest.raises(TypeError):
+        pipe.stage((10, 10, 1, 1), np.float64)
+    eng.close()
