@@ -263,18 +263,19 @@ int override_cfg(const std::string &layer) {
 // reference's own per-frame call, deploy_network.py:103-111: there the persistent kernels have fewer work
 // items than CUs, and tilings with smaller channel groups / tiles win).  Other image sizes of the same layer
 // type reuse the entry (e.g. the long-axis models at 176x208).
-struct Tuned { int ks, stride, cin, cout, cfg, alt; };   // alt (or -1): used when cfg's tiles do not divide the map and alt's do
+struct Tuned { int ks, stride, cin, cout, cfg, alt, alt2; };   // alt / alt2 (or -1): the first of the three whose tiles divide the map wins
 const Tuned g_tuned_large[] = {
-    {3, 1, 16, 16, 11, -1}, {3, 2, 16, 32, 120, 123},  {3, 1, 32, 32, 301, -1},
-    {3, 2, 32, 64, 124, 123},  {3, 1, 64, 64, 300, -1},  {3, 2, 64, 128, 124, 123},
-    {3, 1, 128, 128, 300, -1},  {3, 2, 128, 256, 124, 123}, {3, 1, 256, 256, 300, -1},
+    {3, 1, 16, 16, 11, -1, -1}, {3, 2, 16, 32, 120, 123, -1},  {3, 1, 32, 32, 301, -1, -1},
+    {3, 2, 32, 64, 124, 123, 142},  {3, 1, 64, 64, 300, -1, -1},  {3, 2, 64, 128, 124, 123, 142},
+    {3, 1, 128, 128, 300, -1, -1},  {3, 2, 128, 256, 124, 123, 142}, {3, 1, 256, 256, 300, -1, -1},
 };      // r02: the stride-2 layers moved to the producer/consumer kernel once its loads ran two stages ahead (profiles/r02_notes.md);
         // its straight-line producer needs tiles that divide the map: 12x13 tiles for the 192x208 pyramid, 8x16 (123) for the
-        // power-of-two maps of the aortic U-Net (256x256: 148 / 143 / 133 / 136 us instead of 184 / 208 / 159 / 156 at N = 100)
+        // power-of-two maps of the aortic U-Net (256x256: 148 / 143 / 133 / 136 us instead of 184 / 208 / 159 / 156 at N = 100),
+        // 11x13 (142) for the long-axis models' 176x208 pyramid (88x104, 44x52, 22x26, 11x13)
 const Tuned g_tuned_small[] = {
-    {3, 1, 16, 16, 11, -1}, {3, 2, 16, 32, 29, -1},  {3, 1, 32, 32, 301, -1},
-    {3, 2, 32, 64, 20, -1},  {3, 1, 64, 64, 300, -1},  {3, 2, 64, 128, 123, -1},
-    {3, 1, 128, 128, 301, -1},  {3, 2, 128, 256, 26, -1}, {3, 1, 256, 256, 301, -1},
+    {3, 1, 16, 16, 11, -1, -1}, {3, 2, 16, 32, 29, -1, -1},  {3, 1, 32, 32, 301, -1, -1},
+    {3, 2, 32, 64, 20, -1, -1},  {3, 1, 64, 64, 300, -1, -1},  {3, 2, 64, 128, 123, -1, -1},
+    {3, 1, 128, 128, 301, -1, -1},  {3, 2, 128, 256, 26, -1, -1}, {3, 1, 256, 256, 301, -1, -1},
 };
 constexpr int SMALL_BATCH = 16;
 // The small-batch table is opt-in (UKBB_SMALL_BATCH_TILINGS=1; +30 % at N = 10): with it the tiling, and so
@@ -354,13 +355,15 @@ int choose_cfg_raw(const std::string &layer, int ks, int stride, int c0, int c1,
         for (size_t j = 0; j < ntab; ++j) {
             const Tuned &t = tab[j];
             if (t.ks == ks && t.stride == stride && t.cin == c0 && t.cout == cout) {
-                ConvConfig cm, ca;
-                const bool main_ok = find_cfg(t.cfg, cm) == 0 && cfg_valid(cm, ks, stride, c0, c1, cout) && tile_fit_ok(cm, Ho, Wo);
-                const bool alt_ok = t.alt >= 0 && find_cfg(t.alt, ca) == 0 && cfg_valid(ca, ks, stride, c0, c1, cout) && tile_fit_ok(ca, Ho, Wo);
-                const bool main_div = main_ok && Ho % cm.th == 0 && Wo % cm.tw == 0;
-                if (alt_ok && !main_div && Ho % ca.th == 0 && Wo % ca.tw == 0) return t.alt;
-                if (main_ok) return t.cfg;
-                if (alt_ok) return t.alt;
+                const int cand[3] = {t.cfg, t.alt, t.alt2};
+                int first_ok = -1;
+                for (int k = 0; k < 3; ++k) {
+                    ConvConfig cc;
+                    if (cand[k] < 0 || find_cfg(cand[k], cc) || !cfg_valid(cc, ks, stride, c0, c1, cout) || !tile_fit_ok(cc, Ho, Wo)) continue;
+                    if (Ho % cc.th == 0 && Wo % cc.tw == 0) return cand[k];      // tiles divide the map: straight-line producer applies
+                    if (first_ok < 0) first_ok = cand[k];
+                }
+                if (first_ok >= 0) return first_ok;
             }
         }
     }

@@ -1037,7 +1037,10 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
     Y(128, 3, 2, 16, 12, 13, 8, 4, 1, 1)             \
     Y(129, 3, 2, 16, 6, 13, 8, 4, 1, 2)              \
     Y(140, 3, 2, 32, 12, 13, 8, 4, 1, 1)             \
-    Y(141, 3, 2, 16, 12, 13, 8, 2, 2, 1)
+    Y(141, 3, 2, 16, 12, 13, 8, 2, 2, 1)             \
+    Y(142, 3, 2, 16, 11, 13, 8, 2, 2, 2)             \
+    Y(143, 3, 2, 16, 8, 13, 16, 2, 2, 1)             \
+    Y(144, 3, 2, 16, 11, 13, 16, 2, 2, 1)
 
 // bf16-operand tilings (single-role kernel, MB = 32, KC = 16).  B(id, KS, STRIDE, TH, TW, WM, WN, CB)
 #define UKBB_BF_CONFIGS(B)                 \
