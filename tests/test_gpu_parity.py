@@ -178,6 +178,21 @@ def test_config3_shapes_vs_c_oracle(engines, parity_log, model, shape):
     _grade_vs_c_oracle(engines(model), arch, synthetic_params(arch, 1234), img, parity_log)
 
 
+def test_full_batch64_slices_equal_single_slice_runs(engines):
+    """At the bench batch every workgroup of the stride-2 layers has enough stages for the straight-line producer
+    (loads two stages ahead, last halo column / rows below the image through buffer-descriptor ranges); a slice run
+    alone takes the generic producer (per-lane range tests).  Same tiling, same consumer arithmetic: the logits of a
+    slice must be bit-identical either way -- first, last and a middle slice of the batch, borders included."""
+    from ukbb_cardiac_amd.phantom import cine_phantom
+    eng = engines('FCN_sa')
+    img = cine_phantom(64, 192, 208, seed=77)
+    full = eng.run(img, want_logits=True, want_prob=False)
+    for i in (0, 31, 63):
+        one = eng.run(img[i:i + 1], want_logits=True, want_prob=False)
+        assert np.array_equal(one['logits'][0], full['logits'][i]), i
+        assert np.array_equal(one['pred'][0], full['pred'][i]), i
+
+
 def test_full_batch64_properties(engines):
     """N=64 x 192 x 208 (the bench workload): shift-of-batch invariance and
     label histogram consistency between device pred and device logits."""
