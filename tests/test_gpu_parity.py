@@ -178,6 +178,18 @@ def test_config3_shapes_vs_c_oracle(engines, parity_log, model, shape):
     _grade_vs_c_oracle(engines(model), arch, synthetic_params(arch, 1234), img, parity_log)
 
 
+@pytest.mark.parametrize('shape', [(1, 1024, 1024), (3, 272, 304), (2, 16, 16), (5, 48, 400)])
+def test_unusual_sizes_vs_c_oracle(engines, parity_log, shape):
+    """Sizes the reference never pads to but accepts (any multiple of 16, deploy_network.py:97): a 1024 x 1024 slice (2048
+    stride-2 tiles per image: the straight-line producer with 8x16 tiles), shapes whose pyramids no tiling divides, the
+    smallest legal image (one pixel at level 4) and a very elongated one."""
+    from ukbb_cardiac_amd.arch import MODELS
+    from ukbb_cardiac_amd.phantom import cine_phantom
+    from ukbb_cardiac_amd.weights import synthetic_params
+    arch = MODELS['FCN_sa']
+    _grade_vs_c_oracle(engines('FCN_sa'), arch, synthetic_params(arch, 1234), cine_phantom(*shape, seed=shape[1] + shape[2]), parity_log, chunk=2)
+
+
 def test_full_batch64_slices_equal_single_slice_runs(engines):
     """At the bench batch every workgroup of the stride-2 layers has enough stages for the straight-line producer
     (loads two stages ahead, last halo column / rows below the image through buffer-descriptor ranges); a slice run
