@@ -1,5 +1,6 @@
+"""Throughput of the bench workload with 1, 2 and 3 batches in flight (one engine + one HIP stream each).  GPU box only."""
 import os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ukbb_cardiac_amd.arch import MODELS
 from ukbb_cardiac_amd.engine import Engine

@@ -1,5 +1,7 @@
+"""Winograd kernel phase stamps (diagnostic build: make EXTRA=-DUKBB_WINO_STAMPS): prints, per Winograd layer of one forward,
+producer / consumer cycles per stage; UKBB_CONV_DIAG=32 additionally drops the output stores.  GPU box only."""
 import os, sys
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ukbb_cardiac_amd.arch import MODELS
 from ukbb_cardiac_amd.engine import Engine
