@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define UKBB_FCN_ABI_VERSION 2
+#define UKBB_FCN_ABI_VERSION 3
 #define UKBB_FCN_MAX_LEVEL 8
 
 #define UKBB_OK 0
@@ -161,6 +161,29 @@ int ukbb_fcn_rescale_pack(const float *d_vol, int X, int Y, int Z, int T, int64_
  * common/deploy_network.py:125-130 sums).  Replaces :114-116.  n_class <= 16. */
 int ukbb_fcn_unpack_labels(const int32_t *d_pred, int X, int Y, int Z, int T, int X2, int Y2, int x_pre, int y_pre, int n_class,
                            uint8_t *d_vol, uint64_t *d_counts, void *stream);
+
+/* -- the aortic z-score, common/image_utils.py:60-67 (normalise_intensity), bit-identical to numpy ----------------
+ * np.mean / np.std over image[roi] are float32 PAIRWISE sums over the compressed array; the three calls below
+ * reproduce numpy's summation tree rather than just its value (ukbb_cardiac_amd/device_pipeline.py
+ * device_zscore_stats shows the sequence, including the percentile threshold from ukbb_fcn_select_kth). */
+
+/* d_out[i] = the i-th element >= thr of the (X,Y,Z,T) float32 volume with element strides (sx,sy,sz,st), in
+ * row-major INDEX order (last index fastest: the order of numpy's image[image >= thr]).  d_out holds up to
+ * X*Y*Z*T floats; *n_host receives the count.  Synchronous. */
+int ukbb_fcn_roi_compact(const float *d_vol, int X, int Y, int Z, int T, int64_t sx, int64_t sy, int64_t sz, int64_t st, float thr,
+                         float *d_out, uint64_t *n_host, void *stream);
+
+/* *sum_host = np.add.reduce over the n contiguous float32 values at d_a (squared_dev = 0) or over
+ * (d_a[i] - mean)^2 evaluated in float32 (squared_dev = 1, the inner sum of np.var), with numpy's pairwise
+ * summation order (blocks of <= 128 elements on 8 interleaved accumulators, halves split at a multiple of 8, one
+ * such tree per 8192-element buffer of numpy's reduction iterator [np.getbufsize() default], buffers added in
+ * sequence): every leaf block is summed by one device thread, the host adds the leaves up.  Synchronous. */
+int ukbb_fcn_pairwise_sum(const float *d_a, uint64_t n, int squared_dev, float mean, float *sum_host, void *stream);
+
+/* ukbb_fcn_rescale_pack with the z-score arithmetic: d_batch[t*Z+z][X2][Y2] = (v - mu) / den in float32 (IEEE
+ * division), zero padding around it.  Replaces image_utils.py:67 + deploy_network_ao.py:105-108,147-150. */
+int ukbb_fcn_zscore_pack(const float *d_vol, int X, int Y, int Z, int T, int64_t sx, int64_t sy, int64_t sz, int64_t st,
+                         float mu, float den, int X2, int Y2, int x_pre, int y_pre, float *d_batch, void *stream);
 
 /* ---- measurement / introspection (bench.py, tests) ---------------------- */
 

@@ -187,3 +187,93 @@ def test_subject_pipeline_equals_sequential_device_path():
     with pytest.raises(TypeError):
         pipe.stage((10, 10, 1, 1), np.float64)
     eng.close()
+
+
+# ---- aortic z-score on the device (common/image_utils.py:60-67) -------------------------------------------------------
+
+@pytest.mark.parametrize('n', [1, 2, 3, 7, 100, 1001, 240 * 196 * 50])
+@pytest.mark.parametrize('q', [10.0, 1.0, 99.0, 50.0, 0.0, 100.0, 33.3])
+def test_host_half_of_scalar_percentile_matches_numpy(n, q):
+    """np.percentile(float32 array, Python scalar) stays in float32 (normalise_intensity calls it that way)."""
+    rng = np.random.default_rng(n + int(q * 10))
+    a = (rng.random(n) * rng.integers(1, 5000)).astype(np.float32)
+    s = np.sort(a)
+    k, k1, g = dp.scalar_percentile_ranks(n, q)
+    got = np.quantile(np.array([s[k], s[k1]], np.float32), g)
+    want = np.percentile(a, q)
+    assert got == want and type(got) is type(want)
+
+
+def _aortic_like(shape, seed, order='F'):
+    rng = np.random.default_rng(seed)
+    v = (rng.gamma(1.5, 120.0, size=shape)).astype(np.float32)
+    v[rng.random(shape) < 0.08] = 0.0                               # background ties at the bottom of the histogram
+    return np.asarray(np.round(v), dtype=np.float32, order=order)  # MR magnitudes are integers: many ties at the threshold
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape,order', [((37, 41, 3, 5), 'F'), ((37, 41, 3, 5), 'C'), ((240, 196, 1, 50), 'F'), ((5, 3, 1, 1), 'F')])
+def test_roi_compact_is_numpy_boolean_indexing(shape, order):
+    import ctypes as C
+    import torch
+    from ukbb_cardiac_amd import _lib
+    img = _aortic_like(shape, 3, order)
+    t = torch.from_numpy(img).cuda()
+    out = torch.full((img.size,), -1.0, dtype=torch.float32, device='cuda')
+    for thr in (np.percentile(img, 10.0), np.float32(-1.0), np.float32(1e9), np.float32(0.0)):
+        n = C.c_uint64(0)
+        sx, sy, sz, st = t.stride()
+        _lib.check(_lib.lib.ukbb_fcn_roi_compact(t.data_ptr(), *shape, sx, sy, sz, st, float(thr), out.data_ptr(), C.byref(n), 0), 'compact')
+        want = img[img >= thr]
+        assert n.value == want.size
+        np.testing.assert_array_equal(out.cpu().numpy()[:n.value], want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n', [1, 7, 8, 9, 127, 128, 129, 1000, 8191, 8192, 8193, 16385, 100003, 4233599])
+def test_pairwise_sum_is_numpy_add_reduce(n):
+    import ctypes as C
+    import torch
+    from ukbb_cardiac_amd import _lib
+    rng = np.random.default_rng(n)
+    a = (rng.random(n) * 1000).astype(np.float32)
+    t = torch.from_numpy(a).cuda()
+    s = C.c_float(0)
+    _lib.check(_lib.lib.ukbb_fcn_pairwise_sum(t.data_ptr(), n, 0, 0.0, C.byref(s), 0), 'sum')
+    assert np.float32(s.value) == np.add.reduce(a)
+    m = np.mean(a)
+    _lib.check(_lib.lib.ukbb_fcn_pairwise_sum(t.data_ptr(), n, 1, float(m), C.byref(s), 0), 'sumsq')
+    x = a - m
+    assert np.float32(s.value) == np.add.reduce(x * x)
+    _lib.check(_lib.lib.ukbb_fcn_pairwise_sum(t.data_ptr(), 0, 0, 0.0, C.byref(s), 0), 'empty')
+    assert s.value == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape,order,seed', [((240, 196, 1, 50), 'F', 1), ((208, 256, 1, 30), 'F', 2), ((61, 47, 2, 11), 'C', 3),
+                                              ((256, 256, 1, 20), 'F', 4), ((33, 250, 1, 9), 'F', 5)])
+def test_zscore_on_device_is_normalise_intensity(shape, order, seed):
+    """mu, sigma + eps and the packed network input bit for bit against image_utils.normalise_intensity + the pad /
+    transpose of deploy_network_ao.py:105-108,147-150."""
+    import torch
+    from ukbb_cardiac_amd import _lib
+    from ukbb_cardiac_amd.image_utils import normalise_intensity
+    from ukbb_cardiac_amd.pipeline import pad_amounts_fixed
+    img = _aortic_like(shape, seed, order)
+    X, Y, Z, T = shape
+    t = torch.from_numpy(img).cuda()
+    mu, den, n_roi, val_l = dp.device_zscore_stats(t, 10.0)
+    roi = img >= np.percentile(img, 10.0)
+    assert val_l == np.percentile(img, 10.0) and n_roi == int(roi.sum())
+    assert mu == np.mean(img[roi]) and type(mu) is np.float32
+    assert den == np.std(img[roi]) + 1e-6 and type(den) is np.float32
+    X2, Y2, x_pre, x_post, y_pre, y_post = pad_amounts_fixed(X, Y)
+    batch = torch.empty((T * Z, X2, Y2), dtype=torch.float32, device='cuda')
+    sx, sy, sz, st = t.stride()
+    _lib.check(_lib.lib.ukbb_fcn_zscore_pack(t.data_ptr(), X, Y, Z, T, sx, sy, sz, st, float(mu), float(den), X2, Y2, x_pre, y_pre,
+                                             batch.data_ptr(), 0), 'zscore_pack')
+    norm = normalise_intensity(img, 10.0)
+    assert norm.dtype == np.float32
+    padded = np.pad(norm, ((x_pre, x_post), (y_pre, y_post), (0, 0), (0, 0)), 'constant')
+    want = np.transpose(padded, (3, 2, 0, 1)).reshape(T * Z, X2, Y2)
+    np.testing.assert_array_equal(batch.cpu().numpy(), want)

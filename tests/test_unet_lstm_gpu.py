@@ -162,3 +162,43 @@ def test_drop_in_aortic_script_with_the_default_model(tmp_path, model):
     np.testing.assert_array_equal(seg, np.argmax(want, -1).astype(np.int32))
     with pytest.raises(SystemExit):                                        # a plain UNet flag on an LSTM model
         deploy_network_ao.main(['--seq_name', 'ao', '--data_dir', str(tmp_path / 'data'), '--model_path', mp, '--model', 'UNet'])
+
+
+@pytest.mark.parametrize('shape,time_step', [((70, 90, 1, 11), 1), ((240, 196, 1, 25), 1), ((64, 48, 2, 13), 2)])
+def test_aortic_device_pipeline_equals_host_pipeline(model, shape, time_step):
+    """z-score, pad, transposes, windows, argmax on the GPU (device_pipeline.aortic_lstm_sequence_device) against the numpy
+    mirror of deploy_network_ao.py:92-108,129-189 driven by the same engine: same probabilities bit for bit, same labels."""
+    from ukbb_cardiac_amd import pipeline
+    from ukbb_cardiac_amd.device_pipeline import aortic_lstm_sequence_device
+    arch, params, eng = model
+    rng = np.random.default_rng(shape[0] + time_step)
+    vol = np.asfortranarray(np.round(100 * rng.gamma(2.0, 1.0, size=shape)).astype(np.float32))
+    keep = vol.copy()
+    pred, aux = aortic_lstm_sequence_device(vol, eng, time_step=time_step, return_aux=True)
+    assert np.array_equal(vol, keep)                                       # input untouched
+    prob = pipeline.aortic_lstm_prob_sequence(vol, lambda f, R, r, ts=1: eng.run_cine(f, R, r, ts)[0], time_step=time_step)
+    np.testing.assert_array_equal(aux['prob'], prob)
+    want = np.argmax(prob, axis=-1).astype(np.int32)
+    assert pred.dtype == np.int32 and pred.shape == shape
+    np.testing.assert_array_equal(pred, want)
+    for c in range(arch.n_class):                                          # per-frame class areas (eval_aortic_area.py:60-78)
+        np.testing.assert_array_equal(aux['counts'][:, c], (want == c).sum(axis=(0, 1, 2)))
+    assert len(np.unique(pred)) > 1
+
+
+def test_aortic_script_device_and_host_preprocessing_write_the_same_file(tmp_path, model):
+    from ukbb_cardiac_amd import deploy_network_ao, nifti
+    from ukbb_cardiac_amd.weights import save_blob
+    arch, params, eng = model
+    mp = str(tmp_path / 'UNet-LSTM_ao')
+    save_blob(mp + '.ukbbw', arch, params)
+    rng = np.random.default_rng(77)
+    vol = np.round(100 * rng.gamma(2.0, 1.0, size=(96, 80, 1, 14))).astype(np.float32)
+    d = tmp_path / 'data' / 'subj1'
+    d.mkdir(parents=True)
+    nifti.save(vol, str(d / 'ao.nii.gz'), np.diag([1.6, 1.6, 6.0, 1.0]), pixdim=[1, 1.6, 1.6, 6, 0.01, 0, 0, 0])
+    out = {}
+    for flag in ('--device_preproc', '--nodevice_preproc'):
+        deploy_network_ao.main(['--data_dir', str(tmp_path / 'data'), '--model_path', mp, '--time_step', '2', flag])
+        out[flag] = (d / 'seg_ao.nii.gz').read_bytes()
+    assert out['--device_preproc'] == out['--nodevice_preproc']

@@ -12,7 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libukbb_fcn.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_LEVEL = 8
 
 # every symbol include/ukbb_fcn.h declares
@@ -23,6 +23,7 @@ EXPORTS = [
     'ukbb_fcn_kernel_times', 'ukbb_fcn_get_activation', 'ukbb_fcn_kernel_config', 'ukbb_fcn_conv_config_name',
     'ukbb_fcn_set_timing_kernel', 'ukbb_fcn_set_precision', 'ukbb_fcn_kernel_mfma_macs',
     'ukbb_fcn_select_kth', 'ukbb_fcn_rescale_pack', 'ukbb_fcn_unpack_labels',
+    'ukbb_fcn_roi_compact', 'ukbb_fcn_pairwise_sum', 'ukbb_fcn_zscore_pack',
     'ukbb_fcn_forward_seq', 'ukbb_fcn_forward_cine',
 ]
 
@@ -89,6 +90,11 @@ def _load():
                                           C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.ukbb_fcn_unpack_labels.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                            vp, vp, vp]
+    lib.ukbb_fcn_roi_compact.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_float,
+                                         vp, C.POINTER(C.c_uint64), vp]
+    lib.ukbb_fcn_pairwise_sum.argtypes = [vp, C.c_uint64, C.c_int, C.c_float, C.POINTER(C.c_float), vp]
+    lib.ukbb_fcn_zscore_pack.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                         C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.ukbb_fcn_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int, C.c_int]
     lib.ukbb_fcn_get_activation.restype = C.c_int64
     lib.ukbb_fcn_get_activation.argtypes = [vp, C.c_char_p, f32p, C.c_int64]

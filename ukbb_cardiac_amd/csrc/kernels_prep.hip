@@ -14,6 +14,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 #include "../../include/ukbb_fcn.h"
 #include "kernels.h"
@@ -170,6 +171,171 @@ __global__ __launch_bounds__(256) void unpack_labels_kernel(const int *__restric
         atomicAdd(&counts[(size_t)t * n_class + threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
 }
 
+// ---- aortic z-score (common/image_utils.py:60-67) on the device ------------------------------------------
+// normalise_intensity = percentile threshold -> ROI mask -> np.mean / np.std over image[roi] -> (image - mu) / (sigma + eps).
+// The two reductions are float32 PAIRWISE sums in numpy (add.reduce over the contiguous compressed array): to be bit-identical
+// the device reproduces numpy's summation tree, not just its value: (1) the ROI elements are compacted in numpy's order
+// (row-major index order of the (X,Y,Z,T) array, whatever its strides), (2) every leaf of the tree (<= 128 consecutive
+// elements, 8 interleaved accumulators, numpy's pairwise_sum) is summed by one thread in numpy's order, (3) the host adds the
+// leaf sums up the tree in the same order, one tree per 8192-element buffer of numpy's reduction iterator, buffers in sequence.  No FMA contraction (-ffp-contract=off), IEEE division.
+constexpr int CCH = 1024;                            // row-major indices per workgroup of the compaction kernels
+
+__device__ __forceinline__ float roi_elem(const float *vol, long long i, int Y, int Z, int T, long long sx, long long sy, long long sz, long long st) {
+    const int t = (int)(i % T); long long r = i / T;
+    const int z = (int)(r % Z); r /= Z;
+    const int y = (int)(r % Y); const long long x = r / Y;
+    return vol[x * sx + y * sy + z * sz + t * st];
+}
+
+__global__ __launch_bounds__(256) void roi_count_kernel(const float *__restrict__ vol, long long n, int Y, int Z, int T, long long sx, long long sy,
+                                                        long long sz, long long st, float thr, unsigned *__restrict__ counts) {
+    __shared__ unsigned wsum[4];
+    const long long i0 = (long long)blockIdx.x * CCH + threadIdx.x * 4;
+    unsigned c = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (i0 + k < n && roi_elem(vol, i0 + k, Y, Z, T, sx, sy, sz, st) >= thr) ++c;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// exclusive scan of nb block counts by one workgroup; offs[nb] = total
+__global__ __launch_bounds__(1024) void roi_scan_kernel(const unsigned *__restrict__ counts, int nb, unsigned long long *__restrict__ offs) {
+    __shared__ unsigned long long part[1024];
+    const int per = (nb + 1023) / 1024, b0 = threadIdx.x * per, b1 = b0 + per < nb ? b0 + per : nb;
+    unsigned long long s = 0;
+    for (int b = b0; b < b1; ++b) s += counts[b];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long run = 0;
+        for (int k = 0; k < 1024; ++k) { const unsigned long long v = part[k]; part[k] = run; run += v; }
+        offs[nb] = run;
+    }
+    __syncthreads();
+    unsigned long long run = part[threadIdx.x];
+    for (int b = b0; b < b1; ++b) { offs[b] = run; run += counts[b]; }
+}
+
+__global__ __launch_bounds__(256) void roi_write_kernel(const float *__restrict__ vol, long long n, int Y, int Z, int T, long long sx, long long sy,
+                                                        long long sz, long long st, float thr, const unsigned long long *__restrict__ offs,
+                                                        float *__restrict__ out) {
+    __shared__ unsigned wpre[4];
+    const long long i0 = (long long)blockIdx.x * CCH + threadIdx.x * 4;
+    float v[4];
+    bool keep[4];
+    unsigned c = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        keep[k] = false;
+        if (i0 + k < n) { v[k] = roi_elem(vol, i0 + k, Y, Z, T, sx, sy, sz, st); keep[k] = v[k] >= thr; }
+        c += keep[k];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned incl = c;                                   // inclusive scan inside the wave
+    for (int o = 1; o < 64; o <<= 1) { const unsigned u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+    if (lane == 63) wpre[wave] = incl;
+    __syncthreads();
+    unsigned base = 0;
+    for (int w = 0; w < wave; ++w) base += wpre[w];
+    unsigned long long pos = offs[blockIdx.x] + base + (incl - c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (keep[k]) out[pos++] = v[k];
+}
+
+// one thread = one leaf of numpy's pairwise summation tree (loops_utils.h.src, pairwise_sum with PW_BLOCKSIZE = 128)
+__global__ __launch_bounds__(128) void pairwise_leaf_kernel(const float *__restrict__ a, const unsigned long long *__restrict__ leaf_off,
+                                                            const unsigned *__restrict__ leaf_len, int nleaf, int sq, float mean,
+                                                            float *__restrict__ leaf_sum) {
+    const int l = blockIdx.x * 128 + threadIdx.x;
+    if (l >= nleaf) return;
+    const float *p = a + leaf_off[l];
+    const int n = (int)leaf_len[l];
+    auto val = [&](int i) { float v = p[i]; if (sq) { const float d = v - mean; v = d * d; } return v; };
+    float res;
+    if (n < 8) {
+        res = 0.f;
+        for (int i = 0; i < n; ++i) res += val(i);
+    } else {
+        float r0 = val(0), r1 = val(1), r2 = val(2), r3 = val(3), r4 = val(4), r5 = val(5), r6 = val(6), r7 = val(7);
+        int i = 8;
+        for (; i < n - (n % 8); i += 8) {
+            r0 += val(i); r1 += val(i + 1); r2 += val(i + 2); r3 += val(i + 3);
+            r4 += val(i + 4); r5 += val(i + 5); r6 += val(i + 6); r7 += val(i + 7);
+        }
+        res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+        for (; i < n; ++i) res += val(i);
+    }
+    leaf_sum[l] = res;
+}
+
+// (v - mu) / den in float32, centred zero padding, (X,Y,Z,T) -> [T*Z][X2][Y2]: rescale_pack_kernel with the z-score arithmetic
+__global__ __launch_bounds__(256) void zscore_pack_kernel(const float *__restrict__ vol, int X, int Y, int Z, int T,
+                                                          long long sx, long long sy, long long sz, long long st,
+                                                          float mu, float den, int X2, int Y2, int x_pre, int y_pre, float *__restrict__ out) {
+    __shared__ float tile[32][33];
+    const int tiles_x = (X2 + 31) / 32;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int b = blockIdx.y;
+    const int t = b / Z, z = b - t * Z;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int x2 = tx * 32 + lx, y2 = ty * 32 + ly + 8 * j;
+        const int x = x2 - x_pre, y = y2 - y_pre;
+        float r = 0.f;                                  // np.pad(..., 'constant') after the normalisation (deploy_network_ao.py:105-108)
+        if (x >= 0 && x < X && y >= 0 && y < Y) r = __fdiv_rn(vol[x * sx + y * sy + z * sz + t * st] - mu, den);
+        tile[ly + 8 * j][lx] = r;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int x2 = tx * 32 + ly + 8 * j, y2 = ty * 32 + lx;
+        if (x2 < X2 && y2 < Y2) out[((size_t)b * X2 + x2) * Y2 + y2] = tile[lx][ly + 8 * j];
+    }
+}
+
+struct Scratch {                                        // grow-only device scratch of this thread, per device
+    void *p = nullptr; size_t n = 0;
+    void *get(size_t bytes) {
+        if (bytes <= n) return p;
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+        if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+        n = bytes;
+        return p;
+    }
+};
+Scratch *prep_scratch(int which) {
+    static thread_local Scratch s[16][2];
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 16) return nullptr;
+    return &s[d][which];
+}
+
+// numpy's reduction iterator hands the inner loop at most one buffer of elements at a time (np.getbufsize(), 8192 by default)
+// even for a contiguous array: add.reduce = ((0 + pw(a[0:8192])) + pw(a[8192:16384])) + ...
+constexpr uint64_t NPY_BUFSIZE = 8192;
+
+void pairwise_leaves(unsigned long long off, unsigned long long n, std::vector<unsigned long long> &offs, std::vector<unsigned> &lens) {
+    if (n <= 128) { offs.push_back(off); lens.push_back((unsigned)n); return; }
+    unsigned long long n2 = n / 2;
+    n2 -= n2 % 8;
+    pairwise_leaves(off, n2, offs, lens);
+    pairwise_leaves(off + n2, n - n2, offs, lens);
+}
+float pairwise_combine(const float *leaf, size_t &idx, unsigned long long n) {
+    if (n <= 128) return leaf[idx++];
+    unsigned long long n2 = n / 2;
+    n2 -= n2 % 8;
+    const volatile float l = pairwise_combine(leaf, idx, n2);
+    const volatile float r = pairwise_combine(leaf, idx, n - n2);
+    return l + r;
+}
+
 SelState *sel_scratch() {
     static thread_local SelState *p[16] = {nullptr};
     int d = 0;
@@ -246,6 +412,77 @@ int ukbb_fcn_unpack_labels(const int32_t *d_pred, int X, int Y, int Z, int T, in
                        reinterpret_cast<unsigned long long *>(d_counts));
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("unpack_labels: launch failed: %s", hipGetErrorString(e)); return UKBB_EDEVICE; }
+    return UKBB_OK;
+}
+
+int ukbb_fcn_roi_compact(const float *d_vol, int X, int Y, int Z, int T, int64_t sx, int64_t sy, int64_t sz, int64_t st, float thr,
+                         float *d_out, uint64_t *n_host, void *stream) {
+    if (!d_vol || !d_out || !n_host || X < 1 || Y < 1 || Z < 1 || T < 1) { set_error("roi_compact: bad argument"); return UKBB_EINVAL; }
+    const long long n = (long long)X * Y * Z * T;
+    const int nb = (int)((n + CCH - 1) / CCH);
+    Scratch *sc = prep_scratch(0);
+    void *buf = sc ? sc->get((size_t)nb * 4 + 8 + ((size_t)nb + 1) * 8) : nullptr;
+    if (!buf) { set_error("roi_compact: scratch allocation failed"); return UKBB_ENOMEM; }
+    unsigned *counts = static_cast<unsigned *>(buf);
+    unsigned long long *offs = reinterpret_cast<unsigned long long *>(static_cast<char *>(buf) + (((size_t)nb * 4 + 7) / 8) * 8);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(roi_count_kernel, dim3(nb), dim3(256), 0, s, d_vol, n, Y, Z, T, (long long)sx, (long long)sy, (long long)sz, (long long)st, thr, counts);
+    hipLaunchKernelGGL(roi_scan_kernel, dim3(1), dim3(1024), 0, s, counts, nb, offs);
+    hipLaunchKernelGGL(roi_write_kernel, dim3(nb), dim3(256), 0, s, d_vol, n, Y, Z, T, (long long)sx, (long long)sy, (long long)sz, (long long)st, thr, offs, d_out);
+    unsigned long long total = 0;
+    if (hipMemcpyAsync(&total, offs + nb, 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+        set_error("roi_compact: device error: %s", hipGetErrorString(hipGetLastError()));
+        return UKBB_EDEVICE;
+    }
+    *n_host = total;
+    return UKBB_OK;
+}
+
+int ukbb_fcn_pairwise_sum(const float *d_a, uint64_t n, int squared_dev, float mean, float *sum_host, void *stream) {
+    if (!d_a || !sum_host) { set_error("pairwise_sum: NULL argument"); return UKBB_EINVAL; }
+    if (n == 0) { *sum_host = 0.f; return UKBB_OK; }
+    std::vector<unsigned long long> offs;
+    std::vector<unsigned> lens;
+    offs.reserve((size_t)(n / 64) + 2); lens.reserve((size_t)(n / 64) + 2);
+    for (uint64_t c = 0; c < n; c += NPY_BUFSIZE) pairwise_leaves(c, n - c < NPY_BUFSIZE ? n - c : NPY_BUFSIZE, offs, lens);
+    const size_t nl = offs.size();
+    Scratch *sc = prep_scratch(1);
+    char *buf = sc ? static_cast<char *>(sc->get(nl * 16)) : nullptr;
+    if (!buf) { set_error("pairwise_sum: scratch allocation failed"); return UKBB_ENOMEM; }
+    unsigned long long *d_off = reinterpret_cast<unsigned long long *>(buf);
+    unsigned *d_len = reinterpret_cast<unsigned *>(buf + nl * 8);
+    float *d_sum = reinterpret_cast<float *>(buf + nl * 12);
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<float> leaf(nl);
+    if (hipMemcpyAsync(d_off, offs.data(), nl * 8, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(d_len, lens.data(), nl * 4, hipMemcpyHostToDevice, s) != hipSuccess) { set_error("pairwise_sum: H2D failed"); return UKBB_EDEVICE; }
+    hipLaunchKernelGGL(pairwise_leaf_kernel, dim3((unsigned)((nl + 127) / 128)), dim3(128), 0, s, d_a, d_off, d_len, (int)nl, squared_dev, mean, d_sum);
+    if (hipMemcpyAsync(leaf.data(), d_sum, nl * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+        set_error("pairwise_sum: device error: %s", hipGetErrorString(hipGetLastError()));
+        return UKBB_EDEVICE;
+    }
+    size_t idx = 0;
+    volatile float acc = 0.f;                           // add.reduce starts from the identity and adds one pairwise sum per buffer
+    for (uint64_t c = 0; c < n; c += NPY_BUFSIZE) {
+        const volatile float tree = pairwise_combine(leaf.data(), idx, n - c < NPY_BUFSIZE ? n - c : NPY_BUFSIZE);
+        acc = acc + tree;
+    }
+    *sum_host = acc;
+    return UKBB_OK;
+}
+
+int ukbb_fcn_zscore_pack(const float *d_vol, int X, int Y, int Z, int T, int64_t sx, int64_t sy, int64_t sz, int64_t st,
+                         float mu, float den, int X2, int Y2, int x_pre, int y_pre, float *d_batch, void *stream) {
+    if (!d_vol || !d_batch || X < 1 || Y < 1 || Z < 1 || T < 1 || x_pre < 0 || y_pre < 0 || X2 < X + x_pre || Y2 < Y + y_pre ||
+        (long long)Z * T > 65535) {
+        set_error("zscore_pack: bad shape X=%d Y=%d Z=%d T=%d X2=%d Y2=%d pre=(%d,%d) (Z*T <= 65535)", X, Y, Z, T, X2, Y2, x_pre, y_pre);
+        return UKBB_EINVAL;
+    }
+    dim3 grid((unsigned)(((X2 + 31) / 32) * ((Y2 + 31) / 32)), (unsigned)(Z * T));
+    hipLaunchKernelGGL(zscore_pack_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_vol, X, Y, Z, T, (long long)sx, (long long)sy,
+                       (long long)sz, (long long)st, mu, den, X2, Y2, x_pre, y_pre, d_batch);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("zscore_pack: launch failed: %s", hipGetErrorString(e)); return UKBB_EDEVICE; }
     return UKBB_OK;
 }
 

@@ -43,13 +43,16 @@ def define_flags():
     fs.DEFINE_integer('device', default_device(), 'HIP device ordinal (after HIP_VISIBLE_DEVICES); defaults to '
                       'LOCAL_RANK under torch.distributed.run.')
     fs.DEFINE_integer('batch_slices', 64, 'Slices per forward call.')
+    fs.DEFINE_boolean('device_preproc', True, 'UNet-LSTM sequences: z-score, padding, transposes and the argmax on the GPU '
+                      '(bit-identical to the host path; --nodevice_preproc restores it).')
     fs.DEFINE_integer('num_shards', env_cnt, 'Number of workers sharing data_dir.')
     fs.DEFINE_integer('shard_index', env_idx, 'This worker: subjects i with i % num_shards == shard_index.')
     return fs
 
 
-def run(FLAGS, forward, log=print, cine_forward=None):
-    """``forward`` stands for the frame-wise sess.run ('UNet'); ``cine_forward`` for the windowed one ('UNet-LSTM')."""
+def run(FLAGS, forward, log=print, cine_forward=None, engine=None):
+    """``forward`` stands for the frame-wise sess.run ('UNet'); ``cine_forward`` for the windowed one ('UNet-LSTM').
+    With ``engine`` (and --device_preproc, --z_score) float32 UNet-LSTM sequences take device_pipeline.aortic_lstm_sequence_device."""
     if FLAGS.model == 'Temporal-UNet':
         raise NotImplementedError("--model Temporal-UNet (common/network_ao.py:67-114, 3-D convolutions) is not built")
     if FLAGS.model == 'UNet-LSTM':
@@ -78,12 +81,18 @@ def run(FLAGS, forward, log=print, cine_forward=None):
             image = nim.get_data()
             log('  Segmenting full sequence ...')
             t0 = time.time()
-            if FLAGS.model == 'UNet-LSTM':
-                prob = pipeline.aortic_lstm_prob_sequence(image, cine_forward, FLAGS.z_score, FLAGS.weight_R, FLAGS.weight_r,
-                                                          time_step=FLAGS.time_step)
+            on_device = (FLAGS.model == 'UNet-LSTM' and engine is not None and getattr(FLAGS, 'device_preproc', False)
+                         and FLAGS.z_score and image.ndim == 4 and image.dtype == np.float32)
+            if on_device:
+                from ukbb_cardiac_amd.device_pipeline import aortic_lstm_sequence_device
+                pred = aortic_lstm_sequence_device(image, engine, True, FLAGS.weight_R, FLAGS.weight_r, FLAGS.time_step)
             else:
-                prob = pipeline.aortic_prob_sequence(image, forward, FLAGS.z_score, FLAGS.batch_slices)
-            pred = np.argmax(prob, axis=-1).astype(np.int32)          # host argmax, as :189
+                if FLAGS.model == 'UNet-LSTM':
+                    prob = pipeline.aortic_lstm_prob_sequence(image, cine_forward, FLAGS.z_score, FLAGS.weight_R, FLAGS.weight_r,
+                                                              time_step=FLAGS.time_step)
+                else:
+                    prob = pipeline.aortic_prob_sequence(image, forward, FLAGS.z_score, FLAGS.batch_slices)
+                pred = np.argmax(prob, axis=-1).astype(np.int32)      # host argmax, as :189
             if FLAGS.save_seg:
                 log('  Saving segmentation ...')
                 nifti.save(pred, '{0}/seg_{1}.nii.gz'.format(data_dir, seq), nim.affine, nim.header['pixdim'])
@@ -140,7 +149,7 @@ def main(argv=None):
 
         def cine_forward(frames, weight_R, weight_r, time_step=1):
             return sess.engine.run_cine(frames, weight_R, weight_r, time_step)[0]
-        run(FLAGS, forward, cine_forward=cine_forward)
+        run(FLAGS, forward, cine_forward=cine_forward, engine=sess.engine)
 
 
 if __name__ == '__main__':

@@ -18,7 +18,7 @@ import math
 import numpy as np
 
 from . import _lib
-from .pipeline import pad_amounts
+from .pipeline import pad_amounts, pad_amounts_fixed
 
 
 def percentile_ranks(n, q):
@@ -110,3 +110,98 @@ def pick_ed_es_from_counts(counts, seq_name, seg4=False):
     if seq_name == 'sa' or (seq_name == 'la_4ch' and seg4):
         return 0, int(np.argmin(c1))
     return 0, int(np.argmax(c1))
+
+
+# ---- aortic cine: z-score + UNet-LSTM on the device (common/deploy_network_ao.py:92-107,129-189) ------------------
+
+def scalar_percentile_ranks(n, q):
+    """0-based ranks (k, k+1) and the float32 fractional part np.percentile uses when q is a Python SCALAR and the data
+    float32 (image_utils.py:62, ``np.percentile(image, thres_roi)``): numpy 2 then keeps everything in the data's
+    dtype -- quantile = q / float32(100), virtual index (n - 1) * quantile in float32, gamma = float32(float64(virtual) - k)."""
+    quantile = np.true_divide(q, np.float32(100))
+    virtual = np.asanyarray((n - 1) * quantile)
+    if virtual >= n - 1:
+        return n - 1, n - 1, 0.0
+    k = int(np.floor(virtual))
+    gamma = np.asanyarray(np.asanyarray(virtual - np.asanyarray(k, dtype=np.intp)), dtype=virtual.dtype)
+    return k, k + 1, float(gamma)
+
+
+def device_scalar_percentile(vol_t, q, stream=0):
+    """Exact np.percentile(float32 volume, q) for a Python-scalar q, on the device."""
+    n = vol_t.numel()
+    k, k1, g = scalar_percentile_ranks(n, q)
+    r = (C.c_uint64 * 2)(k, k1)
+    out = np.empty(2, np.float32)
+    _lib.check(_lib.lib.ukbb_fcn_select_kth(vol_t.data_ptr(), n, r, 2, _lib.f32ptr(out), stream), 'ukbb_fcn_select_kth')
+    # numpy's own float32 lerp: a Python-float quantile on a float32 array stays float32, (2 - 1) * g = g exactly
+    return np.quantile(out, g)
+
+
+def device_zscore_stats(vol_t, thres_roi=10.0, stream=0):
+    """(mu, sigma + eps, n_roi, val_l) of image_utils.normalise_intensity for a dense float32 (X,Y,Z,T) torch tensor on the
+    GPU, bit-identical to numpy: the ROI is compacted in numpy's element order and summed along numpy's pairwise tree
+    (``ukbb_fcn_roi_compact`` / ``ukbb_fcn_pairwise_sum``); the few scalar operations around the sums are numpy's own."""
+    import torch
+    X, Y, Z, T = vol_t.shape
+    val_l = device_scalar_percentile(vol_t, thres_roi, stream)
+    roi = torch.empty(vol_t.numel(), dtype=torch.float32, device=vol_t.device)
+    sx, sy, sz, st = vol_t.stride()
+    n_roi = C.c_uint64(0)
+    _lib.check(_lib.lib.ukbb_fcn_roi_compact(vol_t.data_ptr(), X, Y, Z, T, sx, sy, sz, st, float(val_l), roi.data_ptr(),
+                                             C.byref(n_roi), stream), 'ukbb_fcn_roi_compact')
+    n = np.intp(n_roi.value)                                  # _count_reduce_items returns an intp scalar: the divisions below are float64
+    s = C.c_float(0)
+    _lib.check(_lib.lib.ukbb_fcn_pairwise_sum(roi.data_ptr(), int(n), 0, 0.0, C.byref(s), stream), 'ukbb_fcn_pairwise_sum')
+    with np.errstate(all='ignore'):
+        mu = np.float32(np.float32(s.value) / n)             # np.mean: ret.dtype.type(ret / rcount)
+        _lib.check(_lib.lib.ukbb_fcn_pairwise_sum(roi.data_ptr(), int(n), 1, float(mu), C.byref(s), stream), 'ukbb_fcn_pairwise_sum')
+        var = np.float32(np.float32(s.value) / n)            # np.var: sum((x - mean)^2) in float32, / n in float64, back to float32
+        sigma = np.float32(np.sqrt(var))
+    return mu, sigma + 1e-6, int(n), val_l                   # float32 + Python float stays float32 (image_utils.py:66-67)
+
+
+def aortic_lstm_sequence_device(image, engine, z_score=True, weight_R=5, weight_r=0.1, time_step=1, return_aux=False):
+    """pipeline.aortic_lstm_prob_sequence + the argmax of deploy_network_ao.py:189 with the array work on the GPU:
+    (X,Y,Z,T) float32 aortic cine -> int32 label volume (X,Y,Z,T).  Only the raw volume goes in and uint8 labels come
+    back (the host path moves the padded float32 cine in and 3 float32 probability maps per voxel out, and spends more
+    time in np.percentile / np.argmax than the network takes).  ``aux['prob']`` (X,Y,Z,T,C) on request; ``aux['counts']``
+    = pixels of each class per frame (what eval_aortic_area.py:60-78 turns into areas)."""
+    import torch
+    if image.ndim != 4 or image.dtype != np.float32:
+        raise TypeError('expected a 4-D float32 (X,Y,Z,T) cine; use pipeline.aortic_lstm_prob_sequence otherwise')
+    if not z_score:
+        raise ValueError('the device path implements the default --z_score pre-processing')
+    X, Y, Z, T = image.shape
+    dev = torch.device('cuda', engine.device)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    src = image if (image.flags.f_contiguous or image.flags.c_contiguous) else np.asfortranarray(image)
+    vol = torch.from_numpy(src).to(dev)
+    mu, den, n_roi, val_l = device_zscore_stats(vol, 10.0, stream)
+    X2, Y2, x_pre, _, y_pre, _ = pad_amounts_fixed(X, Y)
+    n_class = engine.arch.n_class
+    batch = torch.empty((T, Z, X2, Y2), dtype=torch.float32, device=dev)
+    sx, sy, sz, st = vol.stride()
+    _lib.check(_lib.lib.ukbb_fcn_zscore_pack(vol.data_ptr(), X, Y, Z, T, sx, sy, sz, st, float(mu), float(den), X2, Y2, x_pre, y_pre,
+                                             batch.data_ptr(), stream), 'ukbb_fcn_zscore_pack')
+    prob = torch.empty((T, Z, X2, Y2, n_class), dtype=torch.float32, device=dev)
+    pred = torch.empty((T, Z, X2, Y2), dtype=torch.int32, device=dev)
+    for z in range(Z):                                       # slice positions are independent cines (usually Z = 1)
+        fr = batch[:, z] if Z == 1 else batch[:, z].contiguous()
+        pr = prob[:, z] if Z == 1 else torch.empty((T, X2, Y2, n_class), dtype=torch.float32, device=dev)
+        pd = pred[:, z] if Z == 1 else torch.empty((T, X2, Y2), dtype=torch.int32, device=dev)
+        engine.run_cine_device(fr.data_ptr(), T, X2, Y2, pr.data_ptr(), pd.data_ptr(), weight_R, weight_r, time_step, stream)
+        if Z > 1:
+            prob[:, z].copy_(pr)
+            pred[:, z].copy_(pd)
+    lab = torch.empty(X * Y * Z * T, dtype=torch.uint8, device=dev)
+    counts = torch.empty((T, n_class), dtype=torch.int64, device=dev)
+    _lib.check(_lib.lib.ukbb_fcn_unpack_labels(pred.data_ptr(), X, Y, Z, T, X2, Y2, x_pre, y_pre, n_class,
+                                               lab.data_ptr(), counts.data_ptr(), stream), 'ukbb_fcn_unpack_labels')
+    out = lab.cpu().numpy().reshape((X, Y, Z, T), order='F').astype(np.int32)
+    if not return_aux:
+        return out
+    aux = {'mu': mu, 'den': den, 'n_roi': n_roi, 'val_l': val_l, 'counts': counts.cpu().numpy()}
+    p = prob[:, :, x_pre:x_pre + X, y_pre:y_pre + Y].permute(2, 3, 1, 0, 4)
+    aux['prob'] = p.cpu().numpy()
+    return out, aux

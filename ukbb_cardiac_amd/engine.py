@@ -142,6 +142,13 @@ class Engine:
         _lib.check(rc, 'ukbb_fcn_forward_cine')
         return pr.cpu().numpy(), pd.cpu().numpy()
 
+    def run_cine_device(self, frames_ptr, f, h, w, prob_ptr, pred_ptr, weight_R=5, weight_r=0.1, time_step=1, stream=0):
+        """``run_cine`` on device pointers (frames [F,H,W] float32, prob [F,H,W,C] float32, pred [F,H,W] int32), asynchronous on
+        ``stream``: the form device_pipeline.aortic_lstm_sequence_device uses."""
+        rc = _lib.lib.ukbb_fcn_forward_cine(self._h, C.c_void_p(frames_ptr), int(f), int(h), int(w), int(weight_R), float(weight_r),
+                                            int(time_step), C.c_void_p(prob_ptr), C.c_void_p(pred_ptr or None), C.c_void_p(stream or None))
+        _lib.check(rc, 'ukbb_fcn_forward_cine')
+
     def set_precision(self, precision: str):
         """'fp32' (default) or 'bf16' (bf16 MFMA inputs, fp32 accumulate; BASELINE config 5)."""
         code = {'fp32': 0, 'bf16': 1}[precision]
