@@ -104,6 +104,11 @@ __global__ __launch_bounds__(512, 2) void wino_pc_kernel(const ConvArgs a) {
     const int nitems = per_group * (a.Cout / (16 * WNCBL));
     const int my_items = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int nstages = my_items * nchunk;
+    // Regions of one image can cost differently (12-row maps: the lower region runs half the MFMAs, see `half` below), and with
+    // a grid that is a multiple of `regions` a workgroup would meet the same region of some image in every round: rotate the
+    // region index by the round so that every workgroup gets its share of cheap and expensive ones (a bijection on the items
+    // of a round as long as a round holds whole images' region sets).
+    const bool rotate = (int)gridDim.x % regions == 0;
     const bool producer = __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256;
 
     if (producer) {
@@ -130,12 +135,13 @@ __global__ __launch_bounds__(512, 2) void wino_pc_kernel(const ConvArgs a) {
         int cur_cs = 0;
         u32x4 xr[NITX];
         // scalar cursor of the next stage to request
-        int l_ch = 0, l_item = blockIdx.x, l_n = 0, l_n0 = 0, l_iy0 = 0, l_ix0 = 0;
+        int l_ch = 0, l_item = blockIdx.x, l_n = 0, l_n0 = 0, l_iy0 = 0, l_ix0 = 0, l_round = 0;
         auto locate = [&]() {
             const int rest = l_item % per_group;
             l_n = rest / regions;
             l_n0 = a.in0_map ? a.in0_map[l_n] : l_n;     // scalar load; ConvLSTM windows index shared feature frames
-            const int r = rest - l_n * regions;
+            int r = rest - l_n * regions;
+            if (rotate) r = (r + l_round) % regions;
             const int ry = r / regs_x, rx = r - ry * regs_x;
             l_iy0 = ry * 2 * TRY - 1; l_ix0 = rx * 2 * TRX - 1;
         };
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(512, 2) void wino_pc_kernel(const ConvArgs a) {
                 const unsigned vo = (cm & tb[it]) == tb[it] ? pre[it] : 0x80000000u;   // out of range -> zeros
                 xr[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0);
             }
-            if (++l_ch == nchunk) { l_ch = 0; l_item += gridDim.x; if (l_item < nitems) locate(); }
+            if (++l_ch == nchunk) { l_ch = 0; l_item += gridDim.x; ++l_round; if (l_item < nitems) locate(); }
         };
         float *const xs_w = lds + L_XS + pix0 * WXS + 4 * c4;
         auto storex = [&](auto par) {
@@ -258,9 +264,12 @@ __global__ __launch_bounds__(512, 2) void wino_pc_kernel(const ConvArgs a) {
         constexpr int BA = TBW == 2 ? 1 : 2, BR = BA + 1; // B lookahead (k positions) and ring size
         f32x4 aq[AD];
         STAMP_DO(unsigned long long cw = 0, cc = 0, ce = 0, c0, c1, c2, c3;)
-        for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        int round = 0;
+        for (int item = blockIdx.x; item < nitems; item += gridDim.x, ++round) {
             const int grp = item / per_group, rest = item - grp * per_group;
-            const int n = rest / regions, r = rest - n * regions;
+            const int n = rest / regions;
+            int r = rest - n * regions;
+            if (rotate) r = (r + round) % regions;
             const int ry = r / regs_x, rx = r - ry * regs_x;
             const int co = (grp * WNCBL + wave) * 16 + 4 * g;
             const f32x4 bias = ld4(a.bias + co);        // needed after the last chunk; in flight during the stages
