@@ -116,14 +116,20 @@ __device__ __forceinline__ void sqg_body(const SqgArgs &a, int vblock, int vgrid
         // k-step (j,i) pairs channels 8j+i (lanes 0-31) and 8j+4+i (lanes 32-63).
         // Levels 3-4 are small (1-2 blocks per wave): all of the block's feature loads are issued before
         // the first MFMA so their latency is paid once, not once per group of k-steps.
-        f32x4 xv[CIN / 8];
+        // (at most 128 channels at a time: inside sqg_multi_kernel this body must not push the register count past the
+        // two-waves-per-SIMD limit, or level 1's bandwidth-bound stream loses half of its loads in flight)
+        constexpr int XG = CIN / 8 < 16 ? CIN / 8 : 16;
 #pragma unroll
-        for (int j = 0; j < CIN / 8; ++j) xv[j] = ldg4(xp + 8 * j);
+        for (int j0 = 0; j0 < CIN / 8; j0 += XG) {
+            f32x4 xv[XG];
 #pragma unroll
-        for (int j = 0; j < CIN / 8; ++j) {
-            const f32x4 wv = ldg4(a.w_s + (j * 64 + lane) * 4);
+            for (int j = 0; j < XG; ++j) xv[j] = ldg4(xp + 8 * (j0 + j));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) S = MFMA32(wv[i], xv[j][i], S);
+            for (int j = 0; j < XG; ++j) {
+                const f32x4 wv = ldg4(a.w_s + ((j0 + j) * 64 + lane) * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) S = MFMA32(wv[i], xv[j][i], S);
+            }
         }
         relu16(S);
         f32x16 G0, G1;
@@ -152,8 +158,15 @@ __device__ __forceinline__ void sqg_body(const SqgArgs &a, int vblock, int vgrid
 template <int CIN>
 __global__ __launch_bounds__(256) void sqg_kernel(const SqgArgs a) { sqg_body<CIN>(a, blockIdx.x, gridDim.x); }
 
-template <int CIN>
-__device__ __forceinline__ void sqg_stream_body(const SqgArgs &a, int vblock, int vgrid) {
+// TR: the last layer is computed transposed (G^T = S^T W0^T: the same registers with the MFMA operands swapped), which puts
+// the 32 output channels of a block on the lanes and the pixels on the registers: every store instruction then writes two
+// contiguous 128-byte segments (one accumulator register as it stands) instead of 32 segments of 32 bytes.
+// LT: the features of a block (32 pixels x CIN floats, one contiguous chunk of the NHWC map) are fetched with fully contiguous
+// 1-KB wave loads and turned into the operand layout (pixel on the lane) through a wave-private LDS tile, instead of loads
+// that touch 32 rows with 32 bytes each.
+constexpr int SQG_LDS_WAVE = 32 * (64 + 4);
+template <int CIN, bool TR = false, bool LT = false>
+__device__ __forceinline__ void sqg_stream_body(const SqgArgs &a, int vblock, int vgrid, float *lds_x = nullptr) {
     constexpr int NJ = CIN / 8;
     const int lane = threadIdx.x & 63;
     const int p = lane & 31, g = lane >> 5;
@@ -168,23 +181,41 @@ __device__ __forceinline__ void sqg_stream_body(const SqgArgs &a, int vblock, in
         wb[q4] = ldg4(a.w_g + ((1 * 4 + q4) * 64 + lane) * 4);
     }
     const f32x16 bias = bias_tile(a.b_s, g);
-    auto row = [&](long long blk) { const long long q = blk * 32 + p; return a.x + (q < a.npix ? q : a.npix - 1) * CIN + 4 * g; };
+    constexpr int RS = CIN + 4;                         // LDS row stride (floats): b128-aligned, the strided read is conflict-free
+    float *const xl = LT ? lds_x + (threadIdx.x >> 6) * SQG_LDS_WAVE : nullptr;
+    const long long qlast = a.npix * (CIN / 4) - 1;     // last valid 16-byte quad of the map (rows past the end are never stored)
+    auto fetch = [&](long long blk, f32x4 *dst) {
+        if constexpr (LT) {
+#pragma unroll
+            for (int t = 0; t < NJ; ++t) {
+                const long long f = blk * (32 * (CIN / 4)) + t * 64 + lane;
+                dst[t] = ldg4(a.x + 4 * (f < qlast ? f : qlast));
+            }
+        } else {
+            const long long q = blk * 32 + p;
+            const float *xp = a.x + (q < a.npix ? q : a.npix - 1) * CIN + 4 * g;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) dst[j] = ldg4(xp + 8 * j);
+        }
+    };
     long long blk = (long long)vblock * 4 + (threadIdx.x >> 6);
     f32x4 xn[NJ];
-    if (blk < nblk) {
-        const float *xp = row(blk);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) xn[j] = ldg4(xp + 8 * j);
-    }
+    if (blk < nblk) fetch(blk, xn);
     for (; blk < nblk; blk += step) {
         f32x4 xv[NJ];
+        if constexpr (LT) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) xv[j] = xn[j];
-        if (blk + step < nblk) {
-            const float *xp = row(blk + step);
+            for (int t = 0; t < NJ; ++t) {
+                const int f = t * 64 + lane;
+                *reinterpret_cast<f32x4 *>(xl + (f / (CIN / 4)) * RS + (f % (CIN / 4)) * 4) = xn[t];
+            }
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) xn[j] = ldg4(xp + 8 * j);
+            for (int j = 0; j < NJ; ++j) xv[j] = *reinterpret_cast<const f32x4 *>(xl + p * RS + (2 * j + g) * 4);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) xv[j] = xn[j];
         }
+        if (blk + step < nblk) fetch(blk + step, xn);
         f32x16 S = bias;
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
@@ -193,6 +224,35 @@ __device__ __forceinline__ void sqg_stream_body(const SqgArgs &a, int vblock, in
         relu16(S);
         f32x16 G0, G1;
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if constexpr (TR) {
+            G0 = MFMA32(S[0], wa[0][0], zero);
+            G1 = MFMA32(S[0], wb[0][0], zero);
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+                for (int i = (q4 == 0 ? 1 : 0); i < 4; ++i) {
+                    G0 = MFMA32(S[4 * q4 + i], wa[q4][i], G0);
+                    G1 = MFMA32(S[4 * q4 + i], wb[q4][i], G1);
+                }
+            // register r of G0/G1: pixel 8*(r/4) + 4*g + r%4 of the block, channel p (+32)
+            const long long q0 = blk * 32 + 4 * g;
+            float *o = a.out + q0 * 64 + p;
+            if (blk * 32 + 32 <= a.npix) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    o[(8 * (r / 4) + r % 4) * 64] = G0[r];
+                    o[(8 * (r / 4) + r % 4) * 64 + 32] = G1[r];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (q0 + 8 * (r / 4) + r % 4 < a.npix) {
+                        o[(8 * (r / 4) + r % 4) * 64] = G0[r];
+                        o[(8 * (r / 4) + r % 4) * 64 + 32] = G1[r];
+                    }
+            }
+            continue;
+        }
         G0 = MFMA32(wa[0][0], S[0], zero);              // C = 0 as an inline constant: no accumulator clearing
         G1 = MFMA32(wb[0][0], S[0], zero);
 #pragma unroll
@@ -225,13 +285,15 @@ __global__ __launch_bounds__(256) void sqg_stream_kernel(const SqgArgs a) { sqg_
 // HBM stream (82 MB in, 164 MB out at batch 64).  r02: every launch of this network costs ~10 us of fixed time
 // (dispatch + first-load latency + tail, measured as 2 t(N=64) - t(N=128) per kernel), so the four go out together after
 // level 4: the small levels' blocks come first and finish inside the first microseconds of level 1's stream.
-__global__ __launch_bounds__(256) void sqg_multi_kernel(const SqgMultiArgs m) {
+template <bool TR, bool LT>
+__global__ __launch_bounds__(256, 2) void sqg_multi_kernel(const SqgMultiArgs m) {
+    __shared__ __attribute__((aligned(16))) float lds_x[LT ? 4 * SQG_LDS_WAVE : 4];
     const int b = blockIdx.x;
     const int e1 = m.nb[1], e2 = e1 + m.nb[2], e3 = e2 + m.nb[3];
-    if (b < e1) sqg_stream_body<64>(m.lv[1], b, m.nb[1]);
+    if (b < e1) sqg_stream_body<64, TR, LT>(m.lv[1], b, m.nb[1], lds_x);
     else if (b < e2) sqg_body<128>(m.lv[2], b - e1, m.nb[2]);
     else if (b < e3) sqg_body<256>(m.lv[3], b - e2, m.nb[3]);
-    else sqg_stream_body<32>(m.lv[0], b - e3, m.nb[0]);
+    else sqg_stream_body<32, TR, LT>(m.lv[0], b - e3, m.nb[0], lds_x);
 }
 
 hipError_t launch_sqg_multi(const SqgArgs lv[4], hipStream_t s) {
@@ -245,7 +307,11 @@ hipError_t launch_sqg_multi(const SqgArgs lv[4], hipStream_t s) {
         m.nb[i] = (int)wg;
         total += m.nb[i];
     }
-    hipLaunchKernelGGL(sqg_multi_kernel, dim3((unsigned)total), dim3(256), 0, s, m);
+    static const bool tr = [] { const char *e = getenv("UKBB_SQG_TR"); return e ? atoi(e) != 0 : true; }();
+    static const bool lt = [] { const char *e = getenv("UKBB_SQG_LT"); return e ? atoi(e) != 0 : true; }();
+    if (tr && lt) hipLaunchKernelGGL((sqg_multi_kernel<true, true>), dim3((unsigned)total), dim3(256), 0, s, m);
+    else if (tr) hipLaunchKernelGGL((sqg_multi_kernel<true, false>), dim3((unsigned)total), dim3(256), 0, s, m);
+    else hipLaunchKernelGGL((sqg_multi_kernel<false, false>), dim3((unsigned)total), dim3(256), 0, s, m);
     return hipGetLastError();
 }
 
