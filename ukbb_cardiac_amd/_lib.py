@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libukbb_fcn.so')
+LIB_PATH = os.environ.get('UKBB_FCN_LIB') or os.path.join(_HERE, 'libukbb_fcn.so')   # override: A/B builds of the kernels
 ABI_VERSION = 3
 MAX_LEVEL = 8
 
