@@ -185,6 +185,23 @@ int ukbb_fcn_pairwise_sum(const float *d_a, uint64_t n, int squared_dev, float m
 int ukbb_fcn_zscore_pack(const float *d_vol, int X, int Y, int Z, int T, int64_t sx, int64_t sy, int64_t sz, int64_t st,
                          float mu, float den, int X2, int Y2, int x_pre, int y_pre, float *d_batch, void *stream);
 
+/* ---- label-volume files (host only: no device, no stream) ---------------------------------------
+ * What the reference does with the result: nib.save of np.zeros(image.shape) filled with the labels
+ * (common/deploy_network.py:92,116,136-138; deploy_network_ao.py:189-196) -- for a short-axis subject
+ * 160 MB of float64 through zlib, 0.5 s of a core against 11 ms of network time.
+ *
+ * ukbb_fcn_gzip_labels writes ONE gzip member (RFC 1952 / 1951, fixed Huffman codes) whose inflated
+ * content is  prefix || labels converted to the NIfTI voxel type `nifti_datatype`
+ * (2 uint8, 4 int16, 8 int32, 16 float32, 64 float64; little-endian),  i.e. the .nii.gz nibabel writes
+ * when prefix is the 352-byte NIfTI-1 header, without forming the converted volume: a run of equal
+ * labels becomes E literals + matches of distance E, its CRC-32 is computed per run.  labels[n] uint8
+ * in file order (x fastest).  Returns the number of bytes written to out, or UKBB_ENOMEM when out_cap
+ * is too small (ukbb_fcn_gzip_labels_bound is always sufficient; a label map of a real segmentation
+ * needs ~2 % of it), or UKBB_EINVAL. */
+uint64_t ukbb_fcn_gzip_labels_bound(uint64_t n_voxels, int nifti_datatype, uint64_t prefix_len);
+int64_t ukbb_fcn_gzip_labels(const uint8_t *labels, uint64_t n_voxels, int nifti_datatype, const uint8_t *prefix, uint64_t prefix_len,
+                             uint8_t *out, uint64_t out_cap);
+
 /* ---- measurement / introspection (bench.py, tests) ---------------------- */
 
 /* Kernel launches of one forward, in launch order. */

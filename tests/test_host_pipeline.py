@@ -329,3 +329,87 @@ def test_nifti_save_as_dtype_streams_the_same_bytes(tmp_path):
     nifti.save(lab[:, :, 0, 0], b, aff, as_dtype=np.int32)
     nifti.save(lab[:, :, 0, 0].astype(np.int32), a, aff)
     assert open(a, 'rb').read() == open(b, 'rb').read()
+
+
+# ---- label volumes through the run-length gzip writer of the C library (include/ukbb_fcn.h: ukbb_fcn_gzip_labels) ----------
+
+def _blobs(shape, seed):
+    rng = np.random.default_rng(seed)
+    lab = np.zeros(shape, np.uint8)
+    idx = np.indices(shape[:2])
+    for k in range(1, 4):
+        cy, cx, r = rng.integers(10, shape[0] - 10), rng.integers(10, shape[1] - 10), rng.integers(3, 12)
+        m = (idx[0] - cy) ** 2 + (idx[1] - cx) ** 2 < r * r
+        lab[m] = k
+    return lab
+
+
+@pytest.mark.parametrize('dtype', [np.uint8, np.int16, np.int32, np.float32, np.float64])
+def test_label_gzip_inflates_to_what_zlib_path_writes(tmp_path, dtype, monkeypatch):
+    """deploy_network.py:136-138 / deploy_network_ao.py:189-196: the segmentation file.  The run-length writer and the zlib
+    path must give the same bytes after inflation (gzip.open also checks the member's CRC-32 and length)."""
+    import gzip
+    from ukbb_cardiac_amd import nifti
+    lab = _blobs((48, 40, 3, 4), 3)
+    aff = np.diag([1.8, 1.8, 10.0, 1.0])
+    fast, slow = str(tmp_path / 'fast.nii.gz'), str(tmp_path / 'slow.nii.gz')
+    nifti.save(lab.astype(dtype), fast, aff)
+    monkeypatch.setattr(nifti, 'LABEL_FAST_PATH', False)
+    nifti.save(lab.astype(dtype), slow, aff)
+    a, b = gzip.open(fast, 'rb').read(), gzip.open(slow, 'rb').read()
+    assert a == b and len(a) == 352 + lab.size * np.dtype(dtype).itemsize
+    assert open(fast, 'rb').read() != open(slow, 'rb').read()              # it really was the other encoder
+    back = nifti.load(fast)
+    assert back.get_data().dtype == dtype and np.array_equal(back.get_data(), lab)
+
+
+@pytest.mark.parametrize('n', [1, 2, 3, 33, 34, 259, 260, 261, 262, 516, 517, 30000])
+@pytest.mark.parametrize('fill', ['zero', 'one', 'random', 'blocks'])
+def test_label_gzip_run_lengths_and_crc(tmp_path, n, fill, monkeypatch):
+    """Run lengths around the 258-byte match limit, all-zero volumes (CRC of zero runs by polynomial shift), noise."""
+    import gzip
+    from ukbb_cardiac_amd import nifti
+    rng = np.random.default_rng(n)
+    lab = {'zero': np.zeros(n, np.uint8), 'one': np.ones(n, np.uint8), 'random': rng.integers(0, 4, n).astype(np.uint8),
+           'blocks': np.repeat(rng.integers(0, 4, n // 7 + 1), 7)[:n].astype(np.uint8)}[fill].reshape(n, 1, 1)
+    p = str(tmp_path / 'l.nii.gz')
+    nifti.save(lab, p, np.eye(4), as_dtype=np.float64)                     # the sequence-mode form: uint8 labels -> float64 file
+    got = gzip.open(p, 'rb').read()
+    assert got[352:] == lab.astype('<f8').tobytes(order='F')
+
+
+def test_label_gzip_same_bytes_from_uint8_and_float64_volumes(tmp_path):
+    """Device path (uint8 labels, as_dtype=float64) and host path (float64 volume) write the same FILE."""
+    from ukbb_cardiac_amd import nifti
+    lab = np.asfortranarray(_blobs((64, 48, 2, 5), 9))
+    aff = np.diag([1.8, 1.8, 10.0, 1.0])
+    nifti.save(lab, str(tmp_path / 'a.nii.gz'), aff, as_dtype=np.float64)
+    vol = np.zeros(lab.shape)
+    vol[...] = lab
+    nifti.save(vol, str(tmp_path / 'b.nii.gz'), aff)
+    assert (tmp_path / 'a.nii.gz').read_bytes() == (tmp_path / 'b.nii.gz').read_bytes()
+
+
+def test_label_gzip_leaves_images_and_odd_values_to_zlib(tmp_path):
+    from ukbb_cardiac_amd import nifti
+    for data in (np.random.default_rng(0).random((16, 16, 2)).astype(np.float32) * 900,     # MR intensities
+                 np.array([[[0.0, 1.0, 2.5]]]), np.array([[[0, -1, 3]]], np.int32), np.array([[[0.0, np.nan]]])):
+        assert nifti._as_label_volume(data) is None
+        p = str(tmp_path / 'x.nii.gz')
+        nifti.save(data, p, np.eye(4))
+        assert np.array_equal(nifti.load(p).get_data(), data, equal_nan=True)
+
+
+def test_label_gzip_reports_a_short_buffer():
+    import ctypes as C
+    from ukbb_cardiac_amd import _lib
+    lab = np.random.default_rng(1).integers(0, 4, 5000).astype(np.uint8)
+    out = np.empty(64, np.uint8)
+    assert _lib.lib.ukbb_fcn_gzip_labels(lab.ctypes.data, lab.size, 64, b'', 0, out.ctypes.data, out.size) == -4      # UKBB_ENOMEM
+    cap = _lib.lib.ukbb_fcn_gzip_labels_bound(lab.size, 64, 0)
+    out = np.empty(cap, np.uint8)
+    got = _lib.lib.ukbb_fcn_gzip_labels(lab.ctypes.data, lab.size, 64, b'', 0, out.ctypes.data, cap)
+    assert 0 < got <= cap
+    import gzip
+    assert gzip.decompress(out[:got].tobytes()) == lab.astype('<f8').tobytes()
+    assert _lib.lib.ukbb_fcn_gzip_labels(lab.ctypes.data, lab.size, 1024, b'', 0, out.ctypes.data, cap) == -1         # int64: not offered

@@ -198,6 +198,10 @@ def save(img_or_data, path, affine=None, pixdim=None, as_dtype=None):
     struct.pack_into('<2h', hdr, 252, 0, 2)
     struct.pack_into('<12f', hdr, 280, *[float(v) for v in affine[:3].ravel()])
     hdr[344:348] = b'n+1\x00'
+    if str(path).endswith('.gz') and _CODES[key] in (2, 4, 8, 16, 64):
+        lab = _as_label_volume(data)
+        if lab is not None and _save_labels_gz(lab, _CODES[key], bytes(hdr) + b'\x00\x00\x00\x00', path):
+            return
     with _open(path, 'wb') as f:
         f.write(bytes(hdr))
         f.write(b'\x00\x00\x00\x00')
@@ -210,3 +214,46 @@ def save(img_or_data, path, affine=None, pixdim=None, as_dtype=None):
             else:
                 for k in range(data.shape[-1]):               # x fastest on disk: the last axis is the slowest
                     f.write(np.asfortranarray(data[..., k]).astype(le).tobytes(order='F'))
+
+
+# ---- label volumes: run-length gzip writer of the C library ---------------------------------------------------------
+LABEL_FAST_PATH = True     # tests switch it off to compare with the zlib path
+
+def _as_label_volume(data):
+    """data as a uint8 array in file (Fortran) order if every voxel is an integer in 0..255 (a segmentation), else None."""
+    if data.dtype == np.uint8:
+        return np.asfortranarray(data)
+    if data.dtype.kind not in 'iuf' or data.size == 0:
+        return None
+    probe = data.ravel(order='K')[:4096]                      # a view for C- or F-contiguous data
+    with np.errstate(invalid='ignore'):
+        if not np.array_equal(probe.astype(np.uint8), probe):   # MR intensities fail here at once
+            return None
+        lab = np.asfortranarray(data).astype(np.uint8, order='F')
+        return lab if np.array_equal(lab, data) else None
+
+
+def _save_labels_gz(lab, datatype_code, prefix, path):
+    """The .nii.gz of a label volume through ukbb_fcn_gzip_labels (include/ukbb_fcn.h): same inflated bytes as the zlib
+    path below, ~20x less time for the float64 volumes of the sequence loop.  False = not available (caller falls back)."""
+    if not LABEL_FAST_PATH:
+        return False
+    try:
+        from . import _lib
+    except ImportError:
+        return False
+    import ctypes as C
+    flat = lab.reshape(-1, order='F')
+    n = flat.size
+    cap = max(1 << 16, len(prefix) * 2 + n * (np.dtype(_DTYPES[datatype_code]).itemsize) // 24)
+    for _ in range(2):
+        out = np.empty(cap, np.uint8)
+        got = _lib.lib.ukbb_fcn_gzip_labels(flat.ctypes.data, n, datatype_code, prefix, len(prefix), out.ctypes.data, cap)
+        if got >= 0:
+            with open(path, 'wb') as f:
+                f.write(memoryview(out)[:got])
+            return True
+        if got != -4:                                           # UKBB_ENOMEM: retry once with the guaranteed bound
+            raise RuntimeError('ukbb_fcn_gzip_labels failed (%d)' % got)
+        cap = int(_lib.lib.ukbb_fcn_gzip_labels_bound(n, datatype_code, len(prefix)))
+    raise RuntimeError('ukbb_fcn_gzip_labels: output bound exceeded')
