@@ -27,6 +27,9 @@ if __name__ == '__main__':
     ap.add_argument('--cohort', type=int, default=12)
     ap.add_argument('--io_threads', default='4,8,16')
     ap.add_argument('--skip-host', action='store_true')
+    ap.add_argument('--data', choices=['noise', 'phantom'], default='noise',
+                    help='noise: float32 gamma noise (inflates slowly, gives noisy label maps: the worst case for the file stages); '
+                         'phantom: smooth integer-valued cine phantom (closer to an MR magnitude volume)')
     args = ap.parse_args()
     import torch
     from ukbb_cardiac_amd import deploy_network, device_pipeline as dp, nifti
@@ -41,7 +44,13 @@ if __name__ == '__main__':
     eng = Engine(arch, params)
     rng = np.random.default_rng(0)
     shape = (192, 208, 10, 50)
-    vols = [np.asfortranarray((1000 * rng.gamma(2.0, 1.0, size=shape)).astype(np.float32)) for _ in range(3)]
+    if args.data == 'phantom':
+        from ukbb_cardiac_amd.phantom import cine_phantom
+        X, Y, Z, T = shape
+        vols = [np.asfortranarray(np.round(cine_phantom(Z * T, X, Y, seed=40 + i)[..., 0].reshape(T, Z, X, Y).transpose(2, 3, 1, 0) * 1000.0)
+                                  .astype(np.float32)) for i in range(3)]
+    else:
+        vols = [np.asfortranarray((1000 * rng.gamma(2.0, 1.0, size=shape)).astype(np.float32)) for _ in range(3)]
     n = shape[2] * shape[3]
     print('subject %dx%dx%dx%d (%d slices); host cores: %d logical' % (shape + (n, os.cpu_count())))
 
@@ -129,8 +138,24 @@ if __name__ == '__main__':
         tw = (time.perf_counter() - t0) / args.cohort
         size = os.path.getsize(os.path.join(src, 's000', 'sa.nii.gz')) / 1e6
         t0 = time.perf_counter(); nifti.load(os.path.join(src, 's000', 'sa.nii.gz')); tr = time.perf_counter() - t0
-        print('4. cohort of %d subjects on disk: sa.nii.gz %.0f MB each (synthetic noise compresses badly; reading one: %.0f ms, '
-              'writing one: %.0f ms, single thread)' % (args.cohort, size, tr * 1e3, tw * 1e3))
+        print('4. cohort of %d subjects on disk: sa.nii.gz %.0f MB each (--data %s; reading one: %.0f ms, writing one: %.0f ms, single thread)'
+              % (args.cohort, size, args.data, tr * 1e3, tw * 1e3))
+        # where one subject's time goes when nothing overlaps (the stages of the sequential loop, deploy_network.py:80-151)
+        w1 = os.path.join(root, 'one')
+        shutil.copytree(os.path.join(src, 's000'), os.path.join(w1, 's000'))
+        t0 = time.perf_counter(); nim = nifti.load(os.path.join(w1, 's000', 'sa.nii.gz')); t1 = time.perf_counter()
+        pred, aux = dp.segment_sequence_device(nim.get_data(), eng, return_aux=True); t2 = time.perf_counter()
+        lab8 = pred.astype(np.uint8); t3 = time.perf_counter()
+        nifti.save(lab8, os.path.join(w1, 's000', 'seg_sa.nii.gz'), nim.affine, nim.header['pixdim'], as_dtype=np.float64); t4 = time.perf_counter()
+        nifti.LABEL_FAST_PATH = False
+        nifti.save(lab8, os.path.join(w1, 's000', 'seg_zlib.nii.gz'), nim.affine, nim.header['pixdim'], as_dtype=np.float64); t5 = time.perf_counter()
+        nifti.LABEL_FAST_PATH = True
+        runs = int(np.count_nonzero(np.diff(lab8.reshape(-1, order='F')))) + 1
+        print('   one subject, nothing overlapped: read+inflate %.0f ms | segment (device path, pageable) %.0f ms | write seg_sa: run-length gzip %.0f ms '
+              '(%.1f MB, %d runs) vs zlib level 1 %.0f ms (%.1f MB)' % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t4 - t3) * 1e3,
+              os.path.getsize(os.path.join(w1, 's000', 'seg_sa.nii.gz')) / 1e6, runs, (t5 - t4) * 1e3,
+              os.path.getsize(os.path.join(w1, 's000', 'seg_zlib.nii.gz')) / 1e6))
+        shutil.rmtree(w1)
         for thr in [0] + [int(v) for v in args.io_threads.split(',')]:
             work = os.path.join(root, 'run%d' % thr)
             shutil.copytree(src, work)

@@ -129,6 +129,9 @@ int64_t ukbb_fcn_gzip_labels(const uint8_t *labels, uint64_t n_voxels, int nifti
     if ((!labels && n_voxels) || (!prefix && prefix_len) || !out) return UKBB_EINVAL;
     uint8_t pat[256][8];
     bool have[256] = {false};
+    struct Chunk { uint32_t bits; int len; };
+    Chunk first_tok[256][3];                           // the E literals that open a run of label v, packed into <= 32-bit pieces
+    int first_n[256];
     uint8_t probe[8];
     const int E = element_pattern(nifti_datatype, 0, probe);
     if (!E) return UKBB_EINVAL;
@@ -174,11 +177,24 @@ int64_t ukbb_fcn_gzip_labels(const uint8_t *labels, uint64_t n_voxels, int nifti
                 while (j < n_voxels && labels[j] == v) ++j;
             }
         }
-        if (!have[v]) { element_pattern(nifti_datatype, v, pat[v]); have[v] = true; }
+        if (!have[v]) {
+            element_pattern(nifti_datatype, v, pat[v]);
+            have[v] = true;
+            int nchunk = 0;
+            Chunk c{0, 0};
+            for (int b = 0; b < E; ++b) {
+                const uint32_t lb = t.lit_bits[pat[v][b]];
+                const int ll = t.lit_len[pat[v][b]];
+                if (c.len + ll > 32) { first_tok[v][nchunk++] = c; c = Chunk{0, 0}; }
+                c.bits |= lb << c.len; c.len += ll;
+            }
+            first_tok[v][nchunk++] = c;
+            first_n[v] = nchunk;
+        }
         const uint8_t *P = pat[v];
         const uint64_t run = j - i;
         // ---- deflate tokens ----
-        for (int b = 0; b < E; ++b) literal(P[b]);
+        for (int c = 0; c < first_n[v]; ++c) w.put(first_tok[v][c].bits, first_tok[v][c].len);
         uint64_t R = (run - 1) * (uint64_t)E;
         while (R >= 258 + 3 || R == 258) { w.put(tok258, tok258_len); R -= 258; }
         if (R > 258) { match((int)(R - 3)); R = 3; }   // 259, 260: leave a legal match of 3
