@@ -9,6 +9,7 @@ sform/qform affines, pixdim.  Data is returned in (X, Y, Z, T) order, i.e. the
 file's Fortran order, like nibabel.
 """
 import gzip
+import zlib
 import struct
 
 import numpy as np
@@ -61,10 +62,87 @@ class _GzWriter:
         self._raw.close()
 
 
+class _GzReader:
+    """Inflates a .gz file (all its members) in pieces of 1 MB of compressed input.  gzip.GzipFile feeds zlib 8 KB at a time
+    from Python: thousands of interpreter round trips per cine, all under the GIL -- with several reader threads
+    (deploy_network.py --io_threads) that, not inflate itself, was what bounded a cohort run.  Here the interpreter is entered a
+    dozen times per file and zlib (which releases the GIL and checks each member's CRC-32 and length) does the rest."""
+    PIECE = 1 << 20
+
+    def __init__(self, path):
+        with open(path, 'rb') as f:
+            self._mv = memoryview(f.read())
+        self._pos = 0
+        self._pending = b''                                 # input handed to zlib but lying behind a member's trailer
+        self._d = zlib.decompressobj(31)                     # 31: gzip container
+        self._out = memoryview(b'')
+
+    def _piece(self):
+        if self._pending:
+            piece, self._pending = self._pending, b''
+            return piece
+        piece = self._mv[self._pos:self._pos + self.PIECE]
+        self._pos += len(piece)
+        return piece
+
+    def _more(self):
+        """Next run of inflated bytes, b'' at the end of the file."""
+        while True:
+            if self._d.eof:                                  # a member ended: zero padding, another member, or the end
+                rest = self._d.unused_data.lstrip(b'\x00')
+                while not rest and self._pos < len(self._mv):
+                    rest = bytes(self._piece()).lstrip(b'\x00')
+                if not rest:
+                    return b''
+                if rest[:2] != b'\x1f\x8b' and len(rest) >= 2:
+                    raise ValueError('trailing bytes after the gzip stream are not a gzip member')
+                self._pending = rest
+                self._d = zlib.decompressobj(31)
+            piece = self._piece()
+            if not len(piece):
+                raise EOFError('compressed file ended before the end-of-stream marker was reached')
+            out = self._d.decompress(piece)
+            if out:
+                return out
+
+    def readinto(self, view):
+        view = memoryview(view).cast('B')
+        got = 0
+        while got < len(view):
+            if not len(self._out):
+                self._out = memoryview(self._more())
+                if not len(self._out):
+                    break
+            k = min(len(view) - got, len(self._out))
+            view[got:got + k] = self._out[:k]
+            self._out = self._out[k:]
+            got += k
+        return got
+
+    def read(self, n=-1):
+        if n < 0:
+            parts = [bytes(self._out)]
+            self._out = memoryview(b'')
+            while True:
+                more = self._more()
+                if not more:
+                    return b''.join(parts)
+                parts.append(more)
+        buf = bytearray(n)
+        got = self.readinto(buf)
+        return buf if got == n else bytes(buf[:got])
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self._mv = self._out = None
+
+
 def _open(path, mode):
     if not str(path).endswith('.gz'):
         return open(path, mode)
-    return _GzWriter(path) if 'w' in mode else gzip.open(path, mode)
+    return _GzWriter(path) if 'w' in mode else _GzReader(path)
 
 
 def _quat_affine(b, c, d, qx, qy, qz, pixdim):
