@@ -49,7 +49,7 @@ def define_flags():
                       '(float32 sequences; results identical to the host path).')
     fs.DEFINE_boolean('numpy1_casting', False, 'Rescale intensities with the float32 arithmetic numpy 1.x used when the reference '
                       'was written (1 ulp from numpy 2; host pre-processing only; INTEGRATION.md section 5).')
-    fs.DEFINE_integer('io_threads', 4, 'Reader threads (gzip NIfTI -> pinned staging) and writer threads (float64 label volume, gzip) '
+    fs.DEFINE_integer('io_threads', 8, 'Reader threads (gzip NIfTI -> pinned staging) and writer threads (float64 label volume, gzip) '
                       'around the GPU in sequence mode; 0 = strictly sequential subjects as in the reference.')
     fs.DEFINE_integer('num_shards', env_cnt, 'Number of workers sharing data_dir.')
     fs.DEFINE_integer('shard_index', env_idx, 'This worker: subjects i with i % num_shards == shard_index.')
