@@ -946,7 +946,7 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
         }
 #ifdef UKBB_DIAG
         if ((a.diag & 16) && threadIdx.x == 0) {
-            unsigned long long *o = reinterpret_cast<unsigned long long *>(const_cast<float *>(a.first_w)) + (size_t)blockIdx.x * 16;
+            unsigned long long *o = reinterpret_cast<unsigned long long *>(const_cast<float *>(FIRST ? a.in1 : a.first_w)) + (size_t)blockIdx.x * 16;
             o[0] = __builtin_amdgcn_s_memtime() - st_t0; o[1] = __builtin_amdgcn_s_memrealtime() - st_r0;
             o[2] = st_wait; o[3] = st_mfma; o[4] = st_epi; o[5] = (unsigned long long)nstages;
             o[6] = st_r0; o[7] = __builtin_amdgcn_s_memrealtime();
@@ -1090,13 +1090,14 @@ hipError_t launch_conv(int cfg_id, const ConvArgs &a_in, hipStream_t s) {
     { const char *e = getenv("UKBB_CONV_DIAG"); a.diag = e ? atoi(e) : 0; }
     static unsigned long long *d_stamps = nullptr;
     const char *scfg = getenv("UKBB_CONV_STAMP_CFG");
-    const bool stamp = (a.diag & 16) && scfg && atoi(scfg) == cfg_id && !a.first_w;
+    const bool stamp = (a.diag & 16) && scfg && atoi(scfg) == cfg_id && (!a.first_w || !a.in1);   // fused-first kernel: in1 is free
     if (a.diag & 16) {
         if (!stamp) a.diag &= ~16;
         else {
             if (!d_stamps && hipMalloc(reinterpret_cast<void **>(&d_stamps), 1024 * 16 * 8) != hipSuccess) return hipErrorOutOfMemory;
             (void)hipMemsetAsync(d_stamps, 0, 1024 * 16 * 8, s);
-            a.first_w = reinterpret_cast<const float *>(d_stamps);
+            if (a.first_w) a.in1 = reinterpret_cast<const float *>(d_stamps);
+            else a.first_w = reinterpret_cast<const float *>(d_stamps);
         }
     }
     struct StampDump {
