@@ -413,3 +413,51 @@ def test_label_gzip_reports_a_short_buffer():
     import gzip
     assert gzip.decompress(out[:got].tobytes()) == lab.astype('<f8').tobytes()
     assert _lib.lib.ukbb_fcn_gzip_labels(lab.ctypes.data, lab.size, 1024, b'', 0, out.ctypes.data, cap) == -1         # int64: not offered
+
+
+# ---- .gz reader: zlib fed in large pieces (nifti._GzReader) ---------------------------------------------------------------
+
+def test_gz_reader_members_padding_truncation_and_crc(tmp_path):
+    """What gzip.open accepted must still load: several members, zero padding between / after them; what it refused must still fail."""
+    import gzip
+    import zlib
+    from ukbb_cardiac_amd import nifti
+    rng = np.random.default_rng(0)
+    vol = np.round(rng.gamma(2.0, 300.0, (40, 36, 3, 7))).astype(np.float32)
+    p = str(tmp_path / 'v.nii.gz')
+    nifti.save(vol, p, np.eye(4))
+    assert np.array_equal(nifti.load(p).get_data(), vol)
+    raw = gzip.open(p, 'rb').read()
+    multi = str(tmp_path / 'm.nii.gz')
+    with open(multi, 'wb') as f:
+        f.write(gzip.compress(raw[:100]) + b'\x00' * 5 + gzip.compress(raw[100:5000]) + gzip.compress(raw[5000:]) + b'\x00\x00')
+    assert np.array_equal(nifti.load(multi).get_data(), vol)
+    buf = np.empty(vol.shape, np.float32, order='F')
+    assert nifti.load(multi, alloc=lambda sh, dt: buf).get_data() is buf and np.array_equal(buf, vol)
+    whole = open(p, 'rb').read()
+    cut = str(tmp_path / 't.nii.gz')
+    open(cut, 'wb').write(whole[:len(whole) // 2])
+    with pytest.raises((EOFError, ValueError)):
+        nifti.load(cut)
+    bad = bytearray(whole)
+    bad[-6] ^= 0xff                                                          # CRC-32 of the member
+    open(cut, 'wb').write(bytes(bad))
+    with pytest.raises(zlib.error):
+        nifti.load(cut)
+    junk = str(tmp_path / 'j.nii.gz')                                        # bytes behind the voxel data are never reached, as with nibabel
+    open(junk, 'wb').write(whole + b'not a gzip member')
+    assert np.array_equal(nifti.load(junk).get_data(), vol)
+
+
+def test_gz_reader_small_pieces(tmp_path, monkeypatch):
+    """Piece boundaries anywhere in the stream (header, trailer, between members)."""
+    import gzip
+    from ukbb_cardiac_amd import nifti
+    vol = np.arange(30 * 20 * 4, dtype=np.int16).reshape(30, 20, 4)
+    p = str(tmp_path / 'v.nii.gz')
+    nifti.save(vol, p, np.eye(4))
+    raw = gzip.open(p, 'rb').read()
+    open(p, 'wb').write(gzip.compress(raw[:353]) + gzip.compress(raw[353:]))
+    for piece in (1, 2, 3, 7, 64, 1000):
+        monkeypatch.setattr(nifti._GzReader, 'PIECE', piece)
+        assert np.array_equal(nifti.load(p).get_data(), vol)
