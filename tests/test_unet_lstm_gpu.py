@@ -202,3 +202,34 @@ def test_aortic_script_device_and_host_preprocessing_write_the_same_file(tmp_pat
         deploy_network_ao.main(['--data_dir', str(tmp_path / 'data'), '--model_path', mp, '--time_step', '2', flag])
         out[flag] = (d / 'seg_ao.nii.gz').read_bytes()
     assert out['--device_preproc'] == out['--nodevice_preproc']
+
+
+def test_aortic_script_read_ahead_write_behind_gives_the_sequential_files(tmp_path, model):
+    """--io_threads only moves file work off the GPU thread: same subjects, same files as the strictly sequential loop."""
+    import shutil
+    from ukbb_cardiac_amd import deploy_network_ao, nifti
+    from ukbb_cardiac_amd.weights import save_blob
+    arch, params, eng = model
+    mp = str(tmp_path / 'UNet-LSTM_ao')
+    save_blob(mp + '.ukbbw', arch, params)
+    rng = np.random.default_rng(5)
+    src = tmp_path / 'src'
+    for i in range(5):
+        d = src / ('s%02d' % i)
+        d.mkdir(parents=True)
+        if i == 3:
+            continue                                                        # a subject directory without ao.nii.gz: skipped, as in the reference
+        vol = np.round(100 * rng.gamma(2.0, 1.0, size=(80 + 8 * i, 72, 1, 10 + i))).astype(np.float32)
+        nifti.save(vol, str(d / 'ao.nii.gz'), np.diag([1.6, 1.6, 6.0, 1.0]), pixdim=[1, 1.6, 1.6, 6, 0.01, 0, 0, 0])
+    out = {}
+    for thr in (0, 3):
+        work = tmp_path / ('run%d' % thr)
+        shutil.copytree(src, work)
+        lines = []
+        deploy_network_ao.run(deploy_network_ao.define_flags().parse(['--data_dir', str(work), '--model_path', mp, '--io_threads', str(thr)])[0],
+                              None, log=lines.append, cine_forward=lambda f, R, r, ts=1: eng.run_cine(f, R, r, ts)[0], engine=eng)
+        out[thr] = ({p.relative_to(work).as_posix(): p.read_bytes() for p in sorted(work.rglob('seg_ao.nii.gz'))},
+                    [l.replace(str(work), 'DIR') for l in lines if 'time' not in l and 'took' not in l])
+    assert sorted(out[0][0]) == ['s00/seg_ao.nii.gz', 's01/seg_ao.nii.gz', 's02/seg_ao.nii.gz', 's04/seg_ao.nii.gz']
+    assert out[0][0] == out[3][0]
+    assert out[0][1] == out[3][1]                                           # same log lines in the same order

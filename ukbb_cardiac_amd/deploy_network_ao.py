@@ -43,6 +43,8 @@ def define_flags():
     fs.DEFINE_integer('device', default_device(), 'HIP device ordinal (after HIP_VISIBLE_DEVICES); defaults to '
                       'LOCAL_RANK under torch.distributed.run.')
     fs.DEFINE_integer('batch_slices', 64, 'Slices per forward call.')
+    fs.DEFINE_integer('io_threads', 2, 'Sequence mode: threads that read (inflate) the next cines ahead of the GPU and threads that '
+                      'write finished segmentations behind it; 0 = strictly sequential subjects as in the reference.')
     fs.DEFINE_boolean('device_preproc', True, 'UNet-LSTM sequences: z-score, padding, transposes and the argmax on the GPU '
                       '(bit-identical to the host path; --nodevice_preproc restores it).')
     fs.DEFINE_integer('num_shards', env_cnt, 'Number of workers sharing data_dir.')
@@ -65,7 +67,31 @@ def run(FLAGS, forward, log=print, cine_forward=None, engine=None):
     data_list = subjects_for_shard(sorted(os.listdir(FLAGS.data_dir)), FLAGS.shard_index, FLAGS.num_shards)
     processed = []
     seq = FLAGS.seq_name
-    for data in data_list:
+    # Sequence mode with --io_threads > 0: the next cines are read (inflated) by reader threads while the GPU works on this one,
+    # and the segmentation files are written behind it; order of subjects, log lines and files are those of the sequential loop.
+    nthr = int(getattr(FLAGS, 'io_threads', 0)) if FLAGS.process_seq else 0
+    readers = writers = None
+    reads, writes = {}, []
+    if nthr > 0:
+        from concurrent.futures import ThreadPoolExecutor
+        readers, writers = ThreadPoolExecutor(nthr), ThreadPoolExecutor(nthr)
+        names = ['{0}/{1}.nii.gz'.format(os.path.join(FLAGS.data_dir, d), seq) for d in data_list]
+        names = [n if os.path.isdir(os.path.dirname(n)) and os.path.exists(n) else None for n in names]
+        ahead = [0]
+
+        def prefetch(upto):
+            while ahead[0] < min(upto, len(names)):
+                if names[ahead[0]] is not None:
+                    reads[ahead[0]] = readers.submit(nifti.load, names[ahead[0]])
+                ahead[0] += 1
+
+    def save(*args):
+        if writers is not None:
+            writes.append(writers.submit(nifti.save, *args))
+        else:
+            nifti.save(*args)
+
+    for idx, data in enumerate(data_list):
         log(data)
         data_dir = os.path.join(FLAGS.data_dir, data)
         if not os.path.isdir(data_dir):
@@ -77,7 +103,11 @@ def run(FLAGS, forward, log=print, cine_forward=None, engine=None):
                     data_dir, os.path.basename(image_name)))
                 continue
             log('  Reading {} ...'.format(image_name))
-            nim = nifti.load(image_name)
+            if readers is not None:
+                prefetch(idx + 1 + nthr)
+                nim = reads.pop(idx).result() if idx in reads else nifti.load(image_name)
+            else:
+                nim = nifti.load(image_name)
             image = nim.get_data()
             log('  Segmenting full sequence ...')
             t0 = time.time()
@@ -95,7 +125,7 @@ def run(FLAGS, forward, log=print, cine_forward=None, engine=None):
                 pred = np.argmax(prob, axis=-1).astype(np.int32)      # host argmax, as :189
             if FLAGS.save_seg:
                 log('  Saving segmentation ...')
-                nifti.save(pred, '{0}/seg_{1}.nii.gz'.format(data_dir, seq), nim.affine, nim.header['pixdim'])
+                save(pred, '{0}/seg_{1}.nii.gz'.format(data_dir, seq), nim.affine, nim.header['pixdim'])
             log('  Segmentation time = {:3f}s'.format(time.time() - t0))
             processed.append(data)
         else:
@@ -118,6 +148,13 @@ def run(FLAGS, forward, log=print, cine_forward=None, engine=None):
                     nifti.save(pred, '{0}/seg_{1}_{2}.nii.gz'.format(data_dir, seq, fr), nim.affine,
                                nim.header['pixdim'])
             processed.append(data)
+    if readers is not None:
+        try:
+            for w in writes:
+                w.result()
+        finally:
+            readers.shutdown(wait=True)
+            writers.shutdown(wait=True)
     process_time = time.time() - start_time
     if processed:
         log('Including image I/O and device resource allocation, it took {:.3f}s for processing {:d} subjects '
