@@ -777,7 +777,11 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
         }
     } else {
         // ===================== consumers: LDS -> MFMA -> global =====================
-        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        // wave index through readfirstlane: hipcc must KNOW it is wave-uniform, or the output descriptor built from wm below
+        // counts as divergent and every buffer store of the epilogue becomes a waterfall loop (4 v_readfirstlane + compares +
+        // exec masking per store -- r02: 2.4 k cycles of epilogue per tile in the fused first layer, in the shadow of the other
+        // workgroup's MFMA stream)
+        const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
         const int wm = wave / WN, wn = wave % WN;
         const int g = lane / PB, pl = lane % PB;
         int lbase[PBW];

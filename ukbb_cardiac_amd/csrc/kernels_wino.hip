@@ -139,7 +139,9 @@ __global__ __launch_bounds__(512, 2) void wino_pc_kernel(const ConvArgs a) {
         auto locate = [&]() {
             const int rest = l_item % per_group;
             l_n = rest / regions;
-            l_n0 = a.in0_map ? a.in0_map[l_n] : l_n;     // scalar load; ConvLSTM windows index shared feature frames
+            // ConvLSTM windows index shared feature frames.  readfirstlane: the loaded index arrives in a VGPR, and without it
+            // the buffer descriptors built from it count as divergent -- every halo load became a waterfall loop (r02)
+            l_n0 = a.in0_map ? __builtin_amdgcn_readfirstlane(a.in0_map[l_n]) : l_n;
             int r = rest - l_n * regions;
             if (rotate) r = (r + l_round) % regions;
             const int ry = r / regs_x, rx = r - ry * regs_x;
