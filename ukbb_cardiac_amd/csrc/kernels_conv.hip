@@ -388,11 +388,18 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
     const int nitems = per_group * (a.Cout / (MB * NCBL));
     const int my_items = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int nstages = my_items * nchunk;
-    const bool producer = __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256;
+    // Which half of the workgroup loads.  The SIMD's arbiter favours the older wave when two are ready (r02 A/B): the fused
+    // first layer, whose loaders run conv0_0 on the vector ALU (~200 instructions per tile that must find issue slots next to
+    // the MFMA stream), is 5 us faster with the loaders in waves 0-3; the other layers' loaders issue no VALU in steady state
+    // and are 1.5-2 us faster the usual way round.
+    constexpr bool PRODUCERS_FIRST = FIRST;
+    const bool producer = PRODUCERS_FIRST ? __builtin_amdgcn_readfirstlane(threadIdx.x) < 256
+                                          : __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256;
+    const int role_tid = threadIdx.x & 255;
 
     if (producer) {
         // ===================== producers: global -> registers -> LDS =====================
-        const int tid = threadIdx.x - 256;
+        const int tid = role_tid;
         const int c4 = tid % C4, pix0 = tid / C4;
         int item = blockIdx.x, ch = 0;
         if constexpr (FIRST) {
@@ -769,7 +776,7 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
                 }
             }
 #ifdef UKBB_DIAG
-            if ((a.diag & 16) && threadIdx.x == 256) {
+            if ((a.diag & 16) && role_tid == 0) {
                 unsigned long long *o = reinterpret_cast<unsigned long long *>(const_cast<float *>(a.first_w)) + (size_t)blockIdx.x * 16;
                 o[8] = __builtin_amdgcn_s_memtime() - st_p0; o[9] = st_pbar; o[10] = st_pstore; o[11] = straight ? 1 : 0;
             }
@@ -781,7 +788,7 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
         // counts as divergent and every buffer store of the epilogue becomes a waterfall loop (4 v_readfirstlane + compares +
         // exec masking per store -- r02: 2.4 k cycles of epilogue per tile in the fused first layer, in the shadow of the other
         // workgroup's MFMA stream)
-        const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
+        const int tid = role_tid, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
         const int wm = wave / WN, wn = wave % WN;
         const int g = lane / PB, pl = lane % PB;
         int lbase[PBW];
@@ -949,7 +956,7 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
             }
         }
 #ifdef UKBB_DIAG
-        if ((a.diag & 16) && threadIdx.x == 0) {
+        if ((a.diag & 16) && role_tid == 0) {
             unsigned long long *o = reinterpret_cast<unsigned long long *>(const_cast<float *>(FIRST ? a.in1 : a.first_w)) + (size_t)blockIdx.x * 16;
             o[0] = __builtin_amdgcn_s_memtime() - st_t0; o[1] = __builtin_amdgcn_s_memrealtime() - st_r0;
             o[2] = st_wait; o[3] = st_mfma; o[4] = st_epi; o[5] = (unsigned long long)nstages;
