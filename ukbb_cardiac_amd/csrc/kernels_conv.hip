@@ -408,26 +408,33 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
             // producers (a) turn raw tile s+1 (LDS) into the KC-channel halo tile of stage s+1,
             // (b) park raw tile s+2 (registers, loaded one iteration ago) in LDS, (c) request raw tile s+3.
             // VALU-lean like the other producers (every VALU instruction here is time taken from the MFMA
-            // waves): conv0_0 as packed FMAs (18 v_pk_fma_f32 per pixel quad), ReLU as one v_max_i32,
-            // per-thread LDS / global offsets computed once, raw pixels outside the image as out-of-range
-            // buffer loads, and the halo-validity select only in tiles that touch the image border.
+            // waves): ReLU as one v_max_i32, per-thread LDS / global offsets computed once, raw pixels outside
+            // the image as out-of-range buffer loads, and the halo-validity select only in tiles that touch the
+            // image border.
             float *raw = lds + 2 * BUF;                        // [2][RP]
-            f32x2 w0p[9][2], b0p[2];
+            // conv0_0 is a [16 x 9] x [9 x pixels] product: three v_mfma_f32_16x16x4_f32 per 16 halo pixels (taps 9..11 carry
+            // zero weights), bias as the C operand; the D layout (lane = pixel, 4 consecutive channels per lane) is exactly
+            // the float4 the halo tile stores.  30 instead of ~200 vector-ALU instructions per thread and tile.
+            static_assert(KC == 16, "fused first layer: 16 channels");
+            constexpr int NBLK = (HP + 15) / 16, NR = (NBLK + 3) / 4;      // 16-pixel blocks of the halo tile; rounds per producer wave
+            const int lane_ = tid & 63, pw_ = tid >> 6, pj = lane_ & 15, pg = lane_ >> 4;
+            float wA[3];                                       // A operand: W[cout = lane % 16][tap = 4 ks + lane / 16]
+            int toff[3];                                       // raw-tile offset of that tap (B operand: lane % 16 = pixel, lane / 16 = k)
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const f32x4 w = *reinterpret_cast<const f32x4 *>(a.first_w + t * KC + 4 * c4);
-                w0p[t][0] = f32x2{w[0], w[1]}; w0p[t][1] = f32x2{w[2], w[3]};
+            for (int ks = 0; ks < 3; ++ks) {
+                const int t = 4 * ks + pg;
+                wA[ks] = t < 9 ? a.first_w[t * KC + pj] : 0.f;
+                const int tt = t < 9 ? t : 8;                  // zero weight: any finite value of the tile will do
+                toff[ks] = (tt / 3) * RW + (tt % 3);
             }
-            {
-                const f32x4 b = *reinterpret_cast<const f32x4 *>(a.first_b + 4 * c4);
-                b0p[0] = f32x2{b[0], b[1]}; b0p[1] = f32x2{b[2], b[3]};
-            }
-            int hy[NIT], hx[NIT], roff[NIT];                   // halo coordinates of this thread's pixels, raw-tile offsets
+            const f32x4 biasq = *reinterpret_cast<const f32x4 *>(a.first_b + 4 * pg);
+            int hy[NR], hx[NR], roff[NR], xoff[NR];            // halo coordinates of this lane's pixel per round, raw / halo-tile offsets
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int pix = pix0 + it * PSTEP;
-                hy[it] = pix / IW; hx[it] = pix - hy[it] * IW;
-                roff[it] = pix < HP ? hy[it] * RW + hx[it] : 0;
+            for (int r = 0; r < NR; ++r) {
+                const int pix = (pw_ + 4 * r) * 16 + pj;
+                hy[r] = pix / IW; hx[r] = pix - hy[r] * IW;
+                roff[r] = pix < HP ? hy[r] * RW + hx[r] : 0;
+                xoff[r] = pix < HP ? pix * XS + 4 * pg : -1;
             }
             int ry_[NRAW], rx_[NRAW];
             unsigned rvo[NRAW];
@@ -469,7 +476,6 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
                 for (int k = 0; k < NRAW; ++k)
                     if (tid + 256 * k < RP) reinterpret_cast<unsigned *>(raw)[b * RP + tid + 256 * k] = rr[k];
             };
-            float *const xs_w = lds + pix0 * XS + 4 * c4;
             auto first_layer = [&](int braw, int bx, int it_item) {   // raw tile (LDS) -> relu(conv0_0 + b) -> xs[bx]
                 locate(it_item);
                 // halo pixels outside the image are conv0_1's zero padding, not conv0_0 of padded input
@@ -477,23 +483,23 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
                 const int xlo = hx0_ < 0 ? -hx0_ : 0, xhi = a.W - hx0_ < IW ? a.W - hx0_ : IW;
                 const bool interior = ylo == 0 && xlo == 0 && yhi == IH && xhi == IW;
                 const float *rt = raw + braw * RP;
+                float bvv[NR][3];
 #pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    const float *rp = rt + roff[it];
-                    f32x2 acc0 = b0p[0], acc1 = b0p[1];         // bias first: one rounding order, the same as the stand-alone kernel
+                for (int r = 0; r < NR; ++r)
 #pragma unroll
-                    for (int t = 0; t < 9; ++t) {
-                        const float v = rp[(t / 3) * RW + (t % 3)];
-                        const f32x2 vv = {v, v};
-                        acc0 = __builtin_elementwise_fma(vv, w0p[t][0], acc0);
-                        acc1 = __builtin_elementwise_fma(vv, w0p[t][1], acc1);
-                    }
-                    f32x4 r = {relu_bits(acc0[0]), relu_bits(acc0[1]), relu_bits(acc1[0]), relu_bits(acc1[1])};
+                    for (int ks = 0; ks < 3; ++ks) bvv[r][ks] = rt[roff[r] + toff[ks]];
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    if ((pw_ + 4 * r) * 16 >= HP) break;       // wave-uniform: this wave has no block in the last round
+                    f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[0], bvv[r][0], biasq, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[1], bvv[r][1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[2], bvv[r][2], acc, 0, 0, 0);
+                    f32x4 v = {relu_bits(acc[0]), relu_bits(acc[1]), relu_bits(acc[2]), relu_bits(acc[3])};
                     if (!interior) {
-                        const bool ok = (unsigned)(hy[it] - ylo) < (unsigned)(yhi - ylo) && (unsigned)(hx[it] - xlo) < (unsigned)(xhi - xlo);
-                        if (!ok) r = f32x4{0.f, 0.f, 0.f, 0.f};
+                        const bool ok = (unsigned)(hy[r] - ylo) < (unsigned)(yhi - ylo) && (unsigned)(hx[r] - xlo) < (unsigned)(xhi - xlo);
+                        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
-                    if (pix0 + it * PSTEP < HP) *reinterpret_cast<f32x4 *>(xs_w + bx * BUF + it * PSTEP * XS) = r;
+                    if (xoff[r] >= 0) *reinterpret_cast<f32x4 *>(lds + bx * BUF + xoff[r]) = v;
                 }
             };
             const int step = gridDim.x;
@@ -522,15 +528,40 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
                 if (nstages > 1) raw_store(1);
                 if (nstages > 2) raw_load(item + 2 * step);
             }
+#ifdef UKBB_DIAG
+            unsigned long long fp_bar = 0, fp_fl = 0, fp_rs = 0;
+            const unsigned long long fp_t0 = __builtin_amdgcn_s_memtime();
+#endif
             for (int s = 0; s < nstages; ++s) {
+#ifdef UKBB_DIAG
+                const unsigned long long q0 = __builtin_amdgcn_s_memtime();
+#endif
                 __syncthreads();                               // barrier #s
+#ifdef UKBB_DIAG
+                const unsigned long long q1 = __builtin_amdgcn_s_memtime();
+                fp_bar += q1 - q0;
+#endif
                 if (s + 1 < nstages) {
                     item += step;
                     first_layer((s + 1) & 1, (s + 1) & 1, item);
+#ifdef UKBB_DIAG
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    const unsigned long long q2 = __builtin_amdgcn_s_memtime();
+                    fp_fl += q2 - q1;
+#endif
                     if (s + 2 < nstages) raw_store(s & 1);     // R(s+2) replaces R(s)
                     if (s + 3 < nstages) raw_load(item + 2 * step);
+#ifdef UKBB_DIAG
+                    fp_rs += __builtin_amdgcn_s_memtime() - q2;
+#endif
                 }
             }
+#ifdef UKBB_DIAG
+            if ((a.diag & 16) && role_tid == 0) {
+                unsigned long long *o = reinterpret_cast<unsigned long long *>(const_cast<float *>(a.in1)) + (size_t)blockIdx.x * 16;
+                o[8] = __builtin_amdgcn_s_memtime() - fp_t0; o[9] = fp_bar; o[10] = fp_rs; o[11] = fp_fl;
+            }
+#endif
         } else {
             // Lean producer (r01: fp32 MFMA and VALU instructions serialise on a SIMD, tools/mfma_coissue.hip,
             // so every VALU instruction here is time taken from the consumers).  Halo-tile coordinates and
