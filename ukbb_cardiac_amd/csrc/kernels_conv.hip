@@ -993,6 +993,10 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
             o[2] = st_wait; o[3] = st_mfma; o[4] = st_epi; o[5] = (unsigned long long)nstages;
             o[6] = st_r0; o[7] = __builtin_amdgcn_s_memrealtime();
         }
+        if ((a.diag & 16) && lane == 0) {              // every consumer wave's own barrier wait and MFMA phase: who arrives last?
+            unsigned long long *o = reinterpret_cast<unsigned long long *>(const_cast<float *>(FIRST ? a.in1 : a.first_w)) + (size_t)blockIdx.x * 16;
+            o[12 + wave] = (st_wait << 32) | (st_mfma & 0xffffffffull);
+        }
 #endif
     }
 }
@@ -1166,6 +1170,10 @@ hipError_t launch_conv(int cfg_id, const ConvArgs &a_in, hipStream_t s) {
             fprintf(stderr, "[stamps cfg %d] %d WGs: consumer total %.0f cyc (%.2f GHz), stages %.1f: per stage barrier-wait %.0f, mfma %.0f; epilogue total %.0f | "
                             "producer total %.0f, barrier-wait %.0f per stage, store(+vmcnt wait) %.0f per stage, straight %.0f\n",
                     cfg, n, m[0], m[0] / (m[1] * 10.0) , m[5], m[2] / m[5], m[3] / m[5], m[4], m[8], m[9] / m[5], m[10] / m[5], m[11]);
+            double ww[4] = {0}, wm_[4] = {0};
+            for (int w = 0; w < 1024; ++w) if (h[w * 16]) for (int k = 0; k < 4; ++k) { ww[k] += (double)(h[w * 16 + 12 + k] >> 32); wm_[k] += (double)(h[w * 16 + 12 + k] & 0xffffffffull); }
+            fprintf(stderr, "[stamps cfg %d] per consumer wave (0..3), per stage: barrier-wait %.0f %.0f %.0f %.0f | mfma %.0f %.0f %.0f %.0f\n", cfg,
+                    ww[0] / n / m[5], ww[1] / n / m[5], ww[2] / n / m[5], ww[3] / n / m[5], wm_[0] / n / m[5], wm_[1] / n / m[5], wm_[2] / n / m[5], wm_[3] / n / m[5]);
         }
     } stamp_dump{stamp, s, d_stamps, cfg_id};
 #endif
