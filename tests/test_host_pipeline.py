@@ -461,3 +461,31 @@ def test_gz_reader_small_pieces(tmp_path, monkeypatch):
     for piece in (1, 2, 3, 7, 64, 1000):
         monkeypatch.setattr(nifti._GzReader, 'PIECE', piece)
         assert np.array_equal(nifti.load(p).get_data(), vol)
+
+
+def test_label_gzip_property_random_volumes(tmp_path):
+    """Property test: for random label volumes (any run structure, any supported voxel type, 1-4 dimensions) the run-length writer's
+    file inflates to header + the voxel bytes, and loads back to the array."""
+    import gzip
+    from hypothesis import given, settings, strategies as st
+    from ukbb_cardiac_amd import nifti
+    p = str(tmp_path / 'h.nii.gz')
+
+    @settings(max_examples=120, deadline=None)
+    @given(st.integers(0, 2 ** 32 - 1), st.sampled_from(['u1', 'i2', 'i4', 'f4', 'f8']), st.integers(1, 4), st.integers(1, 6),
+           st.sampled_from([2, 4, 256]), st.floats(0.0, 1.0))
+    def check(seed, dt, ndim, run_scale, n_labels, zero_frac):
+        rng = np.random.default_rng(seed)
+        shape = tuple(int(v) for v in rng.integers(1, 14, ndim))
+        n = int(np.prod(shape))
+        runs = rng.integers(1, 1 + 40 * run_scale, n)                       # run-structured labels
+        vals = rng.integers(0, n_labels, n)
+        vals[rng.random(n) < zero_frac] = 0
+        lab = np.repeat(vals, runs)[:n].astype(np.uint8).reshape(shape, order='F')
+        data = lab.astype(dt)
+        nifti.save(data, p, np.eye(4))
+        raw = gzip.open(p, 'rb').read()
+        assert raw[352:] == data.astype('<' + dt).tobytes(order='F')
+        assert np.array_equal(nifti.load(p).get_data(), data)
+
+    check()
