@@ -301,6 +301,26 @@ def test_aortic_pipeline_on_device(engines):
     assert (np.argmax(dev, -1) != np.argmax(ref, -1)).mean() < 1e-4
 
 
+@pytest.mark.parametrize('shape', [(200, 180, 1, 7), (96, 120, 2, 5)])
+def test_aortic_unet_device_pipeline_equals_host_pipeline(engines, shape):
+    """Frame-wise 'UNet' sequences with z-score / pack / argmax on the GPU (device_pipeline.aortic_unet_sequence_device) against
+    the numpy mirror of deploy_network_ao.py:92-128,189 driven by the same engine: identical labels, identical class counts."""
+    from ukbb_cardiac_amd import pipeline
+    from ukbb_cardiac_amd.device_pipeline import aortic_unet_sequence_device
+    eng = engines('UNet_ao')
+    rng = np.random.default_rng(shape[0])
+    vol = np.asfortranarray(np.round(1000.0 * rng.gamma(2.0, 1.0, size=shape)).astype(np.float32))
+    keep = vol.copy()
+    pred, aux = aortic_unet_sequence_device(vol, eng, batch_slices=4, return_aux=True)
+    assert np.array_equal(vol, keep)
+    prob = pipeline.aortic_prob_sequence(vol, lambda b: eng.run(b), batch_slices=3)
+    want = np.argmax(prob, axis=-1).astype(np.int32)
+    assert pred.dtype == np.int32 and np.array_equal(pred, want)
+    for c in range(3):
+        assert np.array_equal(aux['counts'][:, c], (want == c).sum(axis=(0, 1, 2)))
+    assert len(np.unique(pred)) > 1
+
+
 def test_sa_pipeline_on_device(engines):
     """deploy_network.py sequence mode on an un-padded (X,Y,Z,T) volume: device labels
     == C-oracle labels through the same host loop (pads 7/7 and 2/2: SURVEY 8(c))."""

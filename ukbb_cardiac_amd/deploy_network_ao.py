@@ -45,7 +45,7 @@ def define_flags():
     fs.DEFINE_integer('batch_slices', 64, 'Slices per forward call.')
     fs.DEFINE_integer('io_threads', 2, 'Sequence mode: threads that read (inflate) the next cines ahead of the GPU and threads that '
                       'write finished segmentations behind it; 0 = strictly sequential subjects as in the reference.')
-    fs.DEFINE_boolean('device_preproc', True, 'UNet-LSTM sequences: z-score, padding, transposes and the argmax on the GPU '
+    fs.DEFINE_boolean('device_preproc', True, 'Sequences: z-score, padding, transposes and the argmax on the GPU '
                       '(bit-identical to the host path; --nodevice_preproc restores it).')
     fs.DEFINE_integer('num_shards', env_cnt, 'Number of workers sharing data_dir.')
     fs.DEFINE_integer('shard_index', env_idx, 'This worker: subjects i with i % num_shards == shard_index.')
@@ -111,11 +111,14 @@ def run(FLAGS, forward, log=print, cine_forward=None, engine=None):
             image = nim.get_data()
             log('  Segmenting full sequence ...')
             t0 = time.time()
-            on_device = (FLAGS.model == 'UNet-LSTM' and engine is not None and getattr(FLAGS, 'device_preproc', False)
+            on_device = (engine is not None and getattr(FLAGS, 'device_preproc', False)
                          and FLAGS.z_score and image.ndim == 4 and image.dtype == np.float32)
-            if on_device:
+            if on_device and FLAGS.model == 'UNet-LSTM':
                 from ukbb_cardiac_amd.device_pipeline import aortic_lstm_sequence_device
                 pred = aortic_lstm_sequence_device(image, engine, True, FLAGS.weight_R, FLAGS.weight_r, FLAGS.time_step)
+            elif on_device:
+                from ukbb_cardiac_amd.device_pipeline import aortic_unet_sequence_device
+                pred = aortic_unet_sequence_device(image, engine, FLAGS.batch_slices)
             else:
                 if FLAGS.model == 'UNet-LSTM':
                     prob = pipeline.aortic_lstm_prob_sequence(image, cine_forward, FLAGS.z_score, FLAGS.weight_R, FLAGS.weight_r,

@@ -205,3 +205,38 @@ def aortic_lstm_sequence_device(image, engine, z_score=True, weight_R=5, weight_
     p = prob[:, :, x_pre:x_pre + X, y_pre:y_pre + Y].permute(2, 3, 1, 0, 4)
     aux['prob'] = p.cpu().numpy()
     return out, aux
+
+
+def aortic_unet_sequence_device(image, engine, batch_slices=128, return_aux=False):
+    """pipeline.aortic_prob_sequence + the argmax of deploy_network_ao.py:189 for the frame-wise 'UNet' model with the array work
+    on the GPU: device z-score, pack, batched forward (the engine's label map is the argmax of the probabilities it would
+    return), labels back as uint8.  (X,Y,Z,T) float32 -> int32 labels (X,Y,Z,T)."""
+    import torch
+    if image.ndim != 4 or image.dtype != np.float32:
+        raise TypeError('expected a 4-D float32 (X,Y,Z,T) cine; use pipeline.aortic_prob_sequence otherwise')
+    X, Y, Z, T = image.shape
+    dev = torch.device('cuda', engine.device)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    src = image if (image.flags.f_contiguous or image.flags.c_contiguous) else np.asfortranarray(image)
+    vol = torch.from_numpy(src).to(dev)
+    mu, den, n_roi, val_l = device_zscore_stats(vol, 10.0, stream)
+    X2, Y2, x_pre, _, y_pre, _ = pad_amounts_fixed(X, Y)
+    n = T * Z
+    batch = torch.empty((n, X2, Y2), dtype=torch.float32, device=dev)
+    sx, sy, sz, st = vol.stride()
+    _lib.check(_lib.lib.ukbb_fcn_zscore_pack(vol.data_ptr(), X, Y, Z, T, sx, sy, sz, st, float(mu), float(den), X2, Y2, x_pre, y_pre,
+                                             batch.data_ptr(), stream), 'ukbb_fcn_zscore_pack')
+    pred = torch.empty((n, X2, Y2), dtype=torch.int32, device=dev)
+    engine.reserve(min(batch_slices, n), X2, Y2)
+    for i in range(0, n, batch_slices):
+        m = min(batch_slices, n - i)
+        engine.run_device(batch[i].data_ptr(), m, X2, Y2, pred_ptr=pred[i].data_ptr(), stream=stream)
+    n_class = engine.arch.n_class
+    lab = torch.empty(X * Y * Z * T, dtype=torch.uint8, device=dev)
+    counts = torch.empty((T, n_class), dtype=torch.int64, device=dev)
+    _lib.check(_lib.lib.ukbb_fcn_unpack_labels(pred.data_ptr(), X, Y, Z, T, X2, Y2, x_pre, y_pre, n_class,
+                                               lab.data_ptr(), counts.data_ptr(), stream), 'ukbb_fcn_unpack_labels')
+    out = lab.cpu().numpy().reshape((X, Y, Z, T), order='F').astype(np.int32)
+    if return_aux:
+        return out, {'mu': mu, 'den': den, 'n_roi': n_roi, 'val_l': val_l, 'counts': counts.cpu().numpy()}
+    return out
