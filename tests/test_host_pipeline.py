@@ -489,3 +489,28 @@ def test_label_gzip_property_random_volumes(tmp_path):
         assert np.array_equal(nifti.load(p).get_data(), data)
 
     check()
+
+
+def test_aortic_deploy_read_ahead_threads_change_nothing(tmp_path):
+    """deploy_network_ao --io_threads: several subjects (one directory without a cine, one stray file) with the stand-in network;
+    files and log lines equal those of the strictly sequential loop."""
+    import shutil
+    src = tmp_path / 'src'
+    src.mkdir()
+    for i in range(6):
+        if i == 2:
+            (src / 'b2').mkdir()                                             # no ao.nii.gz inside
+            continue
+        _write_subject(src, 'a%d' % i, 'ao', (24 + 2 * i, 20, 1, 4 + i), 10 + i)
+    (src / 'notes.txt').write_text('not a subject directory')
+    out = {}
+    for thr in (0, 1, 4):
+        work = tmp_path / ('run%d' % thr)
+        shutil.copytree(src, work)
+        lines = []
+        F, _ = DA.define_flags().parse(['--data_dir', str(work), '--model', 'UNet', '--model_path', 'x', '--io_threads', str(thr)])
+        done = DA.run(F, stub_forward, log=lines.append)
+        out[thr] = (done, {p.relative_to(work).as_posix(): p.read_bytes() for p in sorted(work.rglob('seg_ao.nii.gz'))},
+                    [l.replace(str(work), 'DIR') for l in lines if 'time' not in l and 'took' not in l])
+    assert out[0][0] == ['a0', 'a1', 'a3', 'a4', 'a5'] and len(out[0][1]) == 5
+    assert out[0] == out[1] == out[4]
