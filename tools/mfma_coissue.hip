@@ -21,6 +21,7 @@ __global__ __launch_bounds__(512) void k(unsigned long long *stamps, float *sink
     for (int i = threadIdx.x; i < 4096; i += 512) lds[i] = (float)(i & 7);
     __syncthreads();
     const bool producer = __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256;
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) stamps[4 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_getreg(63492);   // HW_ID: wave slot [3:0], SIMD [5:4]
     unsigned long long t0, t1;
     if (!producer) {
         if (!run_m) return;
@@ -158,6 +159,7 @@ void run(const char *name, unsigned long long *d_st, float *d_sink) {
         hipDeviceSynchronize();
         hipMemcpy(h, d_st, 16, hipMemcpyDeviceToHost);
         const double nm = 32.0 * iters, nv = 32.0 * iters;
+        if (cfg == 2) { unsigned long long hh[12]; hipMemcpy(hh, d_st, 96, hipMemcpyDeviceToHost); printf("   waves 0..7: SIMD"); for (int w = 0; w < 8; ++w) printf(" %llu", (hh[4 + w] >> 4) & 3); printf("  slot"); for (int w = 0; w < 8; ++w) printf(" %llu", hh[4 + w] & 15); printf("\n"); }
         printf("%-34s %-22s mfma %7.1f cyc/inst   other %7.1f cyc/inst\n", name,
                cfg == 0 ? "mfma alone" : cfg == 1 ? "other alone" : cfg == 2 ? "together" : "together, other prio 3",
                rm ? h[0] / nm : 0.0, rv ? h[1] / nv : 0.0);
@@ -166,7 +168,7 @@ void run(const char *name, unsigned long long *d_st, float *d_sink) {
 
 int main() {
     unsigned long long *d_st; float *d_sink;
-    hipMalloc(&d_st, 16); hipMalloc(&d_sink, 256 * 512 * 4);
+    hipMalloc(&d_st, 256); hipMalloc(&d_sink, 256 * 512 * 4);
     run<0, 0>("16x16x4 + indep v_fma_f32", d_st, d_sink);
     run<0, 1>("16x16x4 + dependent v_fma_f32", d_st, d_sink);
     run<0, 2>("16x16x4 + indep v_pk_fma_f32", d_st, d_sink);
