@@ -181,6 +181,36 @@ def inflight_probe(arch, params, x, n, steps):
             'note': 'same workload, two batches in flight on two HIP streams (two workspaces); not the headline'}
 
 
+def f32x3_probe(eng, x, n, steps, head_index):
+    """Reported beside the headline, never as it: the same K steps with UKBB_PREC_F32X3 (include/ukbb_fcn.h): the FCN head's
+    out0 / out1 products from three bf16 pieces per fp32 operand on the dense matrix cores, fp32 accumulation.  Same logits error
+    against the fp64 oracle and the same label maps as the fp32 path (tests/test_gpu_parity.py test_f32x3_*), but not the
+    instruction the metric names (fp32 MFMA), hence its own field."""
+    import torch
+    pred = torch.empty((n, H, W), dtype=torch.int32, device=x.device)
+    eng.set_precision('f32x3')
+    try:
+        for _ in range(4):
+            eng.run_device(x.data_ptr(), n, H, W, pred_ptr=pred.data_ptr())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.run_device(x.data_ptr(), n, H, W, pred_ptr=pred.data_ptr())
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        eng.set_timing(True)
+        for _ in range(5):
+            eng.run_device(x.data_ptr(), n, H, W, pred_ptr=pred.data_ptr())
+        ms, cnt = eng.kernel_times()
+        eng.set_timing(False)
+        head_us = ms[head_index] / max(1, cnt[head_index]) * 1e3
+    finally:
+        eng.set_precision('fp32')
+    return {'value': round(n * steps / dt, 1), 'unit': 'slices/s', 'ms_per_step': round(dt / steps * 1e3, 4), 'head_us': round(head_us, 1),
+            'note': 'same workload with ukbb_fcn_set_precision(UKBB_PREC_F32X3): head products from three bf16 pieces per fp32 '
+                    'operand (6 bf16 MFMAs per fp32 MFMA\'s worth, fp32 accumulate); parity identical to fp32; not the headline'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -188,6 +218,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=BATCH)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-f32x3-probe', action='store_true', help='skip the extra K steps in UKBB_PREC_F32X3 mode reported as out["f32x3"]')
     ap.add_argument('--pmc-traffic', default=None,
                     help='JSON written by tools/pmc_traffic.py (rocprofv3 --pmc passes of this build); default: the newest '
                          'profiles/r*_pmc_traffic.json whose kernel_source_sha matches the sources in this tree')
@@ -354,6 +385,8 @@ def main():
             out['roofline_detail'] = detail
         if world == 1 and args.inflight_probe:
             out['two_batches_in_flight'] = inflight_probe(arch, params, x, n, args.steps)
+        if world == 1 and not args.no_f32x3_probe:
+            out['f32x3'] = f32x3_probe(eng, x, n, args.steps, eng.kernel_names().index('head'))
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -94,6 +94,14 @@ void ukbb_fcn_destroy(ukbb_fcn_handle *h);
  * against the fp32 result (common/image_utils.py:171-175). */
 #define UKBB_PREC_FP32 0
 #define UKBB_PREC_BF16 1
+/* UKBB_PREC_F32X3 (round 2, FCN head only so far): fp32 results from bf16 matrix instructions.  Every fp32 operand x is
+ * split exactly into three bf16 pieces (h = bf16(x), m = bf16(x - h), l = x - h - m); the six partial products whose
+ * magnitude can reach 2^-24 of |x||w| (hh, hm, mh, mm, hl, lh) run on the dense matrix cores with fp32 accumulation,
+ * the other three (< 2^-24 |x||w|) are dropped -- less than what fp32 accumulation itself rounds away.  Measured
+ * against the fp64 oracle the logits error is the same as UKBB_PREC_FP32's (4e-6 relative) and the label maps are
+ * identical; it is a different instruction sequence from an fp32 MFMA, so it is offered as its own mode and reported
+ * under its own name, never as the default.  Layers not converted yet run exactly as in UKBB_PREC_FP32. */
+#define UKBB_PREC_F32X3 2
 int ukbb_fcn_set_precision(ukbb_fcn_handle *h, int precision);
 
 /* Pre-size the activation workspace for batches up to n x h x w (optional;

@@ -196,3 +196,26 @@ def test_bench_two_rank_launch_rehearsal():
     # a mismatch between --gpus and the launched world size is refused
     bad = _run([os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'])
     assert bad.returncode != 0 and 'torch.distributed.run' in bad.stdout
+
+
+def test_precision_flag_f32x3_writes_the_fp32_labels(tmp_path):
+    """deploy_network.py --precision f32x3 (UKBB_PREC_F32X3): a phantom cine through both arithmetic modes of the drop-in script;
+    the label volumes may differ only at numerical ties (here: not at all or in a handful of voxels)."""
+    import shutil
+    from ukbb_cardiac_amd import deploy_network, nifti
+    from ukbb_cardiac_amd.phantom import cine_phantom
+    arch, params, flat, mp = _model(tmp_path, 'FCN_sa')
+    X, Y, Z, T = 150, 170, 3, 6
+    vol = np.round(cine_phantom(Z * T, X, Y, seed=8)[..., 0].reshape(T, Z, X, Y).transpose(2, 3, 1, 0) * 1000.0).astype(np.float32)
+    src = tmp_path / 'src' / 'subj1'
+    src.mkdir(parents=True)
+    nifti.save(vol, str(src / 'sa.nii.gz'), np.diag([1.8, 1.8, 10.0, 1.0]), pixdim=[1, 1.8, 1.8, 10, 0.03, 0, 0, 0])
+    seg = {}
+    for prec in ('fp32', 'f32x3'):
+        work = tmp_path / prec
+        shutil.copytree(tmp_path / 'src', work)
+        deploy_network.main(['--seq_name', 'sa', '--data_dir', str(work), '--model_path', mp, '--precision', prec])
+        seg[prec] = nifti.load(str(work / 'subj1' / 'seg_sa.nii.gz')).get_data()
+    assert seg['fp32'].shape == vol.shape and seg['fp32'].dtype == np.float64
+    assert int((seg['fp32'] != seg['f32x3']).sum()) <= 3
+    assert len(np.unique(seg['f32x3'])) > 1

@@ -371,3 +371,85 @@ def test_unet_bf16_dice_vs_fp32():
         assert np_categorical_dice(b16['pred'], f32['pred'], k) >= 0.98
         assert np_categorical_dice(b16['pred'][:1], ref, k) >= 0.98
     assert (b16['pred'] != f32['pred']).mean() < 0.02
+
+
+# ---- UKBB_PREC_F32X3: fp32 results from three bf16 pieces per operand (FCN head), graded exactly like the fp32 path -----
+
+@pytest.fixture(scope='module')
+def engines_x3():
+    from ukbb_cardiac_amd.arch import MODELS
+    from ukbb_cardiac_amd.engine import Engine
+    from ukbb_cardiac_amd.weights import synthetic_params
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = Engine(MODELS[name], synthetic_params(MODELS[name], 1234))
+            cache[name].set_precision('f32x3')
+        return cache[name]
+    yield get
+    for e in cache.values():
+        e.close()
+
+
+@pytest.mark.parametrize('tag', FCN_GOLDENS)
+def test_f32x3_fcn_golden(engines_x3, engines, tag, parity_log):
+    """Same goldens, same tolerances as test_fcn_golden; and the mode really takes another path (logits differ in the last bits)."""
+    g = np.load(os.path.join(GOLD, tag + '.npz'))
+    out = engines_x3(str(g['model'])).run(g['image'], want_logits=True, want_prob=True, want_pred=True)
+    ref = g['logits64']
+    scale = np.abs(ref).max()
+    err = np.abs(out['logits'] - ref).max()
+    assert err <= LOGIT_RTOL * scale
+    bad = out['pred'] != g['pred64']
+    parity_log(model=str(g['model']) + ' f32x3', shape=list(g['image'].shape[:3]), oracle='numpy fp64 (committed golden)',
+               max_logits_err=float(err), logits_scale=float(scale), rel_err=float(err / scale), pixels=int(bad.size),
+               label_flips=int(bad.sum()), flips_away_from_tie=int((bad & (g['margin64'] > NEAR_TIE)).sum()),
+               near_tie_pixels=int((g['margin64'] <= NEAR_TIE).sum()))
+    assert not np.any(bad & (g['margin64'] > NEAR_TIE))
+    assert bad.sum() <= max(1, int((g['margin64'] <= NEAR_TIE).sum()))
+    assert np.array_equal(np.argmax(out['prob'], -1).astype(np.int32), out['pred'])
+    if g['image'].shape[1] >= 32:                              # big enough for the producer/consumer head kernel
+        plain = engines(str(g['model'])).run(g['image'], want_logits=True)['logits']
+        assert np.abs(plain - out['logits']).max() <= 1e-5 * scale
+
+
+def test_f32x3_full_batch64_vs_c_oracle(engines_x3, parity_log):
+    from ukbb_cardiac_amd.arch import MODELS
+    from ukbb_cardiac_amd.phantom import uniform_slices
+    from ukbb_cardiac_amd.weights import synthetic_params
+    arch = MODELS['FCN_sa']
+
+    def log(**kw):
+        kw['model'] = kw.get('model', '') + ' f32x3'
+        parity_log(**kw)
+    _grade_vs_c_oracle(engines_x3('FCN_sa'), arch, synthetic_params(arch, 1234), uniform_slices(64, 192, 208, seed=1), log)
+
+
+@pytest.mark.parametrize('model,shape', [('FCN_la_2ch', (50, 176, 208)), ('FCN_la_4ch_seg4', (50, 176, 208)), ('FCN_sa', (4, 208, 256))])
+def test_f32x3_config3_shapes_vs_c_oracle(engines_x3, parity_log, model, shape):
+    from ukbb_cardiac_amd.arch import MODELS
+    from ukbb_cardiac_amd.phantom import cine_phantom
+    from ukbb_cardiac_amd.weights import synthetic_params
+    arch = MODELS[model]
+
+    def log(**kw):
+        kw['model'] = kw.get('model', '') + ' f32x3'
+        parity_log(**kw)
+    _grade_vs_c_oracle(engines_x3(model), arch, synthetic_params(arch, 1234), cine_phantom(*shape, seed=17).astype(np.float32), log)
+
+
+def test_f32x3_is_deterministic_and_switchable(engines_x3):
+    from ukbb_cardiac_amd.phantom import uniform_slices
+    eng = engines_x3('FCN_sa')
+    img = uniform_slices(3, 96, 112, seed=4)
+    a = eng.run(img, want_logits=True)
+    b = eng.run(img, want_logits=True)
+    assert np.array_equal(a['logits'], b['logits']) and np.array_equal(a['pred'], b['pred'])
+    eng.set_precision('fp32')
+    c = eng.run(img, want_logits=True)
+    eng.set_precision('f32x3')
+    d = eng.run(img, want_logits=True)
+    assert np.array_equal(a['logits'], d['logits'])
+    assert not np.array_equal(a['logits'], c['logits'])        # another instruction sequence ...
+    assert np.abs(a['logits'] - c['logits']).max() <= 1e-5 * np.abs(c['logits']).max()   # ... the same numbers to fp32 accuracy

@@ -16,7 +16,7 @@ ENGINE_NAMES = (('fcn_head', 'head'), ('sqg_multi', 'sqg1-4'))
 
 
 def main(path):
-    out = {'_note': 'HBM traffic per launch from rocprofv3 --pmc passes of `python3 bench.py --no-cpu-baseline '
+    out = {'_note': 'HBM traffic per launch from rocprofv3 --pmc passes of `python3 bench.py --no-cpu-baseline --no-f32x3-probe '
                     '--no-kernel-events --steps 3 --warmup 1` (tools/run_pmc.sh: FETCH_SIZE and WRITE_SIZE collected in '
                     'separate passes, never with --kernel-trace). Units are KB; on gfx950 FETCH_SIZE reports half the '
                     'bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM) so hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.',

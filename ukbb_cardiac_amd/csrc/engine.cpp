@@ -119,7 +119,7 @@ struct ukbb_fcn_handle {
     DevBuf io_image, io_logits, io_prob, io_pred;   // staging for forward_host
 
     // plan
-    int precision = 0;                        // 0: fp32; 1: bf16 operands for the MFMA convs (fp32 accumulate)
+    int precision = 0;                        // 0: fp32; 1: bf16 operands for the MFMA convs (fp32 accumulate); 2: fp32 from bf16 pieces (head)
     int plan_h = 0, plan_w = 0, cap_n = 0;
     bool plan_small = false;                  // plan built with the small-batch tilings
     std::vector<Op> ops;
@@ -774,9 +774,11 @@ int run_plan(ukbb_fcn_handle *h, const float *image, int n, float *logits, float
                 ha.w_s0 = dev_ptr(h, "head/w_s0"); ha.b_s0 = dev_ptr(h, "same_dim0/bias");
                 ha.w_o0 = dev_ptr(h, "head/w_o0"); ha.b_o0 = dev_ptr(h, "out0/bias");
                 ha.w_o1 = dev_ptr(h, "head/w_o1"); ha.b_o1 = dev_ptr(h, "out1/bias");
+                ha.w_o1x3 = dev_ptr(h, "head/w_o1x3"); ha.w_o0x3 = dev_ptr(h, "head/w_o0x3");
                 ha.w_lg = dev_ptr(h, "head/w_lg"); ha.b_lg = dev_ptr(h, "logits/bias");
                 ha.logits = logits; ha.prob = prob; ha.pred = pred;
                 ha.N = n; ha.H = op.H; ha.W = op.W; ha.n_class = a.n_class;
+                ha.x3 = h->precision == UKBB_PREC_F32X3;
                 e = launch_head(ha, s);
                 break;
             }
@@ -926,6 +928,10 @@ ukbb_fcn_handle *ukbb_fcn_create(const ukbb_fcn_arch *arch, const float *weights
         pack_rowmap_32x64(o1.w.data(), 64, v.data());
         pack_rowmap_32x64(o1.w.data() + 32 * 64, 64, v.data() + 2 * 4 * 64 * 4);
         if (upload(h.get(), "head/w_o1", v)) return nullptr;
+        v.assign(3 * 2 * 4 * 64 * 4, 0.f);      pack_head_x3(o1.w.data(), 64, v.data());
+        if (upload(h.get(), "head/w_o1x3", v)) return nullptr;
+        v.assign(3 * 2 * 2 * 64 * 4, 0.f);      pack_head_x3(o0.w.data(), 32, v.data());
+        if (upload(h.get(), "head/w_o0x3", v)) return nullptr;
         v.assign(2 * arch->n_class * 32, 0.f);  pack_head_lg(lg.w.data(), arch->n_class, v.data());
         if (upload(h.get(), "head/w_lg", v)) return nullptr;
         for (int l = 1; l < arch->n_level; ++l) {
@@ -1168,7 +1174,7 @@ double ukbb_fcn_kernel_mfma_macs(const ukbb_fcn_handle *h, int i) {
 }
 
 int ukbb_fcn_set_precision(ukbb_fcn_handle *h, int precision) {
-    if (!h || (precision != UKBB_PREC_FP32 && precision != UKBB_PREC_BF16)) { set_err("set_precision: bad argument"); return UKBB_EINVAL; }
+    if (!h || (precision != UKBB_PREC_FP32 && precision != UKBB_PREC_BF16 && precision != UKBB_PREC_F32X3)) { set_err("set_precision: bad argument"); return UKBB_EINVAL; }
     if (precision != h->precision) {
         if (hipSetDevice(h->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { set_err("set_precision: device sync failed"); return UKBB_EDEVICE; }
         h->precision = precision;

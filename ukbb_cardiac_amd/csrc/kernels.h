@@ -109,18 +109,22 @@ struct HeadArgs {
     const float *b_o0;       // [64]
     const float *w_o1;       // pack_rowmap_32x64(out1 rows 0..31) ++ pack_rowmap_32x64(out1 rows 32..63)
     const float *b_o1;       // [64]
+    const float *w_o0x3;     // optional (experiment UKBB_HEAD_X3): pack_head_x3(out0 rows 0..31, 32) -- three bf16 pieces per weight; may be null
+    const float *w_o1x3;     // optional: pack_head_x3(out1, 64)
     const float *w_lg;       // pack_head_lg: [2][n_class][32]
     const float *b_lg;       // [n_class]
     float *logits;           // optional [N,H,W,n_class]
     float *prob;             // optional
     int32_t *pred;           // optional [N,H,W]
     int N, H, W, n_class;
+    int x3;                  // UKBB_PREC_F32X3: out0's level-0 slice and out1 from bf16 pieces (needs w_o0x3 / w_o1x3)
     int diag;                // diagnostic builds only (-DUKBB_DIAG, env UKBB_HEAD_DIAG): ablation bits of fcn_head_pc_kernel
 };
 hipError_t launch_head(const HeadArgs &a, hipStream_t s);
 void pack_sq(const float *w /*[cin][32] folded*/, int cin, float *dst /*cin*32*/);
 void pack_rowmap_32x64(const float *w /*32 rows x 64 cols*/, int ld, float *dst /*2*4*64*4*/);
 void pack_head_lg(const float *w /*[64][n_class]*/, int n_class, float *dst /*2*n_class*32*/);
+void pack_head_x3(const float *w /*[k_in][64 out]*/, int k_in /*32 | 64*/, float *dst /*3*2*(k_in/16)*64*4 dwords*/);
 
 // ---------------------------------------------------------------------------
 // U-Net pieces (network_ao.py:48-63)

@@ -26,6 +26,7 @@
 #include "kernels.h"
 
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 namespace ukbb {
@@ -506,15 +507,21 @@ constexpr int PX_WAVE = 8 * 64 * 4;                    // floats of one handed-o
 // LDS map of fcn_head_pc_kernel (floats)
 constexpr int L_GW = 0;                                // [2][GPIX][GSTRIDE]  G windows, double buffered per tile
 constexpr int L_PX = L_GW + 2 * GPIX * GSTRIDE;        // [4][PX_WAVE]        hand-over tiles (single buffered)
-constexpr int L_WS0 = L_PX + 4 * PX_WAVE;              // pack_sq(same_dim0)           512
-constexpr int L_WO0 = L_WS0 + 512;                     // pack_rowmap(out0 rows 0..31) 2048
-constexpr int L_WO1 = L_WO0 + 2048;                    // pack_rowmap(out1) x2         4096
-constexpr int L_BS0 = L_WO1 + 4096;                    // 32
-constexpr int L_BO0 = L_BS0 + 32;                      // 64
-constexpr int L_BO1 = L_BO0 + 64;                      // 64
-constexpr int L_WLG = L_BO1 + 64;                      // [2][NCLS][32] <= 384
-constexpr int L_BLG = L_WLG + 384;                     // <= 8
-constexpr int HEADPC_LDS_FLOATS = L_BLG + 8;
+// Weight part of the map: fp32 fragments, or (X3) out0's level-0 slice and out1 as three bf16 pieces per weight
+template <bool X3> struct HeadLds {
+    static constexpr int WS0 = L_PX + 4 * PX_WAVE;             // pack_sq(same_dim0)                                   512
+    static constexpr int WO0 = WS0 + 512;                      // pack_rowmap(out0 rows 0..31) 2048 | pack_head_x3(.., 32) 3072 dwords
+    static constexpr int WO1 = WO0 + (X3 ? 3072 : 2048);       // pack_rowmap(out1) x2         4096 | pack_head_x3(.., 64) 6144 dwords
+    static constexpr int BS0 = WO1 + (X3 ? 6144 : 4096);       // 32
+    static constexpr int BO0 = BS0 + 32;                       // 64
+    static constexpr int BO1 = BO0 + 64;                       // 64
+    static constexpr int WLG = BO1 + 64;                       // [2][NCLS][32] <= 384
+    static constexpr int BLG = WLG + 384;                      // <= 8
+    static constexpr int FLOATS = BLG + 8;
+};
+constexpr int HEADPC_LDS_FLOATS = HeadLds<false>::FLOATS;
+constexpr int HEADPC_X3_LDS_FLOATS = HeadLds<true>::FLOATS;
+static_assert(HEADPC_X3_LDS_FLOATS * 4 <= 160 * 1024, "head kernel LDS");
 
 __device__ __forceinline__ f32x4 lds4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 
@@ -547,9 +554,31 @@ __device__ __forceinline__ void chain_32to64_lds(const float *wp, int lane, cons
     }
 }
 
-template <int NCLS>
+// ---- X3 experiment: an fp32-exact product from bf16 pieces on the dense matrix cores ---------------------------------------
+// x = h + m + l with h = bf16(x), m = bf16(x - h), l = x - h - m (all exact in fp32); W likewise on the host.  The six partial
+// products that matter (hh, hm, mh, mm, hl, lh) run as v_mfma_f32_32x32x16_bf16 with fp32 accumulation; what is dropped is
+// below 2^-24 of |x||w| per product (profiles/r02_notes.md section 11).
+typedef __bf16 hbf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
+    const __bf16 l = (__bf16)lo, h = (__bf16)hi;       // RNE; v_cvt_pk_bf16_f32
+    return (unsigned)__builtin_bit_cast(unsigned short, l) | ((unsigned)__builtin_bit_cast(unsigned short, h) << 16);
+}
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
+    h = pk_bf16(x0, x1);
+    const float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
+    m = pk_bf16(r0, r1);
+    const float q0 = r0 - __builtin_bit_cast(float, m << 16), q1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+    l = pk_bf16(q0, q1);
+}
+__device__ __forceinline__ f32x16 mfma_b16(const u32x4 &a, const u32x4 &b, const f32x16 &c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hbf16x8, a), __builtin_bit_cast(hbf16x8, b), c, 0, 0, 0);
+}
+
+template <int NCLS, bool X3 = false>
 __global__ __launch_bounds__(768) void fcn_head_pc_kernel(const HeadArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    using LM = HeadLds<X3>;
+    constexpr int L_WS0 = LM::WS0, L_WO0 = LM::WO0, L_WO1 = LM::WO1, L_BS0 = LM::BS0, L_BO0 = LM::BO0, L_BO1 = LM::BO1, L_WLG = LM::WLG, L_BLG = LM::BLG;
     float *gw = lds + L_GW;
     float *px = lds + L_PX;
     const int tiles_x = a.W / HT, tiles_y = a.H / HT;
@@ -565,7 +594,9 @@ __global__ __launch_bounds__(768) void fcn_head_pc_kernel(const HeadArgs a) {
         auto copy = [&](int dst, const float *src, int nfloat) {
             for (int i = t; i < nfloat; i += 768) lds[dst + i] = src[i];
         };
-        copy(L_WS0, a.w_s0, 512); copy(L_WO0, a.w_o0, 2048); copy(L_WO1, a.w_o1, 4096);
+        copy(L_WS0, a.w_s0, 512);
+        if constexpr (X3) { copy(L_WO0, a.w_o0x3, 3072); copy(L_WO1, a.w_o1x3, 6144); }
+        else              { copy(L_WO0, a.w_o0, 2048);   copy(L_WO1, a.w_o1, 4096); }
         copy(L_BS0, a.b_s0, 32);  copy(L_BO0, a.b_o0, 64);   copy(L_BO1, a.b_o1, 64);
         copy(L_WLG, a.w_lg, 2 * NCLS * 32); copy(L_BLG, a.b_lg, NCLS);
     }
@@ -771,13 +802,76 @@ __global__ __launch_bounds__(768) void fcn_head_pc_kernel(const HeadArgs a) {
             if (a.diag & 2) { relu16(P0); relu16(P1); if (a.pred) a.pred[q] = (int)P0[0]; continue; }   // ablation: no out0/out1/logits
 #endif
             // ---- out0: handed tile (bias + upsampled levels 1..4) + W0_0 * S ----
-            chain_32to64_lds(w_o0, lane, S, P0, P1);
+            if constexpr (X3) {                         // out0's level-0 slice from bf16 pieces: K = 32 -> two chunks of 16
+                u32x4 sh[2], sm[2], sl[2];
+#pragma unroll
+                for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        unsigned th, tm, tl;
+                        split_pair(S[8 * kc + 2 * d], S[8 * kc + 2 * d + 1], th, tm, tl);
+                        sh[kc][d] = th; sm[kc][d] = tm; sl[kc][d] = tl;
+                    }
+                const float *wx0 = lds + L_WO0 + lane * 4;
+                auto A0 = [&](int t, int cb, int kc) { return __builtin_bit_cast(u32x4, lds4(wx0 + ((t * 2 + cb) * 2 + kc) * 256)); };
+#pragma unroll
+                for (int kc = 0; kc < 2; ++kc) {
+                    const u32x4 ah0 = A0(0, 0, kc), ah1 = A0(0, 1, kc), am0 = A0(1, 0, kc), am1 = A0(1, 1, kc), al0 = A0(2, 0, kc), al1 = A0(2, 1, kc);
+                    P0 = mfma_b16(al0, sh[kc], P0); P1 = mfma_b16(al1, sh[kc], P1);
+                    P0 = mfma_b16(ah0, sl[kc], P0); P1 = mfma_b16(ah1, sl[kc], P1);
+                    P0 = mfma_b16(am0, sm[kc], P0); P1 = mfma_b16(am1, sm[kc], P1);
+                    P0 = mfma_b16(am0, sh[kc], P0); P1 = mfma_b16(am1, sh[kc], P1);
+                    P0 = mfma_b16(ah0, sm[kc], P0); P1 = mfma_b16(ah1, sm[kc], P1);
+                    P0 = mfma_b16(ah0, sh[kc], P0); P1 = mfma_b16(ah1, sh[kc], P1);
+                }
+            } else {
+                chain_32to64_lds(w_o0, lane, S, P0, P1);
+            }
             relu16(P0);
             relu16(P1);
             // ---- out1 ----
             f32x16 Q0 = bias_tile_lds(lds + L_BO1, g), Q1 = bias_tile_lds(lds + L_BO1 + 32, g);
-            chain_32to64_lds(w_o1, lane, P0, Q0, Q1);
-            chain_32to64_lds(w_o1 + 2 * 4 * 64 * 4, lane, P1, Q0, Q1);
+            if constexpr (X3) {
+                // B operands: lane (pixel p, half g) supplies k slots e = 0..7 of chunk kc = registers 8 (kc & 1) + e of P0 (kc < 2) / P1.
+                // The split of chunk kc+1 (~60 vector instructions) is interleaved with the 12 MFMAs of chunk kc: a bf16 MFMA leaves
+                // about six vector-issue slots free inside the issuing wave (tools/mfma_bf16_coissue.hip).
+                u32x4 bh[4], bm[4], bl[4];
+                auto split = [&](auto kcc) {
+                    constexpr int kc = decltype(kcc)::value;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        constexpr int r0 = 8 * (kc & 1);
+                        const float x0 = kc < 2 ? P0[r0 + 2 * d] : P1[r0 + 2 * d], x1 = kc < 2 ? P0[r0 + 2 * d + 1] : P1[r0 + 2 * d + 1];
+                        unsigned th, tm, tl;
+                        split_pair(x0, x1, th, tm, tl);
+                        bh[kc][d] = th; bm[kc][d] = tm; bl[kc][d] = tl;
+                    }
+                };
+                const float *wx = lds + L_WO1 + lane * 4;
+                auto A = [&](int t, int cb, int kc) { return __builtin_bit_cast(u32x4, lds4(wx + ((t * 2 + cb) * 4 + kc) * 256)); };
+                split(std::integral_constant<int, 0>{});
+                unroll_n<4>([&](auto kcc) {
+                    constexpr int kc = decltype(kcc)::value;
+                    const u32x4 ah0 = A(0, 0, kc), ah1 = A(0, 1, kc), am0 = A(1, 0, kc), am1 = A(1, 1, kc), al0 = A(2, 0, kc), al1 = A(2, 1, kc);
+                    if constexpr (kc < 3) split(std::integral_constant<int, kc + 1>{});
+                    Q0 = mfma_b16(al0, bh[kc], Q0); Q1 = mfma_b16(al1, bh[kc], Q1);      // small terms first
+                    Q0 = mfma_b16(ah0, bl[kc], Q0); Q1 = mfma_b16(ah1, bl[kc], Q1);
+                    Q0 = mfma_b16(am0, bm[kc], Q0); Q1 = mfma_b16(am1, bm[kc], Q1);
+                    Q0 = mfma_b16(am0, bh[kc], Q0); Q1 = mfma_b16(am1, bh[kc], Q1);
+                    Q0 = mfma_b16(ah0, bm[kc], Q0); Q1 = mfma_b16(ah1, bm[kc], Q1);
+                    Q0 = mfma_b16(ah0, bh[kc], Q0); Q1 = mfma_b16(ah1, bh[kc], Q1);
+                    if constexpr (kc < 3) {
+#pragma unroll
+                        for (int i = 0; i < 12; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+                            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // five vector instructions of the next chunk's split
+                        }
+                    }
+                });
+            } else {
+                chain_32to64_lds(w_o1, lane, P0, Q0, Q1);
+                chain_32to64_lds(w_o1 + 2 * 4 * 64 * 4, lane, P1, Q0, Q1);
+            }
             relu16(Q0);
             relu16(Q1);
 #ifdef UKBB_DIAG
@@ -835,6 +929,28 @@ static hipError_t launch_head_pc(const HeadArgs &a, hipStream_t s) {
                                  return v; }();
     const int ntiles = a.N * (a.H / HT) * (a.W / HT);
     dim3 grid((unsigned)(ntiles < n_cu ? ntiles : n_cu)), block(768);
+    static const bool x3_env = [] { const char *e = getenv("UKBB_HEAD_X3"); return e && atoi(e) != 0; }();   // A/B knob
+    if ((a.x3 || x3_env) && a.w_o1x3 && a.w_o0x3) {     // UKBB_PREC_F32X3
+        const size_t ldsx = HEADPC_X3_LDS_FLOATS * sizeof(float);
+#define UKBB_HEADX3_CASE(NC)                                                                          \
+    case NC: {                                                                                       \
+        auto k = fcn_head_pc_kernel<NC, true>;                                                       \
+        static bool done = false;                                                                    \
+        if (!done) {                                                                                 \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),                    \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx); \
+            if (e != hipSuccess) return e;                                                           \
+            done = true;                                                                             \
+        }                                                                                            \
+        hipLaunchKernelGGL(k, grid, block, ldsx, s, a);                                              \
+        break;                                                                                       \
+    }
+        switch (a.n_class) {
+            UKBB_HEADX3_CASE(2) UKBB_HEADX3_CASE(3) UKBB_HEADX3_CASE(4) UKBB_HEADX3_CASE(5) UKBB_HEADX3_CASE(6)
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     const size_t lds = HEADPC_LDS_FLOATS * sizeof(float);
 #define UKBB_HEADPC_CASE(NC)                                                                          \
     case NC: {                                                                                       \
@@ -905,6 +1021,37 @@ void pack_rowmap_32x64(const float *w, int ld, float *dst) {
                     const int g = lane >> 5, m = lane & 31;
                     dst[(((cb * 4 + q4) * 64 + lane) * 4) + i] = w[rowmap(4 * q4 + i, g) * ld + cb * 32 + m];
                 }
+}
+
+static inline unsigned short host_bf16_rne(float f) {
+    unsigned u; memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+static inline float host_bf16_to_f32(unsigned short b) { const unsigned u = (unsigned)b << 16; float f; memcpy(&f, &u, 4); return f; }
+
+void pack_head_x3(const float *w, int k_in, float *dst) {
+    // W is [k_in rows (32 or 64)][64 out], row stride 64.  dst[t][cb][kc][lane][d] (dwords), kc < k_in / 16: t = piece (bf16 of w, of
+    // the remainder, of the rest), lane = (g << 5) | m, cout = 32 cb + m, k slot e = 2 d (+1 in the high half) <-> input row
+    // 32 (kc / 2) + rowmap(8 (kc & 1) + e, g): the registers of the 32-row accumulator tile(s) the MFMA wave holds
+    unsigned *o = reinterpret_cast<unsigned *>(dst);
+    const int nkc = k_in / 16;
+    for (int t = 0; t < 3; ++t)
+        for (int cb = 0; cb < 2; ++cb)
+            for (int kc = 0; kc < nkc; ++kc)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int d = 0; d < 4; ++d) {
+                        const int g = lane >> 5, m = lane & 31;
+                        unsigned short piece[2];
+                        for (int hh = 0; hh < 2; ++hh) {
+                            const int e = 2 * d + hh, ch = 32 * (kc / 2) + rowmap(8 * (kc & 1) + e, g);
+                            float x = w[ch * 64 + 32 * cb + m];
+                            unsigned short b = 0;
+                            for (int k = 0; k <= t; ++k) { b = host_bf16_rne(x); x -= host_bf16_to_f32(b); }
+                            piece[hh] = b;
+                        }
+                        o[((((t * 2 + cb) * nkc + kc) * 64 + lane) * 4) + d] = (unsigned)piece[0] | ((unsigned)piece[1] << 16);
+                    }
 }
 
 void pack_head_lg(const float *w, int n_class, float *dst) {

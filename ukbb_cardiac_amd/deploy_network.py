@@ -51,6 +51,8 @@ def define_flags():
                       'was written (1 ulp from numpy 2; host pre-processing only; INTEGRATION.md section 5).')
     fs.DEFINE_integer('io_threads', 8, 'Reader threads (gzip NIfTI -> pinned staging) and writer threads (float64 label volume, gzip) '
                       'around the GPU in sequence mode; 0 = strictly sequential subjects as in the reference.')
+    fs.DEFINE_enum('precision', 'fp32', ['fp32', 'f32x3'], 'Arithmetic of the matrix products: fp32 MFMA (default) or fp32 results from three '
+                   'bf16 pieces per operand (UKBB_PREC_F32X3, include/ukbb_fcn.h; same labels, faster head).')
     fs.DEFINE_integer('num_shards', env_cnt, 'Number of workers sharing data_dir.')
     fs.DEFINE_integer('shard_index', env_idx, 'This worker: subjects i with i % num_shards == shard_index.')
     return fs
@@ -275,6 +277,8 @@ def main(argv=None):
         os.environ['HIP_VISIBLE_DEVICES'] = os.environ['CUDA_VISIBLE_DEVICES']   # demo_pipeline.py:25,63
     from ukbb_cardiac_amd.engine import Session          # raises if the HIP library is missing
     with Session(FLAGS.model_path, device=FLAGS.device) as sess:
+        if FLAGS.precision != 'fp32':
+            sess.engine.set_precision(FLAGS.precision)
         print('Start deployment on the data set ...')
 
         def forward(batch):

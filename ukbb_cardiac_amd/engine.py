@@ -150,8 +150,9 @@ class Engine:
         _lib.check(rc, 'ukbb_fcn_forward_cine')
 
     def set_precision(self, precision: str):
-        """'fp32' (default) or 'bf16' (bf16 MFMA inputs, fp32 accumulate; BASELINE config 5)."""
-        code = {'fp32': 0, 'bf16': 1}[precision]
+        """'fp32' (default), 'bf16' (bf16 MFMA inputs, fp32 accumulate; BASELINE config 5) or 'f32x3' (fp32 results from three
+        bf16 pieces per operand on the dense matrix cores; FCN head so far; include/ukbb_fcn.h UKBB_PREC_F32X3)."""
+        code = {'fp32': 0, 'bf16': 1, 'f32x3': 2}[precision]
         _lib.check(_lib.lib.ukbb_fcn_set_precision(self._h, code), 'ukbb_fcn_set_precision')
 
     # -- measurement -----------------------------------------------------------
