@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define UKBB_FCN_ABI_VERSION 3
+#define UKBB_FCN_ABI_VERSION 4
 #define UKBB_FCN_MAX_LEVEL 8
 
 #define UKBB_OK 0
@@ -112,8 +112,10 @@ int ukbb_fcn_reserve(ukbb_fcn_handle *h, int n, int height, int width);
  * (a hipStream_t; NULL = the null stream).  image: [n,h,w,1] float32 with
  * h % 16 == 0 and w % 16 == 0 (the reference pads to that,
  * common/deploy_network.py:97).  Any of logits / prob ([n,h,w,n_class]
- * float32) and pred ([n,h,w] int32, = argmax over classes, lowest index on
- * ties) may be NULL to skip producing it. */
+ * float32) and pred ([n,h,w] int32 = argmax over the float32 probabilities,
+ * lowest index on ties, as common/train_network.py:199 defines it -- equal to
+ * the argmax of the logits except where two classes' probabilities round to
+ * the same float) may be NULL to skip producing it. */
 int ukbb_fcn_forward(ukbb_fcn_handle *h, const float *image, int n, int height, int width,
                      float *logits, float *prob, int32_t *pred, void *stream);
 
@@ -198,7 +200,7 @@ int ukbb_fcn_zscore_pack(const float *d_vol, int X, int Y, int Z, int T, int64_t
  * (common/deploy_network.py:92,116,136-138; deploy_network_ao.py:189-196) -- for a short-axis subject
  * 160 MB of float64 through zlib, 0.5 s of a core against 11 ms of network time.
  *
- * ukbb_fcn_gzip_labels writes ONE gzip member (RFC 1952 / 1951, fixed Huffman codes) whose inflated
+ * ukbb_fcn_gzip_labels writes ONE gzip member (RFC 1952 / 1951, one deflate block) whose inflated
  * content is  prefix || labels converted to the NIfTI voxel type `nifti_datatype`
  * (2 uint8, 4 int16, 8 int32, 16 float32, 64 float64; little-endian),  i.e. the .nii.gz nibabel writes
  * when prefix is the 352-byte NIfTI-1 header, without forming the converted volume: a run of equal
@@ -209,6 +211,13 @@ int ukbb_fcn_zscore_pack(const float *d_vol, int X, int Y, int Z, int T, int64_t
 uint64_t ukbb_fcn_gzip_labels_bound(uint64_t n_voxels, int nifti_datatype, uint64_t prefix_len);
 int64_t ukbb_fcn_gzip_labels(const uint8_t *labels, uint64_t n_voxels, int nifti_datatype, const uint8_t *prefix, uint64_t prefix_len,
                              uint8_t *out, uint64_t out_cap);
+/* Same, with the Huffman code set chosen: UKBB_GZIP_DYNAMIC (what ukbb_fcn_gzip_labels uses: a counting pass over the
+ * runs, then codes built from the exact token histogram -- files no larger than zlib level 1 writes for the same volume)
+ * or UKBB_GZIP_FIXED (the fixed codes of RFC 1951 3.2.6: no counting pass, files 2-4x larger).  Same inflated bytes. */
+#define UKBB_GZIP_FIXED 0
+#define UKBB_GZIP_DYNAMIC 1
+int64_t ukbb_fcn_gzip_labels_mode(const uint8_t *labels, uint64_t n_voxels, int nifti_datatype, const uint8_t *prefix, uint64_t prefix_len,
+                                  uint8_t *out, uint64_t out_cap, int mode);
 
 /* ---- measurement / introspection (bench.py, tests) ---------------------- */
 

@@ -2,6 +2,11 @@
 numpy oracle).  Written against torch.nn.functional
 primitives (NCHW, asymmetric F.pad + F.conv2d, F.conv_transpose2d + crop), i.e.
 a different code path from oracle/fcn_oracle.py's pad+tensordot / scatter.
+What it does NOT cross-check: the SAME-padding rule itself -- ``_same_pad`` below is the same closed form as
+``fcn_oracle.same_pads`` ([TF-recall]).  The checks that are independent of that formula live in
+tests/test_oracle_vs_torch.py: torch's own ``padding='same'`` for the stride-1 layers, and torch.autograd's gradient of
+the forward conv for the transposed convs (so App. B.4 follows from B.1); the stride-2 forward rule ("extra pixel after")
+has no second source in this image.
 
 TEST INFRASTRUCTURE ONLY (see oracle/__init__.py): imported by tests/ and by
 bench.py's ``cpu_baseline`` leg, where ``TorchFCN`` -- this graph with its

@@ -126,3 +126,43 @@ def test_softmax_argmax_ties_lowest_index():
     prob, pred = O.prob_pred(logits)
     assert pred.dtype == np.int32 and pred[0] == 1
     assert np.isclose(prob.sum(), 1.0)
+
+
+# ---- checks that do NOT share the oracle's SAME-pad formula ---------------------------------------
+# oracle/torch_oracle.py computes its pads with the same closed form as oracle/fcn_oracle.py (`_same_pad` == `same_pads`),
+# so the comparisons above cross-check op mechanics, not the padding rule.  Two things torch can say on its own:
+
+@pytest.mark.parametrize('k,cin,cout,hw', [(3, 5, 7, (12, 13)), (1, 6, 4, (9, 16)), (3, 1, 16, (16, 32))])
+def test_stride1_same_against_torch_own_same_rule(k, cin, cout, hw):
+    """F.conv2d(padding='same') is torch's OWN 'same' rule (stride 1 only): the stride-1 3x3 and 1x1 layers of
+    network.py:19-25 (17 of the 21 conv layers of build_FCN) agree with it."""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(k * 100 + cin)
+    x = rng.standard_normal((2,) + hw + (cin,))
+    w = rng.standard_normal((k, k, cin, cout))
+    want = F.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2), torch.from_numpy(w).permute(3, 2, 0, 1), padding='same')
+    got = O.conv2d_same(x, w, 1)
+    assert np.abs(got - want.permute(0, 2, 3, 1).numpy()).max() < 1e-12
+
+
+@pytest.mark.parametrize('k,s,hw', [(3, 2, (6, 5)), (3, 2, (8, 13)), (7, 4, (3, 4)), (31, 16, (2, 3))])
+def test_transposed_conv_is_the_autograd_gradient_of_the_forward_same_conv(k, s, hw):
+    """App. B.4 says conv2d_transpose(SAME) IS the gradient of the forward SAME conv with respect to its input.  Here the
+    gradient is taken by torch.autograd of the forward conv (not by a transposed-conv primitive and not by the oracle's
+    scatter-and-crop), so the crop offsets of O.conv2d_transpose_same follow from the forward padding rule alone:
+    given App. B.1 for the forward conv, B.4 needs no separate recollection."""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(k + s)
+    cin, cout = 3, 2                                             # transposed conv: cin -> cout, filter [k,k,cout,cin]
+    x = rng.standard_normal((2,) + hw + (cin,))
+    w = rng.standard_normal((k, k, cout, cin))
+    H, W = hw[0] * s, hw[1] * s
+    big = torch.zeros((2, cout, H, W), dtype=torch.float64, requires_grad=True)
+    _, pt, pb = O.same_pads(H, k, s)
+    _, pl, pr = O.same_pads(W, k, s)
+    # forward conv cout -> cin with HWIO filter w[k,k,cout,cin]
+    y = F.conv2d(F.pad(big, (pl, pr, pt, pb)), torch.from_numpy(w).permute(3, 2, 0, 1), stride=s)
+    assert y.shape[2:] == hw
+    y.backward(torch.from_numpy(x).permute(0, 3, 1, 2))
+    got = O.conv2d_transpose_same(x, w, s)
+    assert np.abs(got - big.grad.permute(0, 2, 3, 1).numpy()).max() < 1e-12

@@ -6,6 +6,36 @@
 
 namespace ukbb {
 
+// prob / pred of train_network.py:198-199 (network_ao.py:159-160): prob = softmax(logits), pred = argmax(prob) -- the argmax
+// is taken over the float32 PROBABILITIES, lowest index on ties.  It equals argmax(logits) unless another class's logit lies
+// within a few ulps of 1.0 (in exp's argument) of the maximum: exp(l - m) then rounds to 1, or the products with 1/sum
+// round to the same float, and the lower index wins although its logit is smaller.  Only in that case (rare: |logits| of the
+// top two below ~1 and almost equal) the probabilities are formed to decide; the common path costs a subtract and a compare
+// per class.  ``p`` (optional) receives the probabilities, formed the same way, so argmax(p) == return value always.
+template <int NCLS>
+__device__ __forceinline__ int softmax_argmax(const float (&lg)[NCLS], float *p) {
+    int best = 0; float m = lg[0];
+#pragma unroll
+    for (int c = 1; c < NCLS; ++c) if (lg[c] > m) { m = lg[c]; best = c; }
+    bool near = false;
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c) near |= (c != best) & (m - lg[c] < 4e-7f);
+    if (p || near) {
+        float e[NCLS]; float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCLS; ++c) { e[c] = expf(lg[c] - m); sum += e[c]; }
+        const float inv = 1.0f / sum;
+        float pm = -1.f;
+#pragma unroll
+        for (int c = 0; c < NCLS; ++c) {
+            const float pc = e[c] * inv;
+            if (p) p[c] = pc;
+            if (pc > pm) { pm = pc; best = c; }
+        }
+    }
+    return best;
+}
+
 // ---------------------------------------------------------------------------
 // Generic implicit-GEMM convolution (3x3 or 1x1, stride 1 or 2) + bias + ReLU
 // on the f32 MFMA pipes.  NHWC activations, weights pre-packed in MFMA

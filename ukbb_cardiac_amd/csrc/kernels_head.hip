@@ -473,17 +473,12 @@ __global__ __launch_bounds__(256, OCC) void fcn_head_kernel(const HeadArgs a) {
 #pragma unroll
                 for (int c = 0; c < NCLS; ++c) a.logits[q * NCLS + c] = lg[c];
             }
-            int best = 0; float m = lg[0];
-#pragma unroll
-            for (int c = 1; c < NCLS; ++c) if (lg[c] > m) { m = lg[c]; best = c; }
+            float pr[NCLS];
+            const int best = softmax_argmax<NCLS>(lg, a.prob ? pr : nullptr);
             if (a.pred) a.pred[q] = best;
             if (a.prob) {
-                float e[NCLS]; float sum = 0.f;
 #pragma unroll
-                for (int c = 0; c < NCLS; ++c) { e[c] = expf(lg[c] - m); sum += e[c]; }
-                const float inv = 1.0f / sum;
-#pragma unroll
-                for (int c = 0; c < NCLS; ++c) a.prob[q * NCLS + c] = e[c] * inv;
+                for (int c = 0; c < NCLS; ++c) a.prob[q * NCLS + c] = pr[c];
             }
         }
     }
@@ -906,17 +901,12 @@ __global__ __launch_bounds__(768) void fcn_head_pc_kernel(const HeadArgs a) {
 #pragma unroll
                     for (int c = 0; c < NCLS; ++c) a.logits[q * NCLS + c] = lg[c];
                 }
-                int best = 0; float m = lg[0];
-#pragma unroll
-                for (int c = 1; c < NCLS; ++c) if (lg[c] > m) { m = lg[c]; best = c; }
+                float pr[NCLS];
+                const int best = softmax_argmax<NCLS>(lg, a.prob ? pr : nullptr);
                 if (a.pred) a.pred[q] = best;
                 if (a.prob) {
-                    float e[NCLS]; float sum = 0.f;
 #pragma unroll
-                    for (int c = 0; c < NCLS; ++c) { e[c] = expf(lg[c] - m); sum += e[c]; }
-                    const float inv = 1.0f / sum;
-#pragma unroll
-                    for (int c = 0; c < NCLS; ++c) a.prob[q * NCLS + c] = e[c] * inv;
+                    for (int c = 0; c < NCLS; ++c) a.prob[q * NCLS + c] = pr[c];
                 }
             }
         }
@@ -1093,17 +1083,12 @@ __global__ __launch_bounds__(256) void logits_kernel(const LogitsArgs a) {
 #pragma unroll
             for (int c = 0; c < NCLS; ++c) a.logits[q * NCLS + c] = lg[c];
         }
-        int best = 0; float m = lg[0];
-#pragma unroll
-        for (int c = 1; c < NCLS; ++c) if (lg[c] > m) { m = lg[c]; best = c; }
+        float pr[NCLS];
+        const int best = softmax_argmax<NCLS>(lg, a.prob ? pr : nullptr);
         if (a.pred) a.pred[q] = best;
         if (a.prob) {
-            float e[NCLS]; float sum = 0.f;
 #pragma unroll
-            for (int c = 0; c < NCLS; ++c) { e[c] = expf(lg[c] - m); sum += e[c]; }
-            const float inv = 1.0f / sum;
-#pragma unroll
-            for (int c = 0; c < NCLS; ++c) a.prob[q * NCLS + c] = e[c] * inv;
+            for (int c = 0; c < NCLS; ++c) a.prob[q * NCLS + c] = pr[c];
         }
     }
 }

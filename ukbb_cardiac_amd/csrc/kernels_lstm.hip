@@ -78,15 +78,10 @@ __global__ __launch_bounds__(256) void lstm_cell_kernel(const LstmCellArgs a) {
 #pragma unroll
                     for (int k = 0; k < NCLS; ++k) lo[k] = lg[k];
                 }
-                int best = 0; float mx = lg[0];
+                float pr[NCLS];
+                const int best = softmax_argmax<NCLS>(lg, pr);
 #pragma unroll
-                for (int k = 1; k < NCLS; ++k) if (lg[k] > mx) { mx = lg[k]; best = k; }
-                float e[NCLS], sum = 0.f;
-#pragma unroll
-                for (int k = 0; k < NCLS; ++k) { e[k] = expf(lg[k] - mx); sum += e[k]; }
-                const float inv = 1.0f / sum;
-#pragma unroll
-                for (int k = 0; k < NCLS; ++k) acc[k] = e[k] * inv;
+                for (int k = 0; k < NCLS; ++k) acc[k] = pr[k];
                 if (a.pred) a.pred[m * (a.m_stride / NCLS) + pix] = best;
             }
         }

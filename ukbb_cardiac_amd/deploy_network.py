@@ -26,7 +26,7 @@ import numpy as np
 if __package__ in (None, ''):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-from ukbb_cardiac_amd import nifti, pipeline                       # noqa: E402
+from ukbb_cardiac_amd import measures, nifti, pipeline             # noqa: E402
 from ukbb_cardiac_amd.flags import FlagError, FlagSet              # noqa: E402
 from ukbb_cardiac_amd.shard import default_device, shard_from_env, subjects_for_shard   # noqa: E402
 
@@ -53,6 +53,11 @@ def define_flags():
                       'around the GPU in sequence mode; 0 = strictly sequential subjects as in the reference.')
     fs.DEFINE_enum('precision', 'fp32', ['fp32', 'f32x3'], 'Arithmetic of the matrix products: fp32 MFMA (default) or fp32 results from three '
                    'bf16 pieces per operand (UKBB_PREC_F32X3, include/ukbb_fcn.h; same labels, faster head).')
+    fs.DEFINE_enum('label_gzip', 'small', list(nifti.LABEL_GZIP_MODES), 'Deflate of the label volumes: small = run-length tokens + dynamic Huffman '
+                   '(size of zlib level 1 or below, ~20x less CPU), fast = fixed Huffman (2-4x larger files), zlib = as nibabel. Same inflated bytes.')
+    fs.DEFINE_string('output_csv', '', '--seq_name sa, sequence mode: also write the spreadsheet of short_axis/eval_ventricular_volume.py '
+                     '(same columns, same arithmetic) from the per-frame class counts the GPU leaves behind -- no second pass over '
+                     'seg_sa.nii.gz.  Subjects already segmented by an earlier run are measured from their files.')
     fs.DEFINE_integer('num_shards', env_cnt, 'Number of workers sharing data_dir.')
     fs.DEFINE_integer('shard_index', env_idx, 'This worker: subjects i with i % num_shards == shard_index.')
     return fs
@@ -65,13 +70,16 @@ def seg_prefix(FLAGS):
 def save_sequence_outputs(data_dir, pre, seq, affine, pixdim, pred, frames):
     """The five files of deploy_network.py:136-151.  pred: (X,Y,Z,T) labels, stored as float64 (:92); frames: {'ED'|'ES':
     (image frame, label frame)}."""
-    nifti.save(pred, '{0}/{1}_{2}.nii.gz'.format(data_dir, pre, seq), affine, pixdim, as_dtype=np.float64)
     for fr, (img_fr, seg_fr) in frames.items():
         nifti.save(img_fr, '{0}/{1}_{2}.nii.gz'.format(data_dir, seq, fr), affine)
         nifti.save(seg_fr, '{0}/{1}_{2}_{3}.nii.gz'.format(data_dir, pre, seq, fr), affine)
+    # seg_{seq}.nii.gz doubles as the 'already segmented, skip' marker (:66-67), so it is written LAST and -- like every
+    # file nifti.save writes -- appears under its name only when complete (tmp file + os.replace): a worker killed
+    # anywhere in here leaves a subject that the rerun segments again, never a half-written one that it skips.
+    nifti.save(pred, '{0}/{1}_{2}.nii.gz'.format(data_dir, pre, seq), affine, pixdim, as_dtype=np.float64)
 
 
-def run_pipelined(FLAGS, engine, data_list, log=print):
+def run_pipelined(FLAGS, engine, data_list, log=print, csv_rows=None):
     """Sequence mode with subjects overlapped: reader threads decompress the next files into pinned staging buffers,
     the GPU thread (this one) keeps up to two subjects in flight on three streams (subject_pipeline.SubjectPipeline),
     writer threads expand the uint8 labels to the reference's float64 volume, gzip and save.  Same files, byte for byte,
@@ -113,7 +121,20 @@ def run_pipelined(FLAGS, engine, data_list, log=print):
 
     def read(item):
         t0 = time.time()
-        nim = nifti.load(item[2], alloc=alloc)
+        handed = []
+
+        def alloc_tracked(shape, dt):
+            a = alloc(shape, dt)
+            handed.append(a)
+            return a
+        try:
+            nim = nifti.load(item[2], alloc=alloc_tracked)
+        except BaseException:
+            pipe = state['pipe']                            # a truncated / corrupt file: the pinned buffer goes back to the pool
+            for a in handed:
+                if pipe is not None:
+                    pipe.release(a)
+            raise
         return nim, time.time() - t0
 
     processed, table_time, writes = [], [], []
@@ -133,6 +154,8 @@ def run_pipelined(FLAGS, engine, data_list, log=print):
         log('  ED frame = {:d}, ES frame = {:d}'.format(k_ed, k_es))
         table_time.append(seg_time)
         processed.append(data)
+        if csv_rows is not None:
+            csv_rows[data] = measures.sa_row(res.counts, nim.header['pixdim'])
         if FLAGS.save_seg:
             log('  Saving segmentation ...')
             # the saved frames are the CLIPPED intensities (alias quirk)
@@ -155,7 +178,7 @@ def run_pipelined(FLAGS, engine, data_list, log=print):
                 while inflight:                             # odd subject: drain, then take the sequential path
                     finish(*inflight.pop(0))
                 log(item[0])
-                _sequence_subject(FLAGS, item, nim, None, engine, log, processed, table_time)
+                _sequence_subject(FLAGS, item, nim, None, engine, log, processed, table_time, csv_rows)
                 continue
             if len(inflight) >= depth - 1:
                 finish(*inflight.pop(0))
@@ -171,7 +194,7 @@ def run_pipelined(FLAGS, engine, data_list, log=print):
     return processed, table_time, start_time
 
 
-def _sequence_subject(FLAGS, item, nim, forward, engine, log, processed, table_time):
+def _sequence_subject(FLAGS, item, nim, forward, engine, log, processed, table_time, csv_rows=None):
     """One subject of sequence mode, start to finish on this thread (deploy_network.py:80-151)."""
     data, data_dir, image_name = item
     seq, pre = FLAGS.seq_name, seg_prefix(FLAGS)
@@ -199,6 +222,10 @@ def _sequence_subject(FLAGS, item, nim, forward, engine, log, processed, table_t
     else:
         k_ed, k_es = pipeline.pick_ed_es(pred, seq, FLAGS.seg4)
     log('  ED frame = {:d}, ES frame = {:d}'.format(k_ed, k_es))
+    if csv_rows is not None:
+        n_class = 4 if engine is None else engine.arch.n_class
+        counts = aux['counts'] if on_device else measures.counts_from_labels(pred, n_class)
+        csv_rows[data] = measures.sa_row(counts, nim.header['pixdim'])
     if FLAGS.save_seg:
         log('  Saving segmentation ...')
         frames = {}
@@ -209,6 +236,24 @@ def _sequence_subject(FLAGS, item, nim, forward, engine, log, processed, table_t
         save_sequence_outputs(data_dir, pre, seq, nim.affine, nim.header['pixdim'], pred, frames)
 
 
+def write_measures_csv(FLAGS, subjects, csv_rows, log=print):
+    """The spreadsheet of short_axis/eval_ventricular_volume.py:28-79 for this worker's subjects: rows measured during this run
+    come from the device counts; a subject segmented by an earlier run (skipped above) is measured from its files the way the
+    evaluation script does.  Same inclusion rule (:35: image and segmentation both exist), same order (sorted directory names)."""
+    rows = []
+    for data in subjects:
+        data_dir = os.path.join(FLAGS.data_dir, data)
+        image_name, seg_name = '{0}/sa.nii.gz'.format(data_dir), '{0}/seg_sa.nii.gz'.format(data_dir)
+        if data in csv_rows:
+            rows.append((data, csv_rows[data]))
+        elif os.path.exists(image_name) and os.path.exists(seg_name):
+            seg = nifti.load(seg_name).get_data()
+            rows.append((data, measures.sa_row(measures.counts_from_labels(seg, 4), nifti.load_header(image_name)['pixdim'])))
+    path = measures.shard_csv_name(FLAGS.output_csv, FLAGS.shard_index, FLAGS.num_shards)
+    measures.write_csv(path, measures.SA_COLUMNS, rows)
+    log('Clinical measures of {0} subjects written to {1}'.format(len(rows), path))
+
+
 def run(FLAGS, forward, log=print, engine=None):
     """The subject loop of deploy_network.py:52-225 with ``forward`` standing for sess.run.
     With ``engine`` (and --device_preproc) float32 sequences take the device pipeline."""
@@ -216,9 +261,15 @@ def run(FLAGS, forward, log=print, engine=None):
     data_list = subjects_for_shard(sorted(os.listdir(FLAGS.data_dir)), FLAGS.shard_index, FLAGS.num_shards)
     processed, table_time = [], []
     seq, pre = FLAGS.seq_name, seg_prefix(FLAGS)
+    csv_rows = None
+    if getattr(FLAGS, 'output_csv', ''):
+        if seq != 'sa' or not FLAGS.process_seq:
+            raise ValueError('--output_csv writes the table of short_axis/eval_ventricular_volume.py: it needs --seq_name sa in sequence mode')
+        csv_rows = {}
+    shard_subjects = list(data_list)
     if (FLAGS.process_seq and engine is not None and getattr(FLAGS, 'device_preproc', False) and getattr(FLAGS, 'io_threads', 0) > 0
             and not getattr(FLAGS, 'numpy1_casting', False)):
-        processed, table_time, _ = run_pipelined(FLAGS, engine, data_list, log)
+        processed, table_time, _ = run_pipelined(FLAGS, engine, data_list, log, csv_rows)
         data_list = []
     for data in data_list:
         log(data)
@@ -235,7 +286,7 @@ def run(FLAGS, forward, log=print, engine=None):
                 continue
             log('  Reading {} ...'.format(image_name))
             nim = nifti.load(image_name)
-            _sequence_subject(FLAGS, (data, data_dir, image_name), nim, forward, engine, log, processed, table_time)
+            _sequence_subject(FLAGS, (data, data_dir, image_name), nim, forward, engine, log, processed, table_time, csv_rows)
         else:
             names = {fr: '{0}/{1}_{2}.nii.gz'.format(data_dir, seq, fr) for fr in ('ED', 'ES')}
             if not all(os.path.exists(p) for p in names.values()):
@@ -257,6 +308,8 @@ def run(FLAGS, forward, log=print, engine=None):
                     log('  Saving segmentation ...')
                     nifti.save(pred, '{0}/{1}_{2}_{3}.nii.gz'.format(data_dir, pre, seq, fr), nim.affine,
                                nim.header['pixdim'])
+    if csv_rows is not None:
+        write_measures_csv(FLAGS, shard_subjects, csv_rows, log)
     if table_time:
         log('Average segmentation time = {:.3f}s per {}'.format(float(np.mean(table_time)),
                                                                'sequence' if FLAGS.process_seq else 'frame'))
@@ -279,6 +332,7 @@ def main(argv=None):
     with Session(FLAGS.model_path, device=FLAGS.device) as sess:
         if FLAGS.precision != 'fp32':
             sess.engine.set_precision(FLAGS.precision)
+        nifti.set_label_gzip(FLAGS.label_gzip)
         print('Start deployment on the data set ...')
 
         def forward(batch):

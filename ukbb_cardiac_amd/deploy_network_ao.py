@@ -20,7 +20,7 @@ import numpy as np
 if __package__ in (None, ''):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-from ukbb_cardiac_amd import nifti, pipeline                       # noqa: E402
+from ukbb_cardiac_amd import measures, nifti, pipeline             # noqa: E402
 from ukbb_cardiac_amd.flags import FlagError, FlagSet              # noqa: E402
 from ukbb_cardiac_amd.shard import default_device, shard_from_env, subjects_for_shard   # noqa: E402
 
@@ -47,9 +47,26 @@ def define_flags():
                       'write finished segmentations behind it; 0 = strictly sequential subjects as in the reference.')
     fs.DEFINE_boolean('device_preproc', True, 'Sequences: z-score, padding, transposes and the argmax on the GPU '
                       '(bit-identical to the host path; --nodevice_preproc restores it).')
+    fs.DEFINE_enum('label_gzip', 'small', list(nifti.LABEL_GZIP_MODES), 'Deflate of the label volumes: small = run-length tokens + dynamic Huffman '
+                   '(size of zlib level 1 or below), fast = fixed Huffman (larger files), zlib = as nibabel.  Same inflated bytes.')
+    fs.DEFINE_string('output_csv', '', 'Sequence mode: also write the spreadsheet of aortic/eval_aortic_area.py (same columns and arithmetic) from '
+                     'the per-frame class counts the GPU leaves behind.  The evaluation script\'s quality control '
+                     '(cardiac_utils.aorta_pass_quality_control) is NOT applied: every segmented subject gets a row.')
+    fs.DEFINE_string('pressure_csv', '', 'With --output_csv: the blood-pressure spreadsheet of eval_aortic_area.py:41-46 for the distensibility columns '
+                     '(left empty without it).')
     fs.DEFINE_integer('num_shards', env_cnt, 'Number of workers sharing data_dir.')
     fs.DEFINE_integer('shard_index', env_idx, 'This worker: subjects i with i % num_shards == shard_index.')
     return fs
+
+
+def _pp(central_pp, data):
+    """central_pp.loc[int(data)] of eval_aortic_area.py:80; None (no distensibility) when no spreadsheet was given."""
+    if not central_pp:
+        return None
+    try:
+        return central_pp.get(str(int(data)), float('nan'))
+    except ValueError:
+        return central_pp.get(str(data), float('nan'))
 
 
 def run(FLAGS, forward, log=print, cine_forward=None, engine=None):
@@ -67,6 +84,12 @@ def run(FLAGS, forward, log=print, cine_forward=None, engine=None):
     data_list = subjects_for_shard(sorted(os.listdir(FLAGS.data_dir)), FLAGS.shard_index, FLAGS.num_shards)
     processed = []
     seq = FLAGS.seq_name
+    csv_rows = None
+    if getattr(FLAGS, 'output_csv', ''):
+        if not FLAGS.process_seq:
+            raise ValueError('--output_csv writes the table of aortic/eval_aortic_area.py: it needs sequence mode')
+        csv_rows = {}
+        central_pp = measures.read_central_pp(FLAGS.pressure_csv) if getattr(FLAGS, 'pressure_csv', '') else {}
     # Sequence mode with --io_threads > 0: the next cines are read (inflated) by reader threads while the GPU works on this one,
     # and the segmentation files are written behind it; order of subjects, log lines and files are those of the sequential loop.
     nthr = int(getattr(FLAGS, 'io_threads', 0)) if FLAGS.process_seq else 0
@@ -113,12 +136,19 @@ def run(FLAGS, forward, log=print, cine_forward=None, engine=None):
             t0 = time.time()
             on_device = (engine is not None and getattr(FLAGS, 'device_preproc', False)
                          and FLAGS.z_score and image.ndim == 4 and image.dtype == np.float32)
+            if on_device:                                         # the device z-score mirrors numpy internals: verify once
+                from ukbb_cardiac_amd.device_pipeline import device_zscore_matches_numpy
+                on_device = device_zscore_matches_numpy(engine, warn=log)
+            counts = None
             if on_device and FLAGS.model == 'UNet-LSTM':
                 from ukbb_cardiac_amd.device_pipeline import aortic_lstm_sequence_device
-                pred = aortic_lstm_sequence_device(image, engine, True, FLAGS.weight_R, FLAGS.weight_r, FLAGS.time_step)
+                pred, aux = aortic_lstm_sequence_device(image, engine, True, FLAGS.weight_R, FLAGS.weight_r, FLAGS.time_step,
+                                                        return_aux='counts')
+                counts = aux['counts']
             elif on_device:
                 from ukbb_cardiac_amd.device_pipeline import aortic_unet_sequence_device
-                pred = aortic_unet_sequence_device(image, engine, FLAGS.batch_slices)
+                pred, aux = aortic_unet_sequence_device(image, engine, FLAGS.batch_slices, return_aux=True)
+                counts = aux['counts']
             else:
                 if FLAGS.model == 'UNet-LSTM':
                     prob = pipeline.aortic_lstm_prob_sequence(image, cine_forward, FLAGS.z_score, FLAGS.weight_R, FLAGS.weight_r,
@@ -131,6 +161,10 @@ def run(FLAGS, forward, log=print, cine_forward=None, engine=None):
                 save(pred, '{0}/seg_{1}.nii.gz'.format(data_dir, seq), nim.affine, nim.header['pixdim'])
             log('  Segmentation time = {:3f}s'.format(time.time() - t0))
             processed.append(data)
+            if csv_rows is not None:
+                if counts is None:
+                    counts = measures.counts_from_labels(pred, 3)
+                csv_rows[data] = measures.ao_row(counts, nim.header['pixdim'], _pp(central_pp, data))
         else:
             if FLAGS.model == 'UNet-LSTM':                             # reference: deploy_network_ao.py:202-205
                 log('UNet-LSTM does not support frame-wise segmentation. Please use the -process_seq flag.')
@@ -158,6 +192,20 @@ def run(FLAGS, forward, log=print, cine_forward=None, engine=None):
         finally:
             readers.shutdown(wait=True)
             writers.shutdown(wait=True)
+    if csv_rows is not None:
+        rows = []
+        for data in data_list:                                  # eval_aortic_area.py:50-58: image and segmentation both exist
+            data_dir = os.path.join(FLAGS.data_dir, data)
+            image_name, seg_name = os.path.join(data_dir, 'ao.nii.gz'), os.path.join(data_dir, 'seg_ao.nii.gz')
+            if data in csv_rows:
+                rows.append((data, csv_rows[data]))
+            elif os.path.exists(image_name) and os.path.exists(seg_name):
+                seg = nifti.load(seg_name).get_data()
+                rows.append((data, measures.ao_row(measures.counts_from_labels(seg, 3), nifti.load_header(image_name)['pixdim'],
+                                                   _pp(central_pp, data))))
+        path = measures.shard_csv_name(FLAGS.output_csv, FLAGS.shard_index, FLAGS.num_shards)
+        measures.write_csv(path, measures.AO_COLUMNS, rows)
+        log('Aortic areas of {0} subjects written to {1}'.format(len(rows), path))
     process_time = time.time() - start_time
     if processed:
         log('Including image I/O and device resource allocation, it took {:.3f}s for processing {:d} subjects '
@@ -177,6 +225,7 @@ def main(argv=None):
         sys.exit("Error: --model Temporal-UNet is not available on the HIP engine (see DESIGN.md section 7).")
     from ukbb_cardiac_amd.arch import KIND_UNET_LSTM
     from ukbb_cardiac_amd.engine import Session
+    nifti.set_label_gzip(FLAGS.label_gzip)
     with Session(FLAGS.model_path, device=FLAGS.device) as sess:
         is_lstm = sess.engine.arch.kind == KIND_UNET_LSTM
         if is_lstm != (FLAGS.model == 'UNet-LSTM'):

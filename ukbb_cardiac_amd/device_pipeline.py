@@ -161,6 +161,39 @@ def device_zscore_stats(vol_t, thres_roi=10.0, stream=0):
     return mu, sigma + 1e-6, int(n), val_l                   # float32 + Python float stays float32 (image_utils.py:66-67)
 
 
+_ZSCORE_OK = {}
+
+
+def device_zscore_matches_numpy(engine, warn=None):
+    """Once per process and device: does the device z-score reproduce THIS numpy?  ``device_zscore_stats`` mirrors numpy
+    internals -- the 8192-element buffering and the 128-element / 8-accumulator pairwise leaves of ``np.add.reduce``, the float32
+    handling of a scalar percentile -- that ``np.setbufsize`` or another numpy release can change without notice.  A
+    26 k-voxel probe (more than three reduction buffers, ROI not a multiple of anything) is pushed through both; on any
+    difference in (val_l, mu, sigma + eps) the callers keep the host path (deploy_network_ao.py) and say so."""
+    key = engine.device
+    if key not in _ZSCORE_OK:
+        import torch
+        ok, why = True, ''
+        if np.getbufsize() != 8192:
+            ok, why = False, 'np.getbufsize() = %d, the device reproduces the 8192-element default' % np.getbufsize()
+        else:
+            rng = np.random.default_rng(20261003)
+            probe = (1000.0 * rng.gamma(2.0, 1.0, size=(37, 29, 1, 25))).astype(np.float32)
+            val_l = np.percentile(probe, 10.0)
+            roi = probe[probe >= val_l]
+            want = (val_l, np.mean(roi), np.std(roi) + 1e-6)
+            dev = torch.device('cuda', engine.device)
+            vol = torch.from_numpy(np.asfortranarray(probe)).to(dev)
+            mu, den, _, got_l = device_zscore_stats(vol, 10.0, torch.cuda.current_stream(dev).cuda_stream)
+            got = (got_l, mu, den)
+            if not all(np.float32(a) == np.float32(b) for a, b in zip(want, got)):
+                ok, why = False, 'probe statistics differ: numpy %r, device %r (numpy %s)' % (want, got, np.__version__)
+        _ZSCORE_OK[key] = (ok, why)
+        if not ok and warn is not None:
+            warn('  device z-score disabled, host pre-processing used instead: ' + why)
+    return _ZSCORE_OK[key][0]
+
+
 def aortic_lstm_sequence_device(image, engine, z_score=True, weight_R=5, weight_r=0.1, time_step=1, return_aux=False):
     """pipeline.aortic_lstm_prob_sequence + the argmax of deploy_network_ao.py:189 with the array work on the GPU:
     (X,Y,Z,T) float32 aortic cine -> int32 label volume (X,Y,Z,T).  Only the raw volume goes in and uint8 labels come
@@ -202,15 +235,17 @@ def aortic_lstm_sequence_device(image, engine, z_score=True, weight_R=5, weight_
     if not return_aux:
         return out
     aux = {'mu': mu, 'den': den, 'n_roi': n_roi, 'val_l': val_l, 'counts': counts.cpu().numpy()}
-    p = prob[:, :, x_pre:x_pre + X, y_pre:y_pre + Y].permute(2, 3, 1, 0, 4)
-    aux['prob'] = p.cpu().numpy()
+    if return_aux != 'counts':                                 # 'counts': skip the 78 MB of probabilities
+        p = prob[:, :, x_pre:x_pre + X, y_pre:y_pre + Y].permute(2, 3, 1, 0, 4)
+        aux['prob'] = p.cpu().numpy()
     return out, aux
 
 
 def aortic_unet_sequence_device(image, engine, batch_slices=128, return_aux=False):
     """pipeline.aortic_prob_sequence + the argmax of deploy_network_ao.py:189 for the frame-wise 'UNet' model with the array work
-    on the GPU: device z-score, pack, batched forward (the engine's label map is the argmax of the probabilities it would
-    return), labels back as uint8.  (X,Y,Z,T) float32 -> int32 labels (X,Y,Z,T)."""
+    on the GPU: device z-score, pack, batched forward (the engine's label map IS the lowest-index argmax of the float32
+    probabilities it would return: ``softmax_argmax``, csrc/kernels.h), labels back as uint8.
+    (X,Y,Z,T) float32 -> int32 labels (X,Y,Z,T)."""
     import torch
     if image.ndim != 4 or image.dtype != np.float32:
         raise TypeError('expected a 4-D float32 (X,Y,Z,T) cine; use pipeline.aortic_prob_sequence otherwise')

@@ -48,3 +48,113 @@ def aortic_areas(counts, pixdim, central_pp=None):
         if central_pp is not None:
             val[l_name]['distensibility'] = (A.max() - A.min()) / (A.min() * central_pp) * 1e3
     return val
+
+
+# ---- the spreadsheets of the evaluation scripts, written by the deploy scripts (--output_csv) ------------------------
+SA_COLUMNS = ['LVEDV (mL)', 'LVESV (mL)', 'LVSV (mL)', 'LVEF (%)', 'LVCO (L/min)', 'LVM (g)',
+              'RVEDV (mL)', 'RVESV (mL)', 'RVSV (mL)', 'RVEF (%)']                       # eval_ventricular_volume.py:76-78
+AO_COLUMNS = ['AAo max area (mm2)', 'AAo min area (mm2)', 'AAo distensibility (10-3 mmHg-1)',
+              'DAo max area (mm2)', 'DAo min area (mm2)', 'DAo distensibility (10-3 mmHg-1)']   # eval_aortic_area.py:93-95
+
+
+def sa_row(counts, pixdim):
+    """The table line of eval_ventricular_volume.py:72-73 from counts [T, >= 4]."""
+    v = ventricular_volumes(counts, pixdim)
+    return [v['LVEDV'], v['LVESV'], v['LVSV'], v['LVEF'], v['LVCO'], v['LVEDM'], v['RVEDV'], v['RVESV'], v['RVSV'], v['RVEF']]
+
+
+def ao_row(counts, pixdim, central_pp=None):
+    """The table line of eval_aortic_area.py:83-84 from counts [T, 3]; distensibility is NaN without a pulse pressure."""
+    v = aortic_areas(counts, pixdim, central_pp)
+    nan = float('nan')
+    return [v['AAo']['max area'], v['AAo']['min area'], v['AAo'].get('distensibility', nan),
+            v['DAo']['max area'], v['DAo']['min area'], v['DAo'].get('distensibility', nan)]
+
+
+def counts_from_labels(seg, n_class):
+    """[T, n_class] voxel counts of a (X,Y,Z,T) label volume: what np.sum(seg == k, axis=(0, 1, 2)) gives the scripts."""
+    seg = np.asarray(seg)
+    return np.stack([np.sum(seg == k, axis=(0, 1, 2)) for k in range(n_class)], axis=1).astype(np.int64)
+
+
+def _fmt(x):
+    """pandas' to_csv cell for a float: repr of the Python float (shortest round-trip), empty for NaN."""
+    x = float(x)
+    return '' if x != x else repr(x)
+
+
+def write_csv(path, columns, rows):
+    """rows: [(subject, [values])] -> the file ``pd.DataFrame(table, index=subjects, columns=columns).to_csv(path)``
+    writes (eval_ventricular_volume.py:75-79): header with an empty index label, one line per subject, '\\n' line ends.
+    Written under a temporary name and renamed."""
+    import csv
+    import io
+    import os
+    buf = io.StringIO()
+    wr = csv.writer(buf, lineterminator='\n')
+    wr.writerow([''] + list(columns))
+    for subject, vals in rows:
+        wr.writerow([subject] + [_fmt(v) for v in vals])
+    tmp = '%s.tmp.%d' % (path, os.getpid())
+    with open(tmp, 'w', newline='') as f:
+        f.write(buf.getvalue())
+    os.replace(tmp, path)
+
+
+def shard_csv_name(path, shard_index, num_shards):
+    """Where worker shard_index of num_shards writes its part of ``path`` (merged by merge_shard_csv / shard.launch)."""
+    return path if num_shards <= 1 else '%s.shard%d-of-%d' % (path, shard_index, num_shards)
+
+
+def merge_shard_csv(path, num_shards, remove=True):
+    """Concatenate the per-worker parts into ``path`` with the subjects in sorted order (the reference's loop order,
+    eval_ventricular_volume.py:28).  Missing parts (a worker with no subjects writes none) are skipped."""
+    import csv
+    import os
+    header, rows, parts = None, [], []
+    for i in range(num_shards):
+        part = shard_csv_name(path, i, num_shards)
+        if not os.path.exists(part):
+            continue
+        parts.append(part)
+        with open(part, newline='') as f:
+            rd = list(csv.reader(f))
+        if rd:
+            header = header or rd[0]
+            rows += rd[1:]
+    if header is None:
+        return False
+    rows.sort(key=lambda r: r[0])
+    tmp = '%s.tmp.%d' % (path, os.getpid())
+    with open(tmp, 'w', newline='') as f:
+        wr = csv.writer(f, lineterminator='\n')
+        wr.writerow(header)
+        wr.writerows(rows)
+    os.replace(tmp, path)
+    if remove and num_shards > 1:
+        for part in parts:
+            os.remove(part)
+    return True
+
+
+def read_central_pp(pressure_csv):
+    """{subject id (str): central pulse pressure} as eval_aortic_area.py:41-46 derives it: the mean of the two
+    'Central pulse pressure during PWA' columns 12678-2.0 / 12678-2.1 (NaNs skipped), values < 10 mmHg discarded."""
+    import csv
+    with open(pressure_csv, newline='') as f:
+        rd = list(csv.reader(f))
+    h0, h1 = rd[0], rd[1]
+    top = ''
+    cols = []
+    for i, (a, b) in enumerate(zip(h0, h1)):
+        top = a if a and not a.startswith('Unnamed') else top
+        if i > 0 and top == 'Central pulse pressure during PWA' and b in ('12678-2.0', '12678-2.1'):
+            cols.append(i)
+    out = {}
+    for r in rd[2:]:
+        if not r or not r[0]:
+            continue
+        vals = [float(r[i]) for i in cols if i < len(r) and r[i] not in ('', 'nan', 'NaN')]
+        pp = float(np.mean(vals)) if vals else float('nan')
+        out[str(r[0])] = float('nan') if pp < 10 else pp
+    return out

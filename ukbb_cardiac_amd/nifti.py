@@ -9,6 +9,8 @@ sform/qform affines, pixdim.  Data is returned in (X, Y, Z, T) order, i.e. the
 file's Fortran order, like nibabel.
 """
 import gzip
+import os
+import threading
 import zlib
 import struct
 
@@ -48,8 +50,8 @@ class _GzWriter:
     outputs of different workers / reruns can be compared with cmp."""
 
     def __init__(self, path):
-        self._raw = open(path, 'wb')
-        self._gz = gzip.GzipFile(filename='', mode='wb', compresslevel=GZIP_LEVEL, fileobj=self._raw, mtime=0)
+        self._raw = _AtomicFile(path)
+        self._gz = gzip.GzipFile(filename='', mode='wb', compresslevel=GZIP_LEVEL, fileobj=self._raw.f, mtime=0)
 
     def write(self, b):
         return self._gz.write(b)
@@ -58,8 +60,41 @@ class _GzWriter:
         return self
 
     def __exit__(self, *exc):
-        self._gz.close()
-        self._raw.close()
+        try:
+            self._gz.close()
+        finally:
+            self._raw.__exit__(*exc)
+
+
+def _tmp_name(path):
+    return '%s.tmp.%d.%d' % (path, os.getpid(), threading.get_ident())
+
+
+class _AtomicFile:
+    """Binary output file that only appears under its final name once it is complete: written as
+    ``<path>.tmp.<pid>.<thread>`` and ``os.replace``d into place on a clean exit, removed otherwise.  A worker
+    killed mid-write therefore never leaves a truncated ``seg_*.nii.gz`` behind -- that file is the 'already
+    segmented, skip' marker of the deploy loops (common/deploy_network.py:66-67)."""
+
+    def __init__(self, path):
+        self.path, self.tmp = str(path), _tmp_name(str(path))
+        self.f = open(self.tmp, 'wb')
+
+    def write(self, b):
+        return self.f.write(b)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.f.close()
+        if exc and exc[0] is not None:
+            try:
+                os.remove(self.tmp)
+            except OSError:
+                pass
+        else:
+            os.replace(self.tmp, self.path)
 
 
 class _GzReader:
@@ -141,7 +176,7 @@ class _GzReader:
 
 def _open(path, mode):
     if not str(path).endswith('.gz'):
-        return open(path, mode)
+        return _AtomicFile(path) if 'w' in mode else open(path, mode)
     return _GzWriter(path) if 'w' in mode else _GzReader(path)
 
 
@@ -197,6 +232,16 @@ def _parse_header(raw, path):
            'xyzt_units': raw[123], 'descrip': raw[148:228].rstrip(b'\x00')}
     scaled = slope != 0 and not (slope == 1 and inter == 0) and np.isfinite(slope)
     return shape, dt, off, (slope, inter) if scaled else None, affine, pixdim, hdr
+
+
+def load_header(path):
+    """Header fields only (``pixdim``, ``dim``, ..., plus ``shape``, ``dtype``, ``affine``): the first 352 bytes are inflated,
+    not the volume -- what eval scripts take from ``nib.load(image_name).header`` (eval_ventricular_volume.py:40-47)."""
+    with _open(path, 'rb') as f:
+        shape, dt, off, scale, affine, pixdim, hdr = _parse_header(f.read(352), path)
+    hdr = dict(hdr)
+    hdr.update(pixdim=pixdim, shape=shape, dtype=dt, affine=affine)
+    return hdr
 
 
 def load(path, alloc=None) -> NiftiImage:
@@ -296,6 +341,21 @@ def save(img_or_data, path, affine=None, pixdim=None, as_dtype=None):
 
 # ---- label volumes: run-length gzip writer of the C library ---------------------------------------------------------
 LABEL_FAST_PATH = True     # tests switch it off to compare with the zlib path
+# How a label volume's .nii.gz is deflated (deploy scripts: --label_gzip).  All three inflate to the same bytes.
+#   'small' (default)  run-length tokens, dynamic Huffman codes from the exact token histogram: the size of zlib level 1 or
+#                      below, ~20x less CPU than zlib for the float64 volumes of the sequence loop
+#   'fast'             run-length tokens, fixed Huffman codes: no counting pass, files 2-4x larger
+#   'zlib'             zlib level 1 over the converted volume, as nibabel writes it
+LABEL_GZIP_MODE = 'small'
+LABEL_GZIP_MODES = ('small', 'fast', 'zlib')
+
+
+def set_label_gzip(mode):
+    global LABEL_GZIP_MODE
+    if mode not in LABEL_GZIP_MODES:
+        raise ValueError('label gzip mode %r not in %s' % (mode, LABEL_GZIP_MODES))
+    LABEL_GZIP_MODE = mode
+
 
 def _as_label_volume(data):
     """data as a uint8 array in file (Fortran) order if every voxel is an integer in 0..255 (a segmentation), else None."""
@@ -312,26 +372,28 @@ def _as_label_volume(data):
 
 
 def _save_labels_gz(lab, datatype_code, prefix, path):
-    """The .nii.gz of a label volume through ukbb_fcn_gzip_labels (include/ukbb_fcn.h): same inflated bytes as the zlib
-    path below, ~20x less time for the float64 volumes of the sequence loop.  False = not available (caller falls back)."""
-    if not LABEL_FAST_PATH:
+    """The .nii.gz of a label volume through ukbb_fcn_gzip_labels_mode (include/ukbb_fcn.h): same inflated bytes as the zlib
+    path of save(), ~20x less time for the float64 volumes of the sequence loop.  False = not available / not wanted
+    (the caller falls back to zlib)."""
+    if not LABEL_FAST_PATH or LABEL_GZIP_MODE == 'zlib':
         return False
-    try:
-        from . import _lib
-    except ImportError:
+    try:                                                        # missing, unloadable or stale library: the zlib path
+        from . import _labelgz
+        gz, gz_bound = _labelgz.lib.ukbb_fcn_gzip_labels_mode, _labelgz.lib.ukbb_fcn_gzip_labels_bound
+    except Exception:
         return False
-    import ctypes as C
+    mode = _labelgz.FIXED if LABEL_GZIP_MODE == 'fast' else _labelgz.DYNAMIC
     flat = lab.reshape(-1, order='F')
     n = flat.size
     cap = max(1 << 16, len(prefix) * 2 + n * (np.dtype(_DTYPES[datatype_code]).itemsize) // 24)
     for _ in range(2):
         out = np.empty(cap, np.uint8)
-        got = _lib.lib.ukbb_fcn_gzip_labels(flat.ctypes.data, n, datatype_code, prefix, len(prefix), out.ctypes.data, cap)
+        got = gz(flat.ctypes.data, n, datatype_code, prefix, len(prefix), out.ctypes.data, cap, mode)
         if got >= 0:
-            with open(path, 'wb') as f:
+            with _AtomicFile(path) as f:
                 f.write(memoryview(out)[:got])
             return True
         if got != -4:                                           # UKBB_ENOMEM: retry once with the guaranteed bound
-            raise RuntimeError('ukbb_fcn_gzip_labels failed (%d)' % got)
-        cap = int(_lib.lib.ukbb_fcn_gzip_labels_bound(n, datatype_code, len(prefix)))
-    raise RuntimeError('ukbb_fcn_gzip_labels: output bound exceeded')
+            raise RuntimeError('ukbb_fcn_gzip_labels_mode failed (%d)' % got)
+        cap = int(gz_bound(n, datatype_code, len(prefix)))
+    raise RuntimeError('ukbb_fcn_gzip_labels_mode: output bound exceeded')

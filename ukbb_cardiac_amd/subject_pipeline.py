@@ -95,6 +95,15 @@ class SubjectPipeline:
             self._staged[id(st.array)] = st
         return st
 
+    def release(self, array):
+        """Give back a buffer ``stage()`` handed out that will not be submitted after all (its file failed to load)."""
+        with self._lock:
+            st = self._staged.pop(id(array), None)
+        if st is not None:
+            self._in_free.put(st.buf)
+            return True
+        return False
+
     def _acquire(self, shape):
         slot = self.slots[self._next]
         if slot.busy:
