@@ -453,3 +453,75 @@ def test_f32x3_is_deterministic_and_switchable(engines_x3):
     assert np.array_equal(a['logits'], d['logits'])
     assert not np.array_equal(a['logits'], c['logits'])        # another instruction sequence ...
     assert np.abs(a['logits'] - c['logits']).max() <= 1e-5 * np.abs(c['logits']).max()   # ... the same numbers to fp32 accuracy
+
+
+# ---- r03 -------------------------------------------------------------------------------------------------------------------
+
+def test_two_handles_interleaved_on_two_streams():
+    """launch state is per device, never per process.  Two engines of different models created with an
+    explicit device=0 (the nearest a one-GPU box gets to two devices: two handles, two workspaces), forwards interleaved on
+    two HIP streams with every large-LDS kernel family in play (head, Winograd, producer/consumer convs, U-Net): results
+    equal those of each engine running alone."""
+    import torch
+    from ukbb_cardiac_amd.arch import MODELS
+    from ukbb_cardiac_amd.engine import Engine
+    from ukbb_cardiac_amd.phantom import cine_phantom
+    from ukbb_cardiac_amd.weights import synthetic_params
+    dev = torch.device('cuda', 0)
+    xs = {'FCN_sa': torch.from_numpy(cine_phantom(6, 96, 112, seed=5)).to(dev),
+          'UNet_ao': torch.from_numpy(cine_phantom(3, 64, 96, seed=6)).to(dev)}
+    alone = {}
+    for name, x in xs.items():
+        with Engine(MODELS[name], synthetic_params(MODELS[name], 1234), device=0) as e:
+            n, h, w = x.shape
+            lg = torch.empty((n, h, w, MODELS[name].n_class), dtype=torch.float32, device=dev)
+            pd = torch.empty((n, h, w), dtype=torch.int32, device=dev)
+            e.run_device(x.data_ptr(), n, h, w, logits_ptr=lg.data_ptr(), pred_ptr=pd.data_ptr())
+            torch.cuda.synchronize()
+            alone[name] = (lg.cpu().numpy(), pd.cpu().numpy())
+    engs = {name: Engine(MODELS[name], synthetic_params(MODELS[name], 1234), device=0) for name in xs}
+    streams = {name: torch.cuda.Stream(dev) for name in xs}
+    try:
+        outs = {name: [] for name in xs}
+        for rep in range(4):
+            for name, x in xs.items():
+                n, h, w = x.shape
+                lg = torch.empty((n, h, w, MODELS[name].n_class), dtype=torch.float32, device=dev)
+                pd = torch.empty((n, h, w), dtype=torch.int32, device=dev)
+                engs[name].run_device(x.data_ptr(), n, h, w, logits_ptr=lg.data_ptr(), pred_ptr=pd.data_ptr(),
+                                      stream=streams[name].cuda_stream)
+                outs[name].append((lg, pd))
+        torch.cuda.synchronize()
+        for name in xs:
+            for lg, pd in outs[name]:
+                assert np.array_equal(lg.cpu().numpy(), alone[name][0]) and np.array_equal(pd.cpu().numpy(), alone[name][1]), name
+    finally:
+        for e in engs.values():
+            e.close()
+
+
+@pytest.mark.parametrize('name', ['FCN_sa', 'FCN_la_4ch_seg4', 'UNet_ao'])
+def test_pred_is_the_lowest_index_argmax_of_the_float32_probabilities(name):
+    """train_network.py:198-199 / network_ao.py:159-160: pred = argmax(softmax(logits)) over the float32 PROBABILITIES.  With
+    the last layer scaled to 1e-9 every logit difference is far below one ulp of exp's argument at 1.0: all probabilities
+    round to the same float and the reference's label is class 0 everywhere, while the logits still differ (their argmax
+    would scatter over the classes).  Also at 1e-7 -- a mix of ties and non-ties -- pred == np.argmax(prob) exactly."""
+    import copy
+    from ukbb_cardiac_amd.arch import MODELS
+    from ukbb_cardiac_amd.engine import Engine
+    from ukbb_cardiac_amd.phantom import cine_phantom
+    from ukbb_cardiac_amd.weights import synthetic_params
+    arch = MODELS[name]
+    img = cine_phantom(2, 64, 80, seed=9)
+    for scale, expect_all_zero in ((1e-9, True), (1e-7, False)):
+        params = copy.deepcopy(synthetic_params(arch, 1234))
+        params['logits']['kernel'] = (params['logits']['kernel'] * scale).astype(np.float32)
+        params['logits']['bias'] = (params['logits']['bias'] * scale).astype(np.float32)
+        with Engine(arch, params) as e:
+            out = e.run(img, want_logits=True, want_prob=True, want_pred=True)
+            only = e.run(img, want_logits=False, want_prob=False, want_pred=True)       # the pred-only path of the bench
+        assert np.array_equal(out['pred'], np.argmax(out['prob'], axis=-1).astype(np.int32))
+        assert np.array_equal(only['pred'], out['pred'])
+        by_logits = np.argmax(out['logits'], axis=-1)
+        if expect_all_zero:
+            assert not out['pred'].any() and by_logits.any()

@@ -4,7 +4,23 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "device_state.h"
+
 namespace ukbb {
+
+// ---- per-device launch state (device_state.h) on top of the HIP runtime ------------------------------------------------
+inline int current_device() { int d = 0; return hipGetDevice(&d) == hipSuccess ? d : -1; }
+// compute units of the CURRENT device (sizes the persistent grids); 256 if the query fails
+inline int device_cu_count() {
+    static PerDeviceInt cu;
+    const int d = current_device();
+    return cu.get(d, [d] { hipDeviceProp_t p; return d >= 0 && hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 0; }, 256);
+}
+// grant `kernel` `bytes` of dynamic LDS on the CURRENT device, once per device (`once`: one static per kernel instantiation)
+inline hipError_t allow_dynamic_lds(OncePerDevice &once, const void *kernel, int bytes) {
+    return (hipError_t)once.run(current_device(), [&] {
+        return (int)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); });
+}
 
 // prob / pred of train_network.py:198-199 (network_ao.py:159-160): prob = softmax(logits), pred = argmax(prob) -- the argmax
 // is taken over the float32 PROBABILITIES, lowest index on ties.  It equals argmax(logits) unless another class's logit lies

@@ -1190,20 +1190,15 @@ hipError_t launch_conv(int cfg_id, const ConvArgs &a_in, hipStream_t s) {
     }
     dim3 grid((unsigned)(a.N * a.tiles_y * a.tiles_x), (unsigned)(a.Cout / group), 1);
     const long long nitems = (long long)a.N * a.tiles_y * a.tiles_x * (a.Cout / group);
-    static const int n_cu = [] { int v = 256; hipDeviceProp_t p; int d = 0;
-                                 if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) v = p.multiProcessorCount;
-                                 return v; }();
+    const int n_cu = device_cu_count();
     switch (cfg_id) {
 #define UKBB_CFG_CASE(ID, KS, S, MB, TH, TW, KC, WM, WN, CB)                                    \
     case ID: {                                                                                  \
         auto k = conv_mfma_kernel<KS, S, MB, TH, TW, KC, WM, WN, CB>;                           \
-        static bool attr_done = false;                                                          \
-        if (!attr_done) {                                                                       \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),               \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize,      \
-                                               c->lds_bytes);                                   \
+        static OncePerDevice lds_ok;                                                            \
+        {                                                                                       \
+            hipError_t e = allow_dynamic_lds(lds_ok, reinterpret_cast<const void *>(k), c->lds_bytes); \
             if (e != hipSuccess) return e;                                                      \
-            attr_done = true;                                                                   \
         }                                                                                       \
         hipLaunchKernelGGL(k, grid, dim3(256), c->lds_bytes, s, a);                             \
         break;                                                                                  \
@@ -1212,13 +1207,10 @@ hipError_t launch_conv(int cfg_id, const ConvArgs &a_in, hipStream_t s) {
 #define UKBB_PC_CASE(ID, KS, S, MB, TH, TW, KC, WM, WN, CB)                                     \
     case ID: {                                                                                  \
         auto k = conv_pc_kernel<KS, S, MB, TH, TW, KC, WM, WN, CB>;                             \
-        static bool attr_done = false;                                                          \
-        if (!attr_done) {                                                                       \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),               \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize,      \
-                                               c->lds_bytes);                                   \
+        static OncePerDevice lds_ok;                                                            \
+        {                                                                                       \
+            hipError_t e = allow_dynamic_lds(lds_ok, reinterpret_cast<const void *>(k), c->lds_bytes); \
             if (e != hipSuccess) return e;                                                      \
-            attr_done = true;                                                                   \
         }                                                                                       \
         const int per_cu = c->lds_bytes * 2 <= 160 * 1024 ? 2 : 1;                              \
         const long long cap = (long long)n_cu * per_cu;                                         \
@@ -1230,13 +1222,10 @@ hipError_t launch_conv(int cfg_id, const ConvArgs &a_in, hipStream_t s) {
 #define UKBB_PCF_CASE(ID, KS, S, MB, TH, TW, KC, WM, WN, CB)                                    \
     case ID: {                                                                                  \
         auto k = conv_pc_kernel<KS, S, MB, TH, TW, KC, WM, WN, CB, true>;                       \
-        static bool attr_done = false;                                                          \
-        if (!attr_done) {                                                                       \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),               \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize,      \
-                                               c->lds_bytes);                                   \
+        static OncePerDevice lds_ok;                                                            \
+        {                                                                                       \
+            hipError_t e = allow_dynamic_lds(lds_ok, reinterpret_cast<const void *>(k), c->lds_bytes); \
             if (e != hipSuccess) return e;                                                      \
-            attr_done = true;                                                                   \
         }                                                                                       \
         const int per_cu = c->lds_bytes * 2 <= 160 * 1024 ? 2 : 1;                              \
         const long long cap = (long long)n_cu * per_cu;                                         \
@@ -1248,13 +1237,10 @@ hipError_t launch_conv(int cfg_id, const ConvArgs &a_in, hipStream_t s) {
 #define UKBB_BF_CASE(ID, KS, S, TH, TW, WM, WN, CB)                                             \
     case ID: {                                                                                  \
         auto k = conv_mfma_kernel<KS, S, 32, TH, TW, 16, WM, WN, CB, true>;                     \
-        static bool attr_done = false;                                                          \
-        if (!attr_done) {                                                                       \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),               \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize,      \
-                                               c->lds_bytes);                                   \
+        static OncePerDevice lds_ok;                                                            \
+        {                                                                                       \
+            hipError_t e = allow_dynamic_lds(lds_ok, reinterpret_cast<const void *>(k), c->lds_bytes); \
             if (e != hipSuccess) return e;                                                      \
-            attr_done = true;                                                                   \
         }                                                                                       \
         hipLaunchKernelGGL(k, grid, dim3(256), c->lds_bytes, s, a);                             \
         break;                                                                                  \

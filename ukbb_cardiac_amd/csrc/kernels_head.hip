@@ -914,9 +914,7 @@ __global__ __launch_bounds__(768) void fcn_head_pc_kernel(const HeadArgs a) {
 }
 
 static hipError_t launch_head_pc(const HeadArgs &a, hipStream_t s) {
-    static const int n_cu = [] { int v = 256; hipDeviceProp_t p; int d = 0;
-                                 if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) v = p.multiProcessorCount;
-                                 return v; }();
+    const int n_cu = device_cu_count();
     const int ntiles = a.N * (a.H / HT) * (a.W / HT);
     dim3 grid((unsigned)(ntiles < n_cu ? ntiles : n_cu)), block(768);
     static const bool x3_env = [] { const char *e = getenv("UKBB_HEAD_X3"); return e && atoi(e) != 0; }();   // A/B knob
@@ -925,12 +923,10 @@ static hipError_t launch_head_pc(const HeadArgs &a, hipStream_t s) {
 #define UKBB_HEADX3_CASE(NC)                                                                          \
     case NC: {                                                                                       \
         auto k = fcn_head_pc_kernel<NC, true>;                                                       \
-        static bool done = false;                                                                    \
-        if (!done) {                                                                                 \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),                    \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsx); \
+        static OncePerDevice lds_ok;                                                                 \
+        {                                                                                            \
+            hipError_t e = allow_dynamic_lds(lds_ok, reinterpret_cast<const void *>(k), (int)ldsx);    \
             if (e != hipSuccess) return e;                                                           \
-            done = true;                                                                             \
         }                                                                                            \
         hipLaunchKernelGGL(k, grid, block, ldsx, s, a);                                              \
         break;                                                                                       \
@@ -945,12 +941,10 @@ static hipError_t launch_head_pc(const HeadArgs &a, hipStream_t s) {
 #define UKBB_HEADPC_CASE(NC)                                                                          \
     case NC: {                                                                                       \
         auto k = fcn_head_pc_kernel<NC>;                                                             \
-        static bool done = false;                                                                    \
-        if (!done) {                                                                                 \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),                    \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        static OncePerDevice lds_ok;                                                                 \
+        {                                                                                            \
+            hipError_t e = allow_dynamic_lds(lds_ok, reinterpret_cast<const void *>(k), (int)lds);    \
             if (e != hipSuccess) return e;                                                           \
-            done = true;                                                                             \
         }                                                                                            \
         hipLaunchKernelGGL(k, grid, block, lds, s, a);                                               \
         break;                                                                                       \

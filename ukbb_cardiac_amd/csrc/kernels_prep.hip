@@ -310,9 +310,9 @@ struct Scratch {                                        // grow-only device scra
     }
 };
 Scratch *prep_scratch(int which) {
-    static thread_local Scratch s[16][2];
+    static thread_local Scratch s[MAX_DEVICES][2];
     int d = 0;
-    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 16) return nullptr;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MAX_DEVICES) return nullptr;
     return &s[d][which];
 }
 
@@ -337,9 +337,9 @@ float pairwise_combine(const float *leaf, size_t &idx, unsigned long long n) {
 }
 
 SelState *sel_scratch() {
-    static thread_local SelState *p[16] = {nullptr};
+    static thread_local SelState *p[MAX_DEVICES] = {nullptr};
     int d = 0;
-    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 16) return nullptr;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MAX_DEVICES) return nullptr;
     if (!p[d] && hipMalloc(&p[d], sizeof(SelState)) != hipSuccess) p[d] = nullptr;
     return p[d];
 }

@@ -397,15 +397,11 @@ template <int NCB, int TRY>
 static hipError_t launch_wino_t(const ConvArgs &a, hipStream_t s) {
     constexpr int TRX = NT / TRY;
     if (a.Cout % (16 * NCB) || (a.C0 + a.C1) % WKC || a.C0 % WKC || a.up2) return hipErrorInvalidValue;
-    static const int n_cu = [] { int v = 256; hipDeviceProp_t p; int d = 0;
-                                 if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) v = p.multiProcessorCount;
-                                 return v; }();
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wino_pc_kernel<NCB, TRY>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, WINO_LDS_FLOATS * 4);
+    const int n_cu = device_cu_count();
+    static OncePerDevice lds_ok;
+    {
+        hipError_t e = allow_dynamic_lds(lds_ok, reinterpret_cast<const void *>(wino_pc_kernel<NCB, TRY>), WINO_LDS_FLOATS * 4);
         if (e != hipSuccess) return e;
-        attr_done = true;
     }
     const int regs_x = (a.Wo + 2 * TRX - 1) / (2 * TRX), regs_y = (a.Ho + 2 * TRY - 1) / (2 * TRY);
     const long long nitems = (long long)a.N * regs_x * regs_y * (a.Cout / (16 * NCB));

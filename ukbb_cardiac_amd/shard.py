@@ -72,7 +72,22 @@ def launch(gpus: int, argv: Sequence[str], shards_per_gpu: int = 1) -> int:
                   % (i, n, i // shards_per_gpu, code, ' (killed by signal %d)' % (code - 128) if code > 128 else ''),
                   file=sys.stderr)
             rc = rc or code
+    csv_path = _flag_value(argv, 'output_csv')
+    if csv_path and rc == 0 and n > 1:                          # the workers wrote <path>.shard<i>-of-<n>: one table, sorted subjects
+        from .measures import merge_shard_csv
+        merge_shard_csv(csv_path, n)
     return rc
+
+
+def _flag_value(argv, name):
+    """Value of --name VALUE / --name=VALUE in a worker command line, or None."""
+    for i, a in enumerate(argv):
+        if a in ('--' + name, '-' + name) and i + 1 < len(argv):
+            return argv[i + 1]
+        for pre in ('--' + name + '=', '-' + name + '='):
+            if a.startswith(pre):
+                return a[len(pre):]
+    return None
 
 
 def main(argv=None):
