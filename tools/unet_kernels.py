@@ -1,4 +1,4 @@
-"""Per-kernel times of the aortic U-Net (and UNet-LSTM features) at 256x256, batch N:  python tools/unet_kernels.py [N]"""
+"""Per-kernel times of the aortic U-Net (and UNet-LSTM features) at 256x256, batch N:  python tools/unet_kernels.py [N] [fp32|bf16]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,6 +9,8 @@ from ukbb_cardiac_amd.weights import synthetic_params
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 arch = MODELS['UNet_ao']
 eng = Engine(arch, synthetic_params(arch, 1234))
+if len(sys.argv) > 2:
+    eng.set_precision(sys.argv[2])
 x = torch.rand((n, 256, 256, 1), device='cuda'); pred = torch.empty((n, 256, 256), dtype=torch.int32, device='cuda')
 for _ in range(3): eng.run_device(x.data_ptr(), n, 256, 256, pred_ptr=pred.data_ptr())
 eng.set_timing(True)

@@ -122,6 +122,7 @@ struct ukbb_fcn_handle {
     int precision = 0;                        // 0: fp32; 1: bf16 operands for the MFMA convs (fp32 accumulate); 2: fp32 from bf16 pieces (head)
     int plan_h = 0, plan_w = 0, cap_n = 0;
     bool plan_small = false;                  // plan built with the small-batch tilings
+    bool plan_bfio = false;                   // plan stores every activation between layers as bf16 (UKBB_PREC_BF16, U-Net)
     std::vector<Op> ops;
     int last_n = 0;
 
@@ -293,11 +294,15 @@ bool tile_fit_ok(const ConvConfig &c, int Ho, int Wo) {
 // Fallback preference (small tiles / high occupancy won everywhere in the sweep).
 const int g_pref[] = {4, 5, 18, 3, 11, 7, 31, 23, 22, 29, 27, 26};
 
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// bf16: 0 = fp32 tilings, 1 = bf16 operands / fp32 storage (pc 3), 2 = bf16 operands and storage (pc 5)
 bool cfg_valid(const ConvConfig &c, int ks, int stride, int c0, int c1, int cout, bool fused_first = false,
-               bool bf16 = false) {
+               int bf16 = 0) {
     if (c.ks != ks || c.stride != stride) return false;
     if ((c.pc == 2) != fused_first) return false;
-    if ((c.pc == 3) != bf16) return false;
+    if ((c.pc == 3) != (bf16 == 1) || (c.pc == 5) != (bf16 == 2)) return false;
+    if (c.pc == 5) cout = round_up(cout, 32);         // 16-channel layers run zero-padded on the 32-row MFMA
     if (c.pc == 4) {                                  // Winograd: 3x3 s1, 64-channel output groups, single source ok
         static const bool off = getenv("UKBB_NO_WINOGRAD") != nullptr;
         return !off && !fused_first && ks == 3 && stride == 1 && cout % (16 * c.wm) == 0 && c0 % 16 == 0 && c1 % 16 == 0;
@@ -317,29 +322,33 @@ int wino_orient(int id, int Ho, int Wo) {
 }
 
 int choose_cfg_raw(const std::string &layer, int ks, int stride, int c0, int c1, int cout, int Ho, int Wo, int N,
-                   bool fused_first, bool want_bf16);
+                   bool fused_first, int want_bf16);
 int find_cfg(int id, ConvConfig &out);
 
 int choose_cfg(const std::string &layer, int ks, int stride, int c0, int c1, int cout, int Ho, int Wo, int N,
-               bool fused_first = false, bool want_bf16 = false) {
+               bool fused_first = false, int want_bf16 = 0) {
     const int id = choose_cfg_raw(layer, ks, stride, c0, c1, cout, Ho, Wo, N, fused_first, want_bf16);
     return override_cfg(layer) >= 0 ? id : wino_orient(id, Ho, Wo);
 }
 
 int choose_cfg_raw(const std::string &layer, int ks, int stride, int c0, int c1, int cout, int Ho, int Wo, int N,
-                   bool fused_first, bool want_bf16) {
-    if (want_bf16 && !fused_first) {          // bf16 tilings first; fall back to fp32 where none fits (e.g. Cout = 16)
-            double best = 1e300; int best_id = -1;
+                   bool fused_first, int want_bf16) {
+    if (want_bf16 && !fused_first) {          // bf16 tilings first; fall back to fp32 where none fits (e.g. Cout = 16 with fp32 storage)
+        const int forced_bf = override_cfg(layer);
+        double best = 1e300; int best_id = -1;
         for (int i = 0; i < num_conv_configs(); ++i) {
             const ConvConfig &c = conv_config(i);
-            if (!cfg_valid(c, ks, stride, c0, c1, cout, false, true)) continue;
+            if (!cfg_valid(c, ks, stride, c0, c1, cout, false, want_bf16)) continue;
+            if (c.id == forced_bf) return c.id;
             const int group = c.mb * c.cb * c.wm;
+            const int coutp = want_bf16 == 2 ? round_up(cout, 32) : cout;
             const int tiles = ((Ho + c.th - 1) / c.th) * ((Wo + c.tw - 1) / c.tw);
             const int npb = (c.th * c.tw + c.mb - 1) / c.mb, pbw = (npb + c.wn - 1) / c.wn;
-            const double cost = (double)tiles * (cout / group) * pbw * c.cb;
+            const double cost = (double)tiles * (coutp / group) * pbw * c.cb;
             if (cost < best) { best = cost; best_id = c.id; }
         }
         if (best_id >= 0) return best_id;
+        if (want_bf16 == 2) return -1;        // bf16 storage has no fp32 fallback
     }
     const int forced = override_cfg(layer);
     ConvConfig fc;
@@ -415,18 +424,36 @@ int new_act(ukbb_fcn_handle *h, const std::string &name, size_t per_image) {
 int ensure_packed(ukbb_fcn_handle *h, int layer, const ConvConfig &c, const float **wpk) {
     const HostLayer &L = h->layers[layer];
     char key[128];
-    snprintf(key, sizeof key, "%s/pk%s_mb%d_kc%d_g%d", L.name.c_str(), c.pc == 3 ? "bf16" : c.pc == 4 ? "wino" : "", c.mb, c.kc, c.wm * c.cb);
+    const bool bfpk = c.pc == 3 || c.pc == 5;
+    const int coutp = c.pc == 5 ? round_up(L.cout, 32) : L.cout;
+    snprintf(key, sizeof key, "%s/pk%s_mb%d_kc%d_g%d", L.name.c_str(), bfpk ? "bf16" : c.pc == 4 ? "wino" : "", c.mb, c.kc, c.wm * c.cb);
     if (!dev_ptr(h, key)) {
-        std::vector<float> pk(c.pc == 4 ? (size_t)16 * L.cin * L.cout : L.w.size());
+        std::vector<float> pk(c.pc == 4 ? (size_t)16 * L.cin * L.cout : (size_t)L.ks * L.ks * L.cin * coutp);
         if (c.pc == 4) pack_wino_weights(L.w.data(), L.cin, L.cout, c.wm, pk.data());
-        else if (c.pc == 3) pack_conv_weights_bf16(L.w.data(), L.ks, L.cin, L.cout, c.wm * c.cb, pk.data());
+        else if (bfpk && coutp != L.cout) {           // zero rows up to the MFMA's 32
+            std::vector<float> wp((size_t)L.ks * L.ks * L.cin * coutp, 0.f);
+            for (size_t r = 0; r < (size_t)L.ks * L.ks * L.cin; ++r)
+                std::copy(L.w.begin() + r * L.cout, L.w.begin() + (r + 1) * L.cout, wp.begin() + r * coutp);
+            pack_conv_weights_bf16(wp.data(), L.ks, L.cin, coutp, c.wm * c.cb, pk.data());
+        }
+        else if (bfpk) pack_conv_weights_bf16(L.w.data(), L.ks, L.cin, L.cout, c.wm * c.cb, pk.data());
         else pack_conv_weights(L.w.data(), L.ks, L.cin, L.cout, c.mb, c.kc, c.wm * c.cb, pk.data());
         int rc = upload(h, key, pk);
+        if (rc) return rc;
+    }
+    if (coutp != L.cout && !dev_ptr(h, L.name + "/bias_pad")) {
+        std::vector<float> bp((size_t)coutp, 0.f);
+        std::copy(L.b.begin(), L.b.end(), bp.begin());
+        int rc = upload(h, L.name + "/bias_pad", bp);
         if (rc) return rc;
     }
     *wpk = dev_ptr(h, key);
     return UKBB_OK;
 }
+
+// UKBB_PREC_BF16 on the aortic U-Net: bf16 operands AND bf16 activations in HBM between all layers (r03);
+// on the other graphs: bf16 operands, fp32 storage (r01).
+int bf16_mode(const ukbb_fcn_handle *h) { return h->precision != 1 ? 0 : h->arch.kind == UKBB_KIND_UNET ? 2 : 1; }
 
 int add_conv(ukbb_fcn_handle *h, const std::string &lname, int in0, int in1, int c1, int H, int W, int stride,
              int n_hint, int *out_buf, bool fused_first = false) {
@@ -441,13 +468,13 @@ int add_conv(ukbb_fcn_handle *h, const std::string &lname, int in0, int in1, int
     op.pad_x = std::max((op.Wo - 1) * stride + L.ks - W, 0) / 2;
     const int c0 = L.cin - c1;
     op.fused_first = fused_first;
-    op.cfg = choose_cfg(lname, L.ks, stride, c0, c1, L.cout, op.Ho, op.Wo, n_hint, fused_first, h->precision == 1);
+    op.cfg = choose_cfg(lname, L.ks, stride, c0, c1, L.cout, op.Ho, op.Wo, n_hint, fused_first, bf16_mode(h));
     if (op.cfg < 0) { set_err("no conv tiling for layer %s (ks %d stride %d cin %d+%d cout %d)", lname.c_str(), L.ks, stride, c0, c1, L.cout); return UKBB_EARCH; }
     ConvConfig c;
     find_cfg(op.cfg, c);
     int rc = ensure_packed(h, li, c, &op.wpk);
     if (rc) return rc;
-    op.bias = dev_ptr(h, lname + "/bias");
+    op.bias = (c.pc == 5 && L.cout % 32) ? dev_ptr(h, lname + "/bias_pad") : dev_ptr(h, lname + "/bias");
     op.out = new_act(h, lname, (size_t)op.Ho * op.Wo * L.cout);
     op.macs_per_image = (double)op.Ho * op.Wo * L.ks * L.ks * L.cin * L.cout;
     if (c.pc == 4) op.mfma_macs_per_image = op.macs_per_image * (16.0 / 36.0);   // F(2x2,3x3): 16 products per 4 outputs
@@ -464,16 +491,16 @@ int add_tconv(ukbb_fcn_handle *h, const std::string &lname, int in0, int H, int 
     Op op;
     op.kind = OP_TCONV; op.name = lname; op.layer = li; op.in0 = in0;
     op.H = H; op.W = W; op.Ho = H; op.Wo = W; op.stride = 1; op.pad_y = 1; op.pad_x = 1;
-    op.cfg = choose_cfg(lname, 2, 1, L.cin, 0, 4 * L.cout, H, W, n_hint, false, h->precision == 1);
+    op.cfg = choose_cfg(lname, 2, 1, L.cin, 0, 4 * L.cout, H, W, n_hint, false, bf16_mode(h));
     if (op.cfg < 0) { set_err("no tiling for transposed conv %s", lname.c_str()); return UKBB_EARCH; }
     ConvConfig c;
     find_cfg(op.cfg, c);
     char key[128];
-    snprintf(key, sizeof key, "%s/pk2x2%s_mb%d_kc%d_g%d", L.name.c_str(), c.pc == 3 ? "bf16" : "", c.mb, c.kc, c.wm * c.cb);
+    snprintf(key, sizeof key, "%s/pk2x2%s_mb%d_kc%d_g%d", L.name.c_str(), (c.pc == 3 || c.pc == 5) ? "bf16" : "", c.mb, c.kc, c.wm * c.cb);
     if (!dev_ptr(h, key)) {
         std::vector<float> w2((size_t)4 * L.cin * 4 * L.cout), pk(w2.size());
         tconv_as_conv2x2(L.w.data(), L.cin, L.cout, w2.data());
-        if (c.pc == 3) pack_conv_weights_bf16(w2.data(), 2, L.cin, 4 * L.cout, c.wm * c.cb, pk.data());
+        if (c.pc == 3 || c.pc == 5) pack_conv_weights_bf16(w2.data(), 2, L.cin, 4 * L.cout, c.wm * c.cb, pk.data());
         else pack_conv_weights(w2.data(), 2, L.cin, 4 * L.cout, c.mb, c.kc, c.wm * c.cb, pk.data());
         int rc = upload(h, key, pk);
         if (rc) return rc;
@@ -508,7 +535,7 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
             snprintf(nm, sizeof nm, "conv%d_%d", l, i);
             const int stride = (l > 0 && i == 0) ? 2 : 1;
             static const bool no_fuse = getenv("UKBB_NO_FUSE_FIRST") != nullptr;    // A/B knob
-            const bool can_fuse = !no_fuse && a.n_block[0] >= 2 && a.n_filter[0] == 16;
+            const bool can_fuse = !no_fuse && a.n_block[0] >= 2 && a.n_filter[0] == 16 && bf16_mode(h) != 2;
             if (l == 0 && i == 0) {
                 if (can_fuse) continue;              // evaluated inside conv0_1's producers
                 Op op; op.kind = OP_FIRST; op.name = nm; op.layer = h->layer_index.at(nm);
@@ -617,6 +644,7 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
         }
     }
     h->plan_h = H; h->plan_w = W; h->plan_small = small_batch_tilings() && n_hint <= SMALL_BATCH;
+    h->plan_bfio = bf16_mode(h) == 2;
     // events
     for (auto e : h->ev) (void)hipEventDestroy(e);
     h->ev.clear();
@@ -716,7 +744,7 @@ int run_plan(ukbb_fcn_handle *h, const float *image, int n, float *logits, float
             case OP_FIRST: {
                 const HostLayer &L = h->layers[op.layer];
                 FirstArgs fa{image, dev_ptr(h, L.name + "/w"), dev_ptr(h, L.name + "/bias"), h->act[op.out]->p,
-                             n, op.H, op.W, L.cout};
+                             n, op.H, op.W, L.cout, h->plan_bfio ? 1 : 0};
                 e = launch_first(fa, s);
                 break;
             }
@@ -732,6 +760,7 @@ int run_plan(ukbb_fcn_handle *h, const float *image, int n, float *logits, float
                 ca.C0 = L.cin - ca.C1;
                 ca.wpk = op.wpk; ca.bias = op.bias; ca.out = h->act[op.out]->p;
                 ca.N = n; ca.H = op.H; ca.W = op.W; ca.Ho = op.Ho; ca.Wo = op.Wo; ca.Cout = L.cout;
+                if (c.pc == 5) { ca.Cout = round_up(L.cout, 32); ca.cout_store = L.cout; }
                 ca.pad_y = op.pad_y; ca.pad_x = op.pad_x;
                 ca.tiles_y = (op.Ho + c.th - 1) / c.th; ca.tiles_x = (op.Wo + c.tw - 1) / c.tw;
                 ca.relu = L.relu ? 1 : 0;
@@ -802,6 +831,7 @@ int run_plan(ukbb_fcn_handle *h, const float *image, int n, float *logits, float
                 la.in = h->act[op.in0]->p; la.w = dev_ptr(h, "logits/w"); la.bias = dev_ptr(h, "logits/bias");
                 la.logits = logits; la.prob = prob; la.pred = pred;
                 la.npix = (int64_t)n * op.H * op.W; la.C = L.cin; la.n_class = a.n_class;
+                la.in_bf16 = h->plan_bfio ? 1 : 0;
                 e = launch_logits(la, s);
                 break;
             }
@@ -1233,6 +1263,16 @@ int64_t ukbb_fcn_get_activation(ukbb_fcn_handle *h, const char *name, float *dst
         const int64_t n = (int64_t)h->act_per_image[i] * h->last_n;
         if (!dst) return n;
         if (cap < n) { set_err("get_activation: buffer too small (%lld < %lld)", (long long)cap, (long long)n); return UKBB_EINVAL; }
+        if (h->plan_bfio) {                            // stored as bf16: widen on the host
+            std::vector<uint16_t> tmp((size_t)n);
+            if (hipSetDevice(h->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+                hipMemcpy(tmp.data(), h->act[i]->p, (size_t)n * 2, hipMemcpyDeviceToHost) != hipSuccess) {
+                set_err("get_activation: device copy failed");
+                return UKBB_EDEVICE;
+            }
+            for (int64_t k = 0; k < n; ++k) { const uint32_t u = (uint32_t)tmp[(size_t)k] << 16; memcpy(dst + k, &u, 4); }
+            return n;
+        }
         if (hipSetDevice(h->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
             hipMemcpy(dst, h->act[i]->p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
             set_err("get_activation: device copy failed");

@@ -76,6 +76,8 @@ struct ConvArgs {
     const int *in0_map; // optional (Winograd kernel only): image n of the batch reads in0 image in0_map[n]
                         // (ConvLSTM windows share cached U-Net feature frames); in1 / out are not remapped
     int diag;           // diagnostic builds only (-DUKBB_DIAG, env UKBB_CONV_DIAG): ablation bits of conv_pc_kernel
+    int cout_store;     // bf16-storage tilings (ConvConfig::pc == 5) only: real channel count of `out` when Cout is the zero-padded
+                        // count the weights were packed for (a 16-channel layer on the 32-row MFMA); 0 = Cout
 };
 
 // One compiled tiling of the conv kernel.
@@ -91,6 +93,7 @@ struct ConvConfig {
                         // 2: producer/consumer with the C_in = 1 first layer fused into the producers;
                         // 3: single-role kernel with bf16 operands / fp32 accumulation (mb = 32, kc = 16);
                         // 4: Winograd F(2x2,3x3) producer/consumer kernel (kernels_wino.hip)
+                        // 5: as 3 with bf16 NHWC activations in HBM on both sides (in0 / in1 / out point at bf16 data)
     const char *name;
 };
 
@@ -124,6 +127,7 @@ struct FirstArgs {
     const float *bias;  // [Cout]
     float *out;         // [N,H,W,Cout]
     int N, H, W, Cout;
+    int out_bf16;       // 1: out holds bf16 (UKBB_PREC_BF16 of the U-Net: every activation between layers is bf16)
 };
 hipError_t launch_first(const FirstArgs &a, hipStream_t s);
 
@@ -189,6 +193,7 @@ struct LogitsArgs {         // 1x1 conv C -> n_class + bias, softmax / argmax (n
     const float *bias;
     float *logits; float *prob; int32_t *pred;
     int64_t npix; int C, n_class;
+    int in_bf16;            // 1: `in` holds bf16
 };
 hipError_t launch_logits(const LogitsArgs &a, hipStream_t s);
 

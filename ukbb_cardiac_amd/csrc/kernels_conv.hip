@@ -122,15 +122,22 @@ __device__ __forceinline__ void unroll_taps(F &&f) {
 // BF = true: bf16 operands (activations converted while staging, weights pre-converted on the host),
 // fp32 accumulation; requires MB = 32, KC = 16.  LDS then holds [halo px][8 dwords + 4 pad] and
 // one packed 4-dword fragment per lane per tap.
-template <int KS, int STRIDE, int MB, int TH, int TW, int KC, int WM, int WN, int CB, bool BF = false>
+// BFIO = true (with BF): activations are bf16 NHWC in HBM on both sides (UKBB_PREC_BF16 of the aortic U-Net, r03): staging
+// is a straight 16-byte copy of 8 channels (no conversion), the epilogue rounds the fp32 accumulator + bias (+ ReLU) to
+// bf16 once and stores 8 bytes per lane and 4-channel group.  ConvArgs::Cout is then the PADDED channel count the weights
+// were packed for (multiple of the workgroup's group) and ConvArgs::cout_store the real one: a 16-channel layer runs on the
+// 32-row MFMA with 16 zero rows whose results are not stored.
+template <int KS, int STRIDE, int MB, int TH, int TW, int KC, int WM, int WN, int CB, bool BF = false, bool BFIO = false>
 __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM, WN, CB)) void conv_mfma_kernel(const ConvArgs a) {
     static_assert(!BF || (MB == 32 && KC == 16), "bf16 path: 32x32x16 MFMA, one chunk = one K step");
+    static_assert(!BFIO || BF, "bf16 storage needs the bf16 operand path");
     using M = Mfma<MB>;
     using Acc = typename M::Acc;
     constexpr int KK = M::KK, KSTEPS = BF ? 4 : KC / KK, PB = MB;   // BF: "k-steps" = the 4 dwords of one bf16 fragment
     constexpr int NPIX = TH * TW, NPB = (NPIX + PB - 1) / PB, PBW = (NPB + WN - 1) / WN;
     constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
-    constexpr int HP = IH * IW, XS = BF ? KC / 2 + 4 : xs_stride(KC), C4 = KC / 4, KS2 = KS * KS;
+    constexpr int HP = IH * IW, XS = BF ? KC / 2 + 4 : xs_stride(KC), C4 = BFIO ? KC / 8 : KC / 4, KS2 = KS * KS;   // C4: 16-byte pieces per halo pixel
+    constexpr int ES = BFIO ? 2 : 4;                     // bytes per element of the activations in HBM
     constexpr int NCBL = WM * CB;                       // Cout blocks per workgroup
     constexpr int SLAB = KS2 * 64 * KSTEPS;             // packed weights of one Cout block, one chunk
     constexpr int NIT = (HP * C4 + 255) / 256;          // activation float4 per thread per chunk
@@ -181,10 +188,13 @@ __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM,
     for (int cb = 0; cb < CB; ++cb) {
         tapmask[cb] = 0xffffffffu;
         if (KS == 2 && a.up2 > 0) {
-            const int ph = ((cbg + cb) * MB) / a.up2, py = ph >> 1, px = ph & 1;
             tapmask[cb] = 0;
-            for (int t = 0; t < 4; ++t)
-                if ((py == 0 || (t >> 1) == 1) && (px == 0 || (t & 1) == 1)) tapmask[cb] |= 1u << t;
+            const int ph0 = ((cbg + cb) * MB) / a.up2, ph1 = ((cbg + cb) * MB + MB - 1) / a.up2;   // a block covers > 1 phase when up2 < MB
+            for (int ph = ph0; ph <= ph1 && ph < 4; ++ph) {
+                const int py = ph >> 1, px = ph & 1;
+                for (int t = 0; t < 4; ++t)
+                    if ((py == 0 || (t >> 1) == 1) && (px == 0 || (t & 1) == 1)) tapmask[cb] |= 1u << t;
+            }
         }
     }
 
@@ -208,15 +218,15 @@ __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM,
 #define UKBB_PREFETCH(CH)                                                                          \
     {                                                                                              \
         const int ch_ = (CH);                                                                      \
-        const float *src_; int cs_;                                                                \
-        if (ch_ * KC < a.C0) { src_ = a.in0 + ch_ * KC; cs_ = a.C0; }                              \
-        else                 { src_ = a.in1 + (ch_ * KC - a.C0); cs_ = a.C1; }                     \
-        src_ += 4 * c4;                                                                            \
+        const char *src_; int cs_;                                                                 \
+        if (ch_ * KC < a.C0) { src_ = reinterpret_cast<const char *>(a.in0) + (size_t)(ch_ * KC) * ES; cs_ = a.C0; } \
+        else                 { src_ = reinterpret_cast<const char *>(a.in1) + (size_t)(ch_ * KC - a.C0) * ES; cs_ = a.C1; } \
+        src_ += 16 * c4;                                                                           \
         _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                       \
             /* unconditional load from a clamped address: a branch around the load makes hipcc  */ \
             /* wait for it at the join, which would serialise the prefetch with the MFMA phase; */ \
             /* padding pixels are zeroed when the registers are written to LDS instead.          */ \
-            xr[it] = *reinterpret_cast<const f32x4 *>(src_ + (size_t)(goff[it] < 0 ? 0 : goff[it]) * cs_); \
+            xr[it] = *reinterpret_cast<const f32x4 *>(src_ + (size_t)(goff[it] < 0 ? 0 : goff[it]) * cs_ * ES); \
         }                                                                                          \
         const float *wp_ = wsrc + (size_t)ch_ * (NCBL * SLAB);                                     \
         _Pragma("unroll") for (int it = 0; it < NWT; ++it)                                         \
@@ -231,7 +241,9 @@ __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM,
         for (int it = 0; it < NIT; ++it) {
             const int pix = pix0 + it * PSTEP;
             const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (BF) {
+            if constexpr (BFIO) {
+                if (pix < HP) *reinterpret_cast<f32x4 *>(xs + pix * XS + 4 * c4) = goff[it] < 0 ? zero4 : xr[it];   // 8 bf16 as they come
+            } else if constexpr (BF) {
                 const f32x4 v = goff[it] < 0 ? zero4 : xr[it];
                 uint2 pk; pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
                 if (pix < HP) *reinterpret_cast<uint2 *>(xs + pix * XS + 2 * c4) = pk;
@@ -304,6 +316,43 @@ __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM,
 
     // ---- epilogue: + bias, ReLU, NHWC float4 stores -----------------------------
     constexpr int NJ = M::NACC / 4;              // float4 groups per accumulator (4 or 1)
+    if constexpr (BFIO) {
+        // bf16 NHWC: per lane and 4-channel group one 8-byte store; channels >= cout_store (zero-padded rows) are dropped
+        const int cst = a.cout_store > 0 ? a.cout_store : a.Cout;
+        unsigned short *ob = reinterpret_cast<unsigned short *>(a.out);
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            const int co0 = (cbg + cb) * MB + 4 * g;
+            float4 bi[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bi[j] = *reinterpret_cast<const float4 *>(a.bias + co0 + 8 * j);
+#pragma unroll
+            for (int pb = 0; pb < PBW; ++pb) {
+                const int q = (wn + pb * WN) * PB + pl;
+                const int oy = oy0 + q / TW, ox = ox0 + q % TW;
+                if (q < NPIX && oy < a.Ho && ox < a.Wo) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const int chn = co0 + 8 * j;
+                        unsigned short *o;
+                        if (a.up2 == 0) {
+                            if (chn >= cst) continue;
+                            o = ob + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * cst + chn;
+                        } else {                      // sub-pixel scatter of a transposed conv: phase / channel of this 4-channel group
+                            const int ph = chn / a.up2, co = chn % a.up2;
+                            o = ob + ((size_t)(n * 2 * a.Ho + 2 * oy + (ph >> 1)) * (2 * a.Wo) + 2 * ox + (ph & 1)) * a.up2 + co;
+                        }
+                        float v0 = acc[cb][pb][4 * j + 0] + bi[j].x, v1 = acc[cb][pb][4 * j + 1] + bi[j].y;
+                        float v2 = acc[cb][pb][4 * j + 2] + bi[j].z, v3 = acc[cb][pb][4 * j + 3] + bi[j].w;
+                        if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                        uint2 pk; pk.x = pack_bf16x2(v0, v1); pk.y = pack_bf16x2(v2, v3);
+                        *reinterpret_cast<uint2 *>(o) = pk;
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) {
         const int co0 = (cbg + cb) * MB + 4 * g;  // MB=32: + 8j ; MB=16: NJ = 1
@@ -1100,6 +1149,24 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
     B(220, 2, 1, 12, 13, 2, 2, 1)          \
     B(221, 2, 1, 16, 16, 2, 2, 1)
 
+// The same tilings with bf16 activations in HBM on both sides (ConvConfig::pc == 5).
+#define UKBB_BFIO_CONFIGS(B)               \
+    B(230, 3, 1, 12, 13, 2, 2, 1)          \
+    B(231, 3, 1, 12, 26, 2, 2, 1)          \
+    B(232, 3, 1, 16, 16, 1, 4, 1)          \
+    B(233, 3, 1, 16, 16, 2, 2, 1)          \
+    B(234, 3, 1, 8, 16, 1, 4, 1)           \
+    B(235, 3, 1, 8, 16, 2, 2, 1)           \
+    B(236, 3, 1, 16, 32, 1, 4, 1)          \
+    B(240, 3, 2, 12, 13, 2, 2, 1)          \
+    B(241, 3, 2, 8, 16, 1, 4, 1)           \
+    B(242, 3, 2, 8, 16, 2, 2, 1)           \
+    B(243, 3, 2, 16, 16, 1, 4, 1)          \
+    B(250, 2, 1, 12, 13, 2, 2, 1)          \
+    B(251, 2, 1, 16, 16, 2, 2, 1)          \
+    B(252, 2, 1, 16, 16, 1, 4, 1)          \
+    B(253, 2, 1, 8, 16, 2, 2, 1)
+
 // Producer/consumer tilings with the fused first layer (C_in = 1 -> KC, then this conv).
 #define UKBB_PCF_CONFIGS(Z)                          \
     Z(130, 3, 1, 16, 16, 16, 16, 1, 4, 1)            \
@@ -1119,8 +1186,12 @@ __host__ __device__ constexpr int conv_bf_lds_bytes(int ks, int s, int th, int t
     {ID, KS, S, 32, TH, TW, 16, WM, WN, CB, conv_bf_lds_bytes(KS, S, TH, TW, WM, CB), 3,       \
      "convBF16_" #KS "x" #KS "s" #S "_t" #TH "x" #TW "_w" #WM "x" #WN "_cb" #CB},
 
+#define UKBB_BFIO_ENTRY(ID, KS, S, TH, TW, WM, WN, CB)                                          \
+    {ID, KS, S, 32, TH, TW, 16, WM, WN, CB, conv_bf_lds_bytes(KS, S, TH, TW, WM, CB), 5,       \
+     "convBF16io_" #KS "x" #KS "s" #S "_t" #TH "x" #TW "_w" #WM "x" #WN "_cb" #CB},
+
 static const ConvConfig g_cfgs[] = {UKBB_CONV_CONFIGS(UKBB_CFG_ENTRY) UKBB_PC_CONFIGS(UKBB_PC_ENTRY)
-                                    UKBB_PCF_CONFIGS(UKBB_PCF_ENTRY) UKBB_BF_CONFIGS(UKBB_BF_ENTRY)
+                                    UKBB_PCF_CONFIGS(UKBB_PCF_ENTRY) UKBB_BF_CONFIGS(UKBB_BF_ENTRY) UKBB_BFIO_CONFIGS(UKBB_BFIO_ENTRY)
                                     // Winograd F(2x2,3x3): region 4x8 tiles (8x16 px), 64 Cout per item, KC 16
                                     {300, 3, 1, 16, 8, 16, 16, 4, 1, 1, 112640, 4, "winogradF2x2_3x3_t8x16_kc16_cout64"},
                                     {301, 3, 1, 16, 8, 16, 16, 2, 1, 1, 112640, 4, "winogradF2x2_3x3_t8x16_kc16_cout32"},
@@ -1246,6 +1317,18 @@ hipError_t launch_conv(int cfg_id, const ConvArgs &a_in, hipStream_t s) {
         break;                                                                                  \
     }
         UKBB_BF_CONFIGS(UKBB_BF_CASE)
+#define UKBB_BFIO_CASE(ID, KS, S, TH, TW, WM, WN, CB)                                           \
+    case ID: {                                                                                  \
+        auto k = conv_mfma_kernel<KS, S, 32, TH, TW, 16, WM, WN, CB, true, true>;               \
+        static OncePerDevice lds_ok;                                                            \
+        {                                                                                       \
+            hipError_t e = allow_dynamic_lds(lds_ok, reinterpret_cast<const void *>(k), c->lds_bytes); \
+            if (e != hipSuccess) return e;                                                      \
+        }                                                                                       \
+        hipLaunchKernelGGL(k, grid, dim3(256), c->lds_bytes, s, a);                             \
+        break;                                                                                  \
+    }
+        UKBB_BFIO_CONFIGS(UKBB_BFIO_CASE)
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -1307,7 +1390,7 @@ size_t pack_conv_weights_bf16(const float *w, int ks, int cin, int cout, int ncb
 // thin for the matrix pipe and the layer is 0.4 % of the MACs.
 // One thread = one pixel x all Cout; weights broadcast from LDS.
 // ---------------------------------------------------------------------------
-template <int COUT>
+template <int COUT, bool OBF = false>
 __global__ __launch_bounds__(256) void conv_first_kernel(const FirstArgs a) {
     __shared__ float wl[9 * COUT + COUT];
     for (int i = threadIdx.x; i < 9 * COUT; i += 256) wl[i] = a.w[i];
@@ -1325,18 +1408,26 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const FirstArgs a) {
             v[t] = ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W) ? img[(size_t)yy * a.W + xx] : 0.f;
         }
         float *o = a.out + q * COUT;
+        unsigned short *ob = reinterpret_cast<unsigned short *>(a.out) + q * COUT;
 #pragma unroll
-        for (int c = 0; c < COUT; c += 4) {
-            float4 r;
-            float *rp = &r.x;
+        for (int c = 0; c < COUT; c += 8) {
+            float rp[8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 8; ++j) {
                 float s = 0.f;
 #pragma unroll
                 for (int t = 0; t < 9; ++t) s = fmaf(v[t], wl[t * COUT + c + j], s);
                 rp[j] = fmaxf(s + wl[9 * COUT + c + j], 0.f);
             }
-            *reinterpret_cast<float4 *>(o + c) = r;
+            if constexpr (OBF) {
+                uint4 pk;
+                pk.x = pack_bf16x2(rp[0], rp[1]); pk.y = pack_bf16x2(rp[2], rp[3]);
+                pk.z = pack_bf16x2(rp[4], rp[5]); pk.w = pack_bf16x2(rp[6], rp[7]);
+                *reinterpret_cast<uint4 *>(ob + c) = pk;
+            } else {
+                *reinterpret_cast<float4 *>(o + c) = float4{rp[0], rp[1], rp[2], rp[3]};
+                *reinterpret_cast<float4 *>(o + c + 4) = float4{rp[4], rp[5], rp[6], rp[7]};
+            }
         }
     }
 }
@@ -1345,7 +1436,8 @@ hipError_t launch_first(const FirstArgs &a, hipStream_t s) {
     const size_t total = (size_t)a.N * a.H * a.W;
     unsigned grid = (unsigned)((total + 255) / 256);
     if (grid > 256u * 16u) grid = 256u * 16u;
-    if (a.Cout == 16) hipLaunchKernelGGL(conv_first_kernel<16>, dim3(grid), dim3(256), 0, s, a);
+    if (a.Cout == 16 && a.out_bf16) hipLaunchKernelGGL((conv_first_kernel<16, true>), dim3(grid), dim3(256), 0, s, a);
+    else if (a.Cout == 16) hipLaunchKernelGGL((conv_first_kernel<16, false>), dim3(grid), dim3(256), 0, s, a);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

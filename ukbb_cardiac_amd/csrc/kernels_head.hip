@@ -1052,7 +1052,7 @@ void pack_head_lg(const float *w, int n_class, float *dst) {
 // (reference common/network_ao.py:63,159-160).  C = 16: 48 MAC per pixel,
 // bandwidth-bound; one thread per pixel on the vector ALU.
 // ---------------------------------------------------------------------------
-template <int C, int NCLS>
+template <int C, int NCLS, bool IBF = false>
 __global__ __launch_bounds__(256) void logits_kernel(const LogitsArgs a) {
     __shared__ float wl[C * NCLS + NCLS];
     for (int i = threadIdx.x; i < C * NCLS; i += 256) wl[i] = a.w[i];
@@ -1060,10 +1060,24 @@ __global__ __launch_bounds__(256) void logits_kernel(const LogitsArgs a) {
     __syncthreads();
     for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < a.npix; q += (int64_t)gridDim.x * 256) {
         float xin[C];
+        if constexpr (IBF) {                                  // bf16 -> f32 is a 16-bit shift
+            const unsigned short *ib = reinterpret_cast<const unsigned short *>(a.in) + q * C;
+#pragma unroll
+            for (int j = 0; j < C / 8; ++j) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(ib + 8 * j);
+                const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    xin[8 * j + 2 * k] = __builtin_bit_cast(float, u[k] << 16);
+                    xin[8 * j + 2 * k + 1] = __builtin_bit_cast(float, u[k] & 0xffff0000u);
+                }
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < C / 4; ++j) {
             const float4 v = *reinterpret_cast<const float4 *>(a.in + q * C + 4 * j);
             xin[4 * j] = v.x; xin[4 * j + 1] = v.y; xin[4 * j + 2] = v.z; xin[4 * j + 3] = v.w;
+        }
         }
         float lg[NCLS];
 #pragma unroll
@@ -1090,6 +1104,13 @@ __global__ __launch_bounds__(256) void logits_kernel(const LogitsArgs a) {
 hipError_t launch_logits(const LogitsArgs &a, hipStream_t s) {
     unsigned grid = (unsigned)((a.npix + 255) / 256);
     if (grid > 256u * 16u) grid = 256u * 16u;
+    if (a.in_bf16) {
+        if (a.C == 16 && a.n_class == 3) hipLaunchKernelGGL((logits_kernel<16, 3, true>), dim3(grid), dim3(256), 0, s, a);
+        else if (a.C == 16 && a.n_class == 2) hipLaunchKernelGGL((logits_kernel<16, 2, true>), dim3(grid), dim3(256), 0, s, a);
+        else if (a.C == 16 && a.n_class == 4) hipLaunchKernelGGL((logits_kernel<16, 4, true>), dim3(grid), dim3(256), 0, s, a);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
     if (a.C == 16 && a.n_class == 3) hipLaunchKernelGGL((logits_kernel<16, 3>), dim3(grid), dim3(256), 0, s, a);
     else if (a.C == 16 && a.n_class == 2) hipLaunchKernelGGL((logits_kernel<16, 2>), dim3(grid), dim3(256), 0, s, a);
     else if (a.C == 16 && a.n_class == 4) hipLaunchKernelGGL((logits_kernel<16, 4>), dim3(grid), dim3(256), 0, s, a);
