@@ -1,5 +1,5 @@
 """Time given (layer:cfg) pairs on the bench workload (GPU box):  python tools/sweep_convs.py conv2_0:124,127 conv3_0:124,126 ...
-   MODEL=UNet_ao SHAPE=100,256,256 selects another model / batch shape."""
+   MODEL=UNet_ao SHAPE=100,256,256 selects another model / batch shape, PREC=bf16 the precision mode."""
 import os
 import sys
 
@@ -21,6 +21,8 @@ if __name__ == '__main__':
         for cfg in cfgs.split(','):
             os.environ['UKBB_CONV_CFG'] = '%s:%s' % (layer, cfg)
             eng = Engine(arch, params)
+            if os.environ.get('PREC'):
+                eng.set_precision(os.environ['PREC'])
             for _ in range(3):
                 eng.run_device(x.data_ptr(), n, h, w, pred_ptr=pred.data_ptr())
             eng.set_timing(True)

@@ -94,6 +94,7 @@ struct Op {                    // one kernel launch of the plan
     int sq[4] = {-1, -1, -1, -1};   // OP_HEAD: squeezed maps of levels 1..4
     int mlayer[4] = {-1, -1, -1, -1}, min_[4] = {-1, -1, -1, -1}, mout[4] = {-1, -1, -1, -1}, mh[4] = {0, 0, 0, 0}, mw[4] = {0, 0, 0, 0};   // OP_SQG_MULTI: levels 1..4
     bool fused_first = false;       // OP_CONV: conv0_0 (C_in = 1) evaluated by this kernel's producers
+    bool fused_logits = false;      // OP_CONV (bf16 storage): the 1x1 logits conv + softmax / argmax evaluated in this kernel's epilogue
     bool on_side = false;           // launched on the handle's side stream (fork/join by events)
     int H = 0, W = 0, Ho = 0, Wo = 0, stride = 1, pad_y = 0, pad_x = 0;
     double macs_per_image = 0; // algorithmic
@@ -298,8 +299,9 @@ int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // bf16: 0 = fp32 tilings, 1 = bf16 operands / fp32 storage (pc 3), 2 = bf16 operands and storage (pc 5)
 bool cfg_valid(const ConvConfig &c, int ks, int stride, int c0, int c1, int cout, bool fused_first = false,
-               int bf16 = 0) {
+               int bf16 = 0, int fuse = 0) {
     if (c.ks != ks || c.stride != stride) return false;
+    if (c.fuse != fuse) return false;
     if ((c.pc == 2) != fused_first) return false;
     if ((c.pc == 3) != (bf16 == 1) || (c.pc == 5) != (bf16 == 2)) return false;
     if (c.pc == 5) cout = round_up(cout, 32);         // 16-channel layers run zero-padded on the 32-row MFMA
@@ -331,8 +333,29 @@ int choose_cfg(const std::string &layer, int ks, int stride, int c0, int c1, int
     return override_cfg(layer) >= 0 ? id : wino_orient(id, Ho, Wo);
 }
 
+// bf16-storage tilings measured best per layer type of the aortic U-Net at N = 100 x 256 x 256 (tools/sweep_convs.py with
+// PREC=bf16, profiles/r03_sweep_bf16.txt): {ks, stride, cin (both sources), cout (4 x cout for the 2x2 form of a transposed conv), cfg}.
+// Levels 2-4 sit on a 35-50 us floor per launch whatever the tiling (launch + first-load latency + tail at 100-400 tiles);
+// the table mostly avoids the bad cases (conv3_0 108 -> 47 us, up2_0 104 -> 80, conv2_0 61 -> 45).
+const Tuned g_tuned_bfio[] = {
+    {3, 1, 16, 16, 236, 232, -1},   {3, 1, 32, 32, 232, -1, -1},   {3, 1, 64, 64, 235, 232, -1},    {3, 1, 128, 128, 235, 232, -1},
+    {3, 1, 256, 256, 239, 232, -1}, {3, 1, 256, 128, 239, 232, -1}, {3, 1, 128, 64, 239, 232, -1},  {3, 1, 64, 32, 232, -1, -1},
+    {3, 1, 32, 16, 236, 232, -1},
+    {3, 2, 16, 32, 241, -1, -1},    {3, 2, 32, 64, 242, 241, -1},   {3, 2, 64, 128, 244, 241, -1},  {3, 2, 128, 256, 244, 241, -1},
+    {2, 1, 256, 512, 253, 251, -1}, {2, 1, 128, 256, 253, 251, -1}, {2, 1, 64, 128, 253, 251, -1},  {2, 1, 32, 64, 258, 253, 251},
+};
+
 int choose_cfg_raw(const std::string &layer, int ks, int stride, int c0, int c1, int cout, int Ho, int Wo, int N,
                    bool fused_first, int want_bf16) {
+    if (want_bf16 == 2 && !fused_first && override_cfg(layer) < 0) {
+        for (const Tuned &t : g_tuned_bfio) {
+            if (t.ks != ks || t.stride != stride || t.cin != c0 + c1 || t.cout != cout) continue;
+            for (int cand : {t.cfg, t.alt, t.alt2}) {
+                ConvConfig cc;
+                if (cand >= 0 && find_cfg(cand, cc) == 0 && cfg_valid(cc, ks, stride, c0, c1, cout, false, 2) && tile_fit_ok(cc, Ho, Wo)) return cand;
+            }
+        }
+    }
     if (want_bf16 && !fused_first) {          // bf16 tilings first; fall back to fp32 where none fits (e.g. Cout = 16 with fp32 storage)
         const int forced_bf = override_cfg(layer);
         double best = 1e300; int best_id = -1;
@@ -456,7 +479,7 @@ int ensure_packed(ukbb_fcn_handle *h, int layer, const ConvConfig &c, const floa
 int bf16_mode(const ukbb_fcn_handle *h) { return h->precision != 1 ? 0 : h->arch.kind == UKBB_KIND_UNET ? 2 : 1; }
 
 int add_conv(ukbb_fcn_handle *h, const std::string &lname, int in0, int in1, int c1, int H, int W, int stride,
-             int n_hint, int *out_buf, bool fused_first = false) {
+             int n_hint, int *out_buf, bool fused_first = false, bool fused_logits = false) {
     const int li = h->layer_index.at(lname);
     const HostLayer &L = h->layers[li];
     Op op;
@@ -468,7 +491,19 @@ int add_conv(ukbb_fcn_handle *h, const std::string &lname, int in0, int in1, int
     op.pad_x = std::max((op.Wo - 1) * stride + L.ks - W, 0) / 2;
     const int c0 = L.cin - c1;
     op.fused_first = fused_first;
+    const int fuse_bf = bf16_mode(h) != 2 ? 0 : fused_first ? 1 : fused_logits ? 2 : 0;
+    if (fuse_bf) {
+        // bf16 storage: the fused variants of the level-0 tilings (ConvConfig::fuse), first fit in measured order
+        op.cfg = -1;
+        const int forced = override_cfg(lname);
+        for (int cand : {forced, fuse_bf == 1 ? 295 : 298, fuse_bf == 1 ? 294 : 297, fuse_bf == 1 ? 296 : 299}) {
+            ConvConfig cc;
+            if (cand >= 0 && find_cfg(cand, cc) == 0 && cfg_valid(cc, L.ks, stride, c0, c1, L.cout, false, 2, fuse_bf) &&
+                (cand == forced || tile_fit_ok(cc, op.Ho, op.Wo))) { op.cfg = cand; break; }
+        }
+    } else
     op.cfg = choose_cfg(lname, L.ks, stride, c0, c1, L.cout, op.Ho, op.Wo, n_hint, fused_first, bf16_mode(h));
+    op.fused_logits = fuse_bf == 2;
     if (op.cfg < 0) { set_err("no conv tiling for layer %s (ks %d stride %d cin %d+%d cout %d)", lname.c_str(), L.ks, stride, c0, c1, L.cout); return UKBB_EARCH; }
     ConvConfig c;
     find_cfg(op.cfg, c);
@@ -496,11 +531,12 @@ int add_tconv(ukbb_fcn_handle *h, const std::string &lname, int in0, int H, int 
     ConvConfig c;
     find_cfg(op.cfg, c);
     char key[128];
-    snprintf(key, sizeof key, "%s/pk2x2%s_mb%d_kc%d_g%d", L.name.c_str(), (c.pc == 3 || c.pc == 5) ? "bf16" : "", c.mb, c.kc, c.wm * c.cb);
+    const bool bfpk = c.pc == 3 || c.pc == 5;
+    snprintf(key, sizeof key, "%s/pk2x2%s_mb%d_kc%d_g%d", L.name.c_str(), bfpk ? "bf16" : "", c.mb, c.kc, c.wm * c.cb);
     if (!dev_ptr(h, key)) {
         std::vector<float> w2((size_t)4 * L.cin * 4 * L.cout), pk(w2.size());
         tconv_as_conv2x2(L.w.data(), L.cin, L.cout, w2.data());
-        if (c.pc == 3 || c.pc == 5) pack_conv_weights_bf16(w2.data(), 2, L.cin, 4 * L.cout, c.wm * c.cb, pk.data());
+        if (bfpk) pack_conv_weights_bf16(w2.data(), 2, L.cin, 4 * L.cout, c.wm * c.cb, pk.data());
         else pack_conv_weights(w2.data(), 2, L.cin, 4 * L.cout, c.mb, c.kc, c.wm * c.cb, pk.data());
         int rc = upload(h, key, pk);
         if (rc) return rc;
@@ -535,7 +571,7 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
             snprintf(nm, sizeof nm, "conv%d_%d", l, i);
             const int stride = (l > 0 && i == 0) ? 2 : 1;
             static const bool no_fuse = getenv("UKBB_NO_FUSE_FIRST") != nullptr;    // A/B knob
-            const bool can_fuse = !no_fuse && a.n_block[0] >= 2 && a.n_filter[0] == 16 && bf16_mode(h) != 2;
+            const bool can_fuse = !no_fuse && a.n_block[0] >= 2 && a.n_filter[0] == 16;
             if (l == 0 && i == 0) {
                 if (can_fuse) continue;              // evaluated inside conv0_1's producers
                 Op op; op.kind = OP_FIRST; op.name = nm; op.layer = h->layer_index.at(nm);
@@ -611,15 +647,24 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
             int x = -1;
             for (int i = 0; i < a.n_block[l]; ++i) {
                 snprintf(nm, sizeof nm, "up%d_%d", l, i);
+                static const bool no_fuse_lg = getenv("UKBB_NO_FUSE_LOGITS") != nullptr;    // A/B knob
+                // bf16 storage: logits + softmax / argmax ride in the epilogue of the very last conv (its output is never stored)
+                const bool flg = a.kind == UKBB_KIND_UNET && bf16_mode(h) == 2 && !no_fuse_lg && l == 0 && i == a.n_block[0] - 1 &&
+                                 i > 0 && a.n_filter[0] == 16;
                 rc = (i == 0) ? add_conv(h, nm, level_out[l], t, a.n_filter[l], lh[l], lw[l], 1, n_hint, &x)
-                              : add_conv(h, nm, x, -1, 0, lh[l], lw[l], 1, n_hint, &x);
+                              : add_conv(h, nm, x, -1, 0, lh[l], lw[l], 1, n_hint, &x, false, flg);
                 if (rc) return rc;
             }
             up = x;
             h->act_name[up] = std::string("up") + std::to_string(l);
         }
         h->feat_buf = up;                              // net['conv0_up']: what UNet_LSTM_Model feeds the LSTM (:343-347)
-        if (a.kind == UKBB_KIND_UNET) {
+        if (a.kind == UKBB_KIND_UNET && h->ops.back().kind == OP_CONV && h->ops.back().fused_logits) {
+            Op &last = h->ops.back();
+            last.name += "+logits";
+            last.macs_per_image += (double)H * W * a.n_filter[0] * a.n_class;
+            h->act_name[up] = "";                      // net['conv0_up'] does not exist in HBM in this plan
+        } else if (a.kind == UKBB_KIND_UNET) {
             Op op; op.kind = OP_LOGITS; op.name = "logits"; op.layer = h->layer_index.at("logits"); op.in0 = up;
             op.H = op.Ho = H; op.W = op.Wo = W;
             op.macs_per_image = (double)H * W * a.n_filter[0] * a.n_class;
@@ -761,6 +806,10 @@ int run_plan(ukbb_fcn_handle *h, const float *image, int n, float *logits, float
                 ca.wpk = op.wpk; ca.bias = op.bias; ca.out = h->act[op.out]->p;
                 ca.N = n; ca.H = op.H; ca.W = op.W; ca.Ho = op.Ho; ca.Wo = op.Wo; ca.Cout = L.cout;
                 if (c.pc == 5) { ca.Cout = round_up(L.cout, 32); ca.cout_store = L.cout; }
+                if (op.fused_logits) {
+                    ca.lg_w = dev_ptr(h, "logits/w"); ca.lg_b = dev_ptr(h, "logits/bias");
+                    ca.lg_logits = logits; ca.lg_prob = prob; ca.lg_pred = pred; ca.lg_ncls = a.n_class;
+                }
                 ca.pad_y = op.pad_y; ca.pad_x = op.pad_x;
                 ca.tiles_y = (op.Ho + c.th - 1) / c.th; ca.tiles_x = (op.Wo + c.tw - 1) / c.tw;
                 ca.relu = L.relu ? 1 : 0;
@@ -1214,7 +1263,7 @@ int ukbb_fcn_set_precision(ukbb_fcn_handle *h, int precision) {
 }
 
 int ukbb_fcn_kernel_config(const ukbb_fcn_handle *h, int i) {
-    if (!h || i < 0 || i >= (int)h->ops.size() || h->ops[i].kind != OP_CONV) return -1;
+    if (!h || i < 0 || i >= (int)h->ops.size() || (h->ops[i].kind != OP_CONV && h->ops[i].kind != OP_TCONV)) return -1;
     return h->ops[i].cfg;
 }
 

@@ -76,6 +76,12 @@ struct ConvArgs {
     const int *in0_map; // optional (Winograd kernel only): image n of the batch reads in0 image in0_map[n]
                         // (ConvLSTM windows share cached U-Net feature frames); in1 / out are not remapped
     int diag;           // diagnostic builds only (-DUKBB_DIAG, env UKBB_CONV_DIAG): ablation bits of conv_pc_kernel
+    // bf16-storage tilings only (pc == 5): the 1x1 logits conv + softmax / argmax of network_ao.py:63,159-160 evaluated in the
+    // epilogue of the LAST 16-channel conv (out is then not written at all): lg_w [16][lg_ncls], lg_b [lg_ncls]
+    const float *lg_w, *lg_b;
+    float *lg_logits, *lg_prob;   // optional [N,Ho,Wo,lg_ncls]
+    int32_t *lg_pred;             // optional [N,Ho,Wo]
+    int lg_ncls;
     int cout_store;     // bf16-storage tilings (ConvConfig::pc == 5) only: real channel count of `out` when Cout is the zero-padded
                         // count the weights were packed for (a 16-channel layer on the 32-row MFMA); 0 = Cout
 };
@@ -95,6 +101,8 @@ struct ConvConfig {
                         // 4: Winograd F(2x2,3x3) producer/consumer kernel (kernels_wino.hip)
                         // 5: as 3 with bf16 NHWC activations in HBM on both sides (in0 / in1 / out point at bf16 data)
     const char *name;
+    int fuse;           // pc == 5 only: 1 = the C_in = 1 first layer evaluated in this conv's staging (ConvArgs::first_w / first_b,
+                        // in0 = the fp32 image), 2 = the logits conv + softmax / argmax in its epilogue (ConvArgs::lg_*); else 0
 };
 
 int num_conv_configs();

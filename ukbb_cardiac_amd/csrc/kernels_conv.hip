@@ -127,8 +127,9 @@ __device__ __forceinline__ void unroll_taps(F &&f) {
 // bf16 once and stores 8 bytes per lane and 4-channel group.  ConvArgs::Cout is then the PADDED channel count the weights
 // were packed for (multiple of the workgroup's group) and ConvArgs::cout_store the real one: a 16-channel layer runs on the
 // 32-row MFMA with 16 zero rows whose results are not stored.
-template <int KS, int STRIDE, int MB, int TH, int TW, int KC, int WM, int WN, int CB, bool BF = false, bool BFIO = false>
+template <int KS, int STRIDE, int MB, int TH, int TW, int KC, int WM, int WN, int CB, bool BF = false, bool BFIO = false, int FUSE = 0>
 __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM, WN, CB)) void conv_mfma_kernel(const ConvArgs a) {
+    static_assert(FUSE == 0 || (BFIO && KS == 3 && STRIDE == 1 && CB == 1 && WM == 1), "fused first layer / logits: bf16 storage, 3x3 s1, one Cout block");
     static_assert(!BF || (MB == 32 && KC == 16), "bf16 path: 32x32x16 MFMA, one chunk = one K step");
     static_assert(!BFIO || BF, "bf16 storage needs the bf16 operand path");
     using M = Mfma<MB>;
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM,
     }
 
     f32x4 xr[NIT], wr[NWT];
-#define UKBB_PREFETCH(CH)                                                                          \
+#define UKBB_PREFETCH_X(CH)                                                                        \
     {                                                                                              \
         const int ch_ = (CH);                                                                      \
         const char *src_; int cs_;                                                                 \
@@ -228,15 +229,64 @@ __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM,
             /* padding pixels are zeroed when the registers are written to LDS instead.          */ \
             xr[it] = *reinterpret_cast<const f32x4 *>(src_ + (size_t)(goff[it] < 0 ? 0 : goff[it]) * cs_ * ES); \
         }                                                                                          \
-        const float *wp_ = wsrc + (size_t)ch_ * (NCBL * SLAB);                                     \
+    }
+#define UKBB_PREFETCH_W(CH)                                                                        \
+    {                                                                                              \
+        const float *wp_ = wsrc + (size_t)(CH) * (NCBL * SLAB);                                    \
         _Pragma("unroll") for (int it = 0; it < NWT; ++it)                                         \
             wr[it] = *reinterpret_cast<const f32x4 *>((it * 256 + tid < WF4) ? wp_ + 4 * (it * 256 + tid) : a.wpk); \
     }
+#define UKBB_PREFETCH(CH) { UKBB_PREFETCH_X(CH) UKBB_PREFETCH_W(CH) }
 
-    UKBB_PREFETCH(0)
+    // Fused first layer (bf16 storage, 3x3 stride 1 only): in0 is then the network's 1-channel fp32 image and this conv's 16
+    // input channels are relu(BN(conv3x3(image))) (network_ao.py:31-35 with l = 0, i = 0) evaluated here for every halo pixel:
+    // the raw (IH+2) x (IW+2) tile goes to LDS, then per 16 halo pixels three v_mfma_f32_16x16x4_f32 (fp32-exact; A = the
+    // [16 x 12] folded filter with taps 9..11 zero, B = the lane's pixel at tap k, bias as the C operand) give a lane 4
+    // consecutive channels of its pixel, which are rounded to bf16 once -- exactly what the stand-alone first-layer kernel would
+    // have stored -- and written into the halo tile.  conv0_0's output (420 MB per 100 slices, written + re-read) never exists.
+    constexpr bool fusedf = FUSE == 1;
+    if constexpr (fusedf) {
+        {
+            constexpr int RH = IH + 2, RW = IW + 2, RP = RH * RW, NBLK = (HP + 15) / 16;
+            float *raw = ws + NCBL * SLAB;
+            const float *img = a.in0 + (size_t)n * a.H * a.W;
+            for (int i = tid; i < RP; i += 256) {
+                const int ry = i / RW, rx = i - ry * RW, gy = iy0 - 1 + ry, gx = ix0 - 1 + rx;
+                raw[i] = ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) ? img[(size_t)gy * a.W + gx] : 0.f;
+            }
+            const int pj = lane & 15, pg = lane >> 4;
+            float wA[3]; int toff[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int t = 4 * k + pg;
+                wA[k] = t < 9 ? a.first_w[t * 16 + pj] : 0.f;
+                const int tt = t < 9 ? t : 8;                  // zero weight: any finite value of the tile will do
+                toff[k] = (tt / 3) * RW + (tt % 3);
+            }
+            const f32x4 biasq = *reinterpret_cast<const f32x4 *>(a.first_b + 4 * pg);
+            __syncthreads();
+            for (int blk = wave; blk < NBLK; blk += 4) {       // wave-uniform trip count
+                const int pix = blk * 16 + pj;
+                const int hy = pix / IW, hx = pix - hy * IW;
+                const int ro = pix < HP ? hy * RW + hx : 0;
+                f32x4 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[0], raw[ro + toff[0]], biasq, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[1], raw[ro + toff[1]], acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[2], raw[ro + toff[2]], acc0, 0, 0, 0);
+                // halo pixels outside the image are THIS conv's zero padding, not conv0_0 of padded input
+                const bool in = (unsigned)(iy0 + hy) < (unsigned)a.H && (unsigned)(ix0 + hx) < (unsigned)a.W;
+                uint2 pk;
+                pk.x = in ? pack_bf16x2(fmaxf(acc0[0], 0.f), fmaxf(acc0[1], 0.f)) : 0u;
+                pk.y = in ? pack_bf16x2(fmaxf(acc0[2], 0.f), fmaxf(acc0[3], 0.f)) : 0u;
+                if (pix < HP) *reinterpret_cast<uint2 *>(xs + pix * XS + 2 * pg) = pk;
+            }
+        }
+    }
+
+    if constexpr (fusedf) UKBB_PREFETCH_W(0) else UKBB_PREFETCH(0)
     for (int ch = 0; ch < nchunk; ++ch) {
         if (ch > 0) __syncthreads();                    // all waves done reading the previous chunk
         // ---- registers -> LDS (straight 16-byte copies) ----
+        if constexpr (!fusedf) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int pix = pix0 + it * PSTEP;
@@ -250,6 +300,7 @@ __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM,
             } else {
                 if (pix < HP) *reinterpret_cast<f32x4 *>(xs + pix * XS + 4 * c4) = goff[it] < 0 ? zero4 : xr[it];
             }
+        }
         }
 #pragma unroll
         for (int it = 0; it < NWT; ++it)
@@ -320,6 +371,60 @@ __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM,
         // bf16 NHWC: per lane and 4-channel group one 8-byte store; channels >= cout_store (zero-padded rows) are dropped
         const int cst = a.cout_store > 0 ? a.cout_store : a.Cout;
         unsigned short *ob = reinterpret_cast<unsigned short *>(a.out);
+        if constexpr (FUSE == 2) {
+            // Last layer with the logits fused (16 real channels: lane half g holds channels 4g..4g+3 and 8+4g..8+4g+3 of its
+            // pixel): the activation is rounded to bf16 as it would have been stored, each half forms its 8-channel part of the
+            // 16 -> n_class product, the halves are added across lanes l / l^32, then bias, softmax / argmax (kernels.h).
+            float w8[8][4];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) w8[k][c] = c < a.lg_ncls ? a.lg_w[(4 * g + (k & 3) + 8 * (k >> 2)) * a.lg_ncls + c] : 0.f;
+            float bl[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bl[c] = c < a.lg_ncls ? a.lg_b[c] : 0.f;
+            float4 bi2[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bi2[j] = *reinterpret_cast<const float4 *>(a.bias + 4 * g + 8 * j);
+#pragma unroll
+            for (int pb = 0; pb < PBW; ++pb) {
+                const int q = (wn + pb * WN) * PB + pl;
+                const int oy = oy0 + q / TW, ox = ox0 + q % TW;
+                float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int j = k >> 2, i = k & 3;
+                    float v = acc[0][pb][4 * j + i] + (&bi2[j].x)[i];
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    const float r = __builtin_bit_cast(float, pack_bf16x2(v, 0.f) << 16);      // the value the bf16 store would have held
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) part[c] = fmaf(r, w8[k][c], part[c]);
+                }
+                float lgv[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) lgv[c] = (part[c] + __shfl_xor(part[c], 32)) + bl[c];
+                if (g == 0 && q < NPIX && oy < a.Ho && ox < a.Wo) {
+                    const size_t px = (size_t)(n * a.Ho + oy) * a.Wo + ox;
+                    auto finish = [&](auto nc) {
+                        constexpr int NC = decltype(nc)::value;
+                        float l[NC], p[NC];
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) l[c] = lgv[c];
+                        const int best = softmax_argmax<NC>(l, a.lg_prob ? p : nullptr);
+                        if (a.lg_pred) a.lg_pred[px] = best;
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) {
+                            if (a.lg_logits) a.lg_logits[px * NC + c] = l[c];
+                            if (a.lg_prob) a.lg_prob[px * NC + c] = p[c];
+                        }
+                    };
+                    if (a.lg_ncls == 2) finish(std::integral_constant<int, 2>{});
+                    else if (a.lg_ncls == 3) finish(std::integral_constant<int, 3>{});
+                    else finish(std::integral_constant<int, 4>{});
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
             const int co0 = (cbg + cb) * MB + 4 * g;
@@ -1158,14 +1263,31 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
     B(234, 3, 1, 8, 16, 1, 4, 1)           \
     B(235, 3, 1, 8, 16, 2, 2, 1)           \
     B(236, 3, 1, 16, 32, 1, 4, 1)          \
+    B(237, 3, 1, 8, 16, 2, 2, 2)           \
+    B(238, 3, 1, 16, 16, 2, 2, 2)          \
+    B(239, 3, 1, 16, 16, 1, 4, 2)          \
+    B(290, 3, 1, 8, 16, 4, 1, 1)           \
+    B(291, 3, 1, 8, 16, 4, 1, 2)           \
+    B(292, 3, 1, 8, 32, 2, 2, 1)           \
+    B(293, 3, 1, 16, 32, 2, 2, 1)          \
     B(240, 3, 2, 12, 13, 2, 2, 1)          \
     B(241, 3, 2, 8, 16, 1, 4, 1)           \
     B(242, 3, 2, 8, 16, 2, 2, 1)           \
     B(243, 3, 2, 16, 16, 1, 4, 1)          \
+    B(244, 3, 2, 8, 16, 2, 2, 2)           \
+    B(245, 3, 2, 8, 8, 2, 2, 1)            \
+    B(246, 3, 2, 8, 16, 4, 1, 1)           \
+    B(247, 3, 2, 16, 16, 2, 2, 1)          \
+    B(248, 3, 2, 4, 16, 2, 2, 1)           \
     B(250, 2, 1, 12, 13, 2, 2, 1)          \
     B(251, 2, 1, 16, 16, 2, 2, 1)          \
     B(252, 2, 1, 16, 16, 1, 4, 1)          \
-    B(253, 2, 1, 8, 16, 2, 2, 1)
+    B(253, 2, 1, 8, 16, 2, 2, 1)           \
+    B(254, 2, 1, 8, 16, 2, 2, 2)           \
+    B(255, 2, 1, 8, 16, 4, 1, 1)           \
+    B(256, 2, 1, 8, 8, 2, 2, 1)            \
+    B(257, 2, 1, 4, 16, 2, 2, 1)           \
+    B(258, 2, 1, 8, 32, 2, 2, 1)
 
 // Producer/consumer tilings with the fused first layer (C_in = 1 -> KC, then this conv).
 #define UKBB_PCF_CONFIGS(Z)                          \
@@ -1188,10 +1310,22 @@ __host__ __device__ constexpr int conv_bf_lds_bytes(int ks, int s, int th, int t
 
 #define UKBB_BFIO_ENTRY(ID, KS, S, TH, TW, WM, WN, CB)                                          \
     {ID, KS, S, 32, TH, TW, 16, WM, WN, CB, conv_bf_lds_bytes(KS, S, TH, TW, WM, CB), 5,       \
-     "convBF16io_" #KS "x" #KS "s" #S "_t" #TH "x" #TW "_w" #WM "x" #WN "_cb" #CB},
+     "convBF16io_" #KS "x" #KS "s" #S "_t" #TH "x" #TW "_w" #WM "x" #WN "_cb" #CB, 0},
+// F(id, TH, TW, WN-by-4 tiling, FUSE): 3x3 stride 1, one 32-row Cout block (the 16-channel layers of level 0)
+#define UKBB_BFIOF_CONFIGS(F)              \
+    F(294, 16, 16, 1)                      \
+    F(295, 16, 32, 1)                      \
+    F(296, 8, 32, 1)                       \
+    F(297, 16, 16, 2)                      \
+    F(298, 16, 32, 2)                      \
+    F(299, 8, 32, 2)
+#define UKBB_BFIOF_ENTRY(ID, TH, TW, FUSE)                                                      \
+    {ID, 3, 1, 32, TH, TW, 16, 1, 4, 1,                                                         \
+     conv_bf_lds_bytes(3, 1, TH, TW, 1, 1) + ((FUSE) == 1 ? 4 * ((TH) + 4) * ((TW) + 4) : 0), 5,   /* + raw tile of the fused first layer */ \
+     (FUSE) == 1 ? "convBF16io_first+3x3s1_t" #TH "x" #TW "_w1x4_cb1" : "convBF16io_3x3s1+logits_t" #TH "x" #TW "_w1x4_cb1", FUSE},
 
 static const ConvConfig g_cfgs[] = {UKBB_CONV_CONFIGS(UKBB_CFG_ENTRY) UKBB_PC_CONFIGS(UKBB_PC_ENTRY)
-                                    UKBB_PCF_CONFIGS(UKBB_PCF_ENTRY) UKBB_BF_CONFIGS(UKBB_BF_ENTRY) UKBB_BFIO_CONFIGS(UKBB_BFIO_ENTRY)
+                                    UKBB_PCF_CONFIGS(UKBB_PCF_ENTRY) UKBB_BF_CONFIGS(UKBB_BF_ENTRY) UKBB_BFIO_CONFIGS(UKBB_BFIO_ENTRY) UKBB_BFIOF_CONFIGS(UKBB_BFIOF_ENTRY)
                                     // Winograd F(2x2,3x3): region 4x8 tiles (8x16 px), 64 Cout per item, KC 16
                                     {300, 3, 1, 16, 8, 16, 16, 4, 1, 1, 112640, 4, "winogradF2x2_3x3_t8x16_kc16_cout64"},
                                     {301, 3, 1, 16, 8, 16, 16, 2, 1, 1, 112640, 4, "winogradF2x2_3x3_t8x16_kc16_cout32"},
@@ -1329,6 +1463,19 @@ hipError_t launch_conv(int cfg_id, const ConvArgs &a_in, hipStream_t s) {
         break;                                                                                  \
     }
         UKBB_BFIO_CONFIGS(UKBB_BFIO_CASE)
+#define UKBB_BFIOF_CASE(ID, TH, TW, FUSE)                                                       \
+    case ID: {                                                                                  \
+        if ((FUSE) == 1 ? (!a.first_w || !a.first_b) : (!a.lg_w || !a.lg_b || a.lg_ncls < 2 || a.lg_ncls > 4)) return hipErrorInvalidValue; \
+        auto k = conv_mfma_kernel<3, 1, 32, TH, TW, 16, 1, 4, 1, true, true, FUSE>;             \
+        static OncePerDevice lds_ok;                                                            \
+        {                                                                                       \
+            hipError_t e = allow_dynamic_lds(lds_ok, reinterpret_cast<const void *>(k), c->lds_bytes); \
+            if (e != hipSuccess) return e;                                                      \
+        }                                                                                       \
+        hipLaunchKernelGGL(k, grid, dim3(256), c->lds_bytes, s, a);                             \
+        break;                                                                                  \
+    }
+        UKBB_BFIOF_CONFIGS(UKBB_BFIOF_CASE)
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -1397,6 +1544,36 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const FirstArgs a) {
     for (int i = threadIdx.x; i < COUT; i += 256) wl[9 * COUT + i] = a.bias[i];
     __syncthreads();
     const size_t total = (size_t)a.N * a.H * a.W;
+    if constexpr (OBF) {
+        // bf16 output: one thread = 8 channels of one pixel = one 16-byte store, consecutive lanes -> consecutive 16 bytes
+        // (a thread per pixel would store 2 x 16 bytes at a 32-byte lane stride: half-used write bursts, 2.6 TB/s measured)
+        for (size_t q2 = (size_t)blockIdx.x * 256 + threadIdx.x; q2 < 2 * total; q2 += (size_t)gridDim.x * 256) {
+            const size_t q = q2 >> 1;
+            const int c = (int)(q2 & 1) * 8;
+            const int x = (int)(q % a.W);
+            const int y = (int)((q / a.W) % a.H);
+            const float *img = a.in + (q - (size_t)y * a.W - x);
+            float v[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                v[t] = ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W) ? img[(size_t)yy * a.W + xx] : 0.f;
+            }
+            float rp[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) s = fmaf(v[t], wl[t * COUT + c + j], s);
+                rp[j] = fmaxf(s + wl[9 * COUT + c + j], 0.f);
+            }
+            uint4 pk;
+            pk.x = pack_bf16x2(rp[0], rp[1]); pk.y = pack_bf16x2(rp[2], rp[3]);
+            pk.z = pack_bf16x2(rp[4], rp[5]); pk.w = pack_bf16x2(rp[6], rp[7]);
+            *reinterpret_cast<uint4 *>(reinterpret_cast<unsigned short *>(a.out) + q * COUT + c) = pk;
+        }
+        return;
+    }
     for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (size_t)gridDim.x * 256) {
         const int x = (int)(q % a.W);
         const int y = (int)((q / a.W) % a.H);
@@ -1408,32 +1585,24 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const FirstArgs a) {
             v[t] = ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W) ? img[(size_t)yy * a.W + xx] : 0.f;
         }
         float *o = a.out + q * COUT;
-        unsigned short *ob = reinterpret_cast<unsigned short *>(a.out) + q * COUT;
 #pragma unroll
-        for (int c = 0; c < COUT; c += 8) {
-            float rp[8];
+        for (int c = 0; c < COUT; c += 4) {
+            float4 r;
+            float *rp = &r.x;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < 4; ++j) {
                 float s = 0.f;
 #pragma unroll
                 for (int t = 0; t < 9; ++t) s = fmaf(v[t], wl[t * COUT + c + j], s);
                 rp[j] = fmaxf(s + wl[9 * COUT + c + j], 0.f);
             }
-            if constexpr (OBF) {
-                uint4 pk;
-                pk.x = pack_bf16x2(rp[0], rp[1]); pk.y = pack_bf16x2(rp[2], rp[3]);
-                pk.z = pack_bf16x2(rp[4], rp[5]); pk.w = pack_bf16x2(rp[6], rp[7]);
-                *reinterpret_cast<uint4 *>(ob + c) = pk;
-            } else {
-                *reinterpret_cast<float4 *>(o + c) = float4{rp[0], rp[1], rp[2], rp[3]};
-                *reinterpret_cast<float4 *>(o + c + 4) = float4{rp[4], rp[5], rp[6], rp[7]};
-            }
+            *reinterpret_cast<float4 *>(o + c) = r;
         }
     }
 }
 
 hipError_t launch_first(const FirstArgs &a, hipStream_t s) {
-    const size_t total = (size_t)a.N * a.H * a.W;
+    const size_t total = (size_t)a.N * a.H * a.W * (a.out_bf16 ? 2 : 1);
     unsigned grid = (unsigned)((total + 255) / 256);
     if (grid > 256u * 16u) grid = 256u * 16u;
     if (a.Cout == 16 && a.out_bf16) hipLaunchKernelGGL((conv_first_kernel<16, true>), dim3(grid), dim3(256), 0, s, a);
