@@ -377,6 +377,33 @@ def test_unet_bf16_dice_vs_fp32():
     assert (b16['pred'] != f32['pred']).mean() < 0.02
 
 
+def test_unet_bf16_dice_at_the_bench_batch(parity_log):
+    """BASELINE config 5 at its stated size: N = 100 frames of 256 x 256 (deploy_network_ao.py:105-107 pads every aortic frame to
+    that), bf16 path (bf16 operands and bf16 activations in HBM, first layer and logits fused) against the fp32 path of the same
+    engine: per-class Dice (common/image_utils.py:171-175) >= 0.98 on classes 1, 2 over the batch and on every single frame
+    whose class is populated; the fp32 path itself is pinned to the oracles by the other tests of this file."""
+    from ukbb_cardiac_amd.arch import MODELS
+    from ukbb_cardiac_amd.engine import Engine
+    from ukbb_cardiac_amd.image_utils import np_categorical_dice
+    from ukbb_cardiac_amd.phantom import cine_phantom
+    from ukbb_cardiac_amd.weights import synthetic_params
+    arch = MODELS['UNet_ao']
+    img = ((cine_phantom(100, 256, 256, seed=5) - 0.3) / 0.25).astype(np.float32)
+    with Engine(arch, synthetic_params(arch, 1234)) as eng:
+        f32 = eng.run(img, want_prob=False)['pred']
+        eng.set_precision('bf16')
+        b16 = eng.run(img, want_prob=False)['pred']
+        again = eng.run(img, want_prob=False)['pred']
+    assert np.array_equal(b16, again)                                     # bit-deterministic
+    dice = {k: float(np_categorical_dice(b16, f32, k)) for k in (1, 2)}
+    worst = {k: min(float(np_categorical_dice(b16[i], f32[i], k)) for i in range(100) if (f32[i] == k).sum() > 500) for k in (1, 2)}
+    parity_log(model='UNet_ao', shape=[100, 256, 256], oracle='fp32 path of the same engine', dice_class1=dice[1], dice_class2=dice[2],
+               worst_frame_dice_class1=worst[1], worst_frame_dice_class2=worst[2], label_disagreement=float((b16 != f32).mean()))
+    assert dice[1] >= 0.98 and dice[2] >= 0.98, dice
+    assert worst[1] >= 0.97 and worst[2] >= 0.97, worst
+    assert len(np.unique(b16)) == 3
+
+
 # ---- UKBB_PREC_F32X3: fp32 results from three bf16 pieces per operand (FCN head), graded exactly like the fp32 path -----
 
 @pytest.fixture(scope='module')
@@ -529,3 +556,29 @@ def test_pred_is_the_lowest_index_argmax_of_the_float32_probabilities(name):
         by_logits = np.argmax(out['logits'], axis=-1)
         if expect_all_zero:
             assert not out['pred'].any() and by_logits.any()
+
+
+def test_small_batch_plan_is_arithmetic_neutral():
+    """a handle that only ever sees small batches (the reference's sess.run of one frame's 10 slices,
+    deploy_network.py:103-111) takes finer work items on the deep levels -- Winograd items of 32 instead of 64 output channels,
+    one Cout block per wave in the stride-2 convs -- so that more CUs work.  Those siblings compute every output with the same
+    arithmetic: the logits of slices 0..9 from a fresh N = 10 handle equal, bit for bit, those of the same slices inside the
+    N = 64 bench batch on another handle (whose plan uses the large-batch tilings)."""
+    from ukbb_cardiac_amd.arch import MODELS
+    from ukbb_cardiac_amd.engine import Engine
+    from ukbb_cardiac_amd.phantom import uniform_slices
+    from ukbb_cardiac_amd.weights import synthetic_params
+    arch = MODELS['FCN_sa']
+    params = synthetic_params(arch, 1234)
+    img = uniform_slices(64, 192, 208, seed=1)
+    with Engine(arch, params) as big:
+        ref = big.run(img, want_logits=True, want_prob=False)
+        big_cfgs = big.kernel_configs()
+        tail = big.run(img[:10], want_logits=True, want_prob=False)      # a large-batch handle keeps its plan for tail batches
+        assert big.kernel_configs() == big_cfgs
+    with Engine(arch, params) as small:
+        got = small.run(img[:10], want_logits=True, want_prob=False)
+        small_cfgs = small.kernel_configs()
+    assert small_cfgs != big_cfgs and 301 in small_cfgs and 141 in small_cfgs, (small_cfgs, big_cfgs)
+    assert np.array_equal(got['logits'], ref['logits'][:10]) and np.array_equal(got['pred'], ref['pred'][:10])
+    assert np.array_equal(tail['logits'], ref['logits'][:10])

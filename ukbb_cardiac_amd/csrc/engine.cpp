@@ -123,6 +123,9 @@ struct ukbb_fcn_handle {
     int precision = 0;                        // 0: fp32; 1: bf16 operands for the MFMA convs (fp32 accumulate); 2: fp32 from bf16 pieces (head)
     int plan_h = 0, plan_w = 0, cap_n = 0;
     bool plan_small = false;                  // plan built with the small-batch tilings
+    int max_n = 0;                            // largest batch this handle was asked for (reserve / forward): the small-batch plan is
+                                              // used only while that stays <= SMALL_BATCH, so a large-batch caller's tail batches do
+                                              // not flip the plan (a rebuild re-allocates the workspace) back and forth
     bool plan_bfio = false;                   // plan stores every activation between layers as bf16 (UKBB_PREC_BF16, U-Net)
     std::vector<Op> ops;
     int last_n = 0;
@@ -327,10 +330,33 @@ int choose_cfg_raw(const std::string &layer, int ks, int stride, int c0, int c1,
                    bool fused_first, int want_bf16);
 int find_cfg(int id, ConvConfig &out);
 
+// Small batches (N <= SMALL_BATCH, e.g. the reference's own sess.run of one frame's 10 slices, deploy_network.py:103-111): the
+// deep levels have fewer work items than the chip has CUs, and a CU streaming an item's weights alone pulls only ~25-50 GB/s
+// from L2, so those layers are bound by the number of CUs at work.  Swap the tiling for a FINER SIBLING THAT COMPUTES EVERY
+// OUTPUT WITH THE SAME ARITHMETIC -- same algorithm, MFMA shape, channels per stage and tile, only fewer output channels per
+// work item -- so results stay bit-identical whatever batch a slice is part of (tests: batch independence, slices of the
+// bench batch against single-slice runs).  The r01 small-batch table (other tiles / KC) stays opt-in for that reason.
+int finer_sibling(int id, int ks, int stride, int c0, int c1, int cout, int Ho, int Wo, int N) {
+    static const bool off = getenv("UKBB_NO_SMALL_BATCH_SIBLINGS") != nullptr;    // A/B knob
+    if (off || N > SMALL_BATCH) return id;
+    static const int sib[][2] = {{300, 301}, {302, 303},     // Winograd: 64 -> 32 output channels per item
+                                 {124, 141}};                // stride-2 producer/consumer, mb16 12x13 kc8: Cout blocks per wave 2 -> 1
+    ConvConfig c, f;
+    if (find_cfg(id, c)) return id;
+    for (const auto &p : sib) {
+        if (p[0] != id || find_cfg(p[1], f) || !cfg_valid(f, ks, stride, c0, c1, cout)) continue;
+        const long long tiles = (long long)((Ho + c.th - 1) / c.th) * ((Wo + c.tw - 1) / c.tw) * N;
+        const long long items = tiles * (cout / (c.pc == 4 ? 16 * c.wm : c.mb * c.cb * c.wm));
+        if (items <= 128) return p[1];                        // at most half the CUs at work: halve the item (r03: 160-210 items were faster left alone)
+    }
+    return id;
+}
+
 int choose_cfg(const std::string &layer, int ks, int stride, int c0, int c1, int cout, int Ho, int Wo, int N,
                bool fused_first = false, int want_bf16 = 0) {
     const int id = choose_cfg_raw(layer, ks, stride, c0, c1, cout, Ho, Wo, N, fused_first, want_bf16);
-    return override_cfg(layer) >= 0 ? id : wino_orient(id, Ho, Wo);
+    if (override_cfg(layer) >= 0) return id;
+    return finer_sibling(wino_orient(id, Ho, Wo), ks, stride, c0, c1, cout, Ho, Wo, N);
 }
 
 // bf16-storage tilings measured best per layer type of the aortic U-Net at N = 100 x 256 x 256 (tools/sweep_convs.py with
@@ -688,7 +714,7 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
             }
         }
     }
-    h->plan_h = H; h->plan_w = W; h->plan_small = small_batch_tilings() && n_hint <= SMALL_BATCH;
+    h->plan_h = H; h->plan_w = W; h->plan_small = n_hint <= SMALL_BATCH;
     h->plan_bfio = bf16_mode(h) == 2;
     // events
     for (auto e : h->ev) (void)hipEventDestroy(e);
@@ -721,9 +747,10 @@ int prepare(ukbb_fcn_handle *h, int n, int H, int W) {
     int rc = check_shape(n, H, W);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(h->device), UKBB_EDEVICE);
-    if (H != h->plan_h || W != h->plan_w || (small_batch_tilings() && n <= SMALL_BATCH) != h->plan_small) {
+    if (n > h->max_n) h->max_n = n;
+    if (H != h->plan_h || W != h->plan_w || (h->max_n <= SMALL_BATCH) != h->plan_small) {
         HIP_TRY(hipDeviceSynchronize(), UKBB_EDEVICE);
-        rc = build_plan(h, H, W, n);
+        rc = build_plan(h, H, W, h->max_n);
         if (rc) { h->plan_h = h->plan_w = 0; return rc; }
     }
     if (n > h->cap_n) {
