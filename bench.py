@@ -190,6 +190,57 @@ def inflight_probe(arch, params, x, n, steps):
             'note': 'same workload, two batches in flight on two HIP streams (two workspaces); not the headline'}
 
 
+def other_configs_probe(device):
+    """Reported beside the headline, never as it: BASELINE.json configs[4] (aortic U-Net, N = 100 x 256x256, fp32 and the bf16
+    MFMA path with per-class Dice against fp32, common/image_utils.py:171-175) and the reference's own call shape N = 10
+    (deploy_network.py:103-111) of the headline model -- each a few forwards, inputs resident in HBM."""
+    import numpy as np
+    import torch
+    from ukbb_cardiac_amd.arch import MODELS
+    from ukbb_cardiac_amd.engine import Engine
+    from ukbb_cardiac_amd.image_utils import np_categorical_dice
+    from ukbb_cardiac_amd.phantom import cine_phantom, uniform_slices
+    from ukbb_cardiac_amd.weights import synthetic_params
+
+    def rate(eng, x, n, h, w, pred, k=10):
+        for _ in range(3):
+            eng.run_device(x.data_ptr(), n, h, w, pred_ptr=pred.data_ptr())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            eng.run_device(x.data_ptr(), n, h, w, pred_ptr=pred.data_ptr())
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / k
+    out = {}
+    arch = MODELS['UNet_ao']
+    n = 100
+    img = ((cine_phantom(n, 256, 256, seed=5) - 0.3) / 0.25).astype(np.float32)
+    x = torch.from_numpy(img).to(device)
+    pred = torch.empty((n, 256, 256), dtype=torch.int32, device=device)
+    with Engine(arch, synthetic_params(arch, 1234), device=device.index) as eng:
+        t32 = rate(eng, x, n, 256, 256, pred)
+        p32 = pred.cpu().numpy().copy()
+        eng.set_precision('bf16')
+        t16 = rate(eng, x, n, 256, 256, pred)
+        p16 = pred.cpu().numpy()
+        launches = len(eng.kernel_names())
+    out['config5_aortic_unet'] = {
+        'workload': 'UNet_ao (network_ao.py:18-64), N = 100 x 256x256 resident in HBM, int32 labels out',
+        'fp32': {'value': round(n / t32, 1), 'unit': 'slices/s', 'ms_per_step': round(t32 * 1e3, 4)},
+        'bf16': {'value': round(n / t16, 1), 'unit': 'slices/s', 'ms_per_step': round(t16 * 1e3, 4), 'dtype': 'bf16 MFMA operands, fp32 accumulation, '
+                 'bf16 activations in HBM', 'kernel_launches': launches,
+                 'dice_vs_fp32': {'class1': round(float(np_categorical_dice(p16, p32, 1)), 4), 'class2': round(float(np_categorical_dice(p16, p32, 2)), 4)},
+                 'label_disagreement': round(float((p16 != p32).mean()), 5)}}
+    arch = MODELS['FCN_sa']
+    x10 = torch.from_numpy(uniform_slices(10, H, W, seed=1)).to(device)
+    pred10 = torch.empty((10, H, W), dtype=torch.int32, device=device)
+    with Engine(arch, synthetic_params(arch, 1234), device=device.index) as eng:
+        t10 = rate(eng, x10, 10, H, W, pred10, k=30)
+    out['reference_call_shape_n10'] = {'workload': 'FCN_sa, N = 10 x 192x208 (one sess.run of the reference), own handle', 'value': round(10 / t10, 1),
+                                       'unit': 'slices/s', 'ms_per_step': round(t10 * 1e3, 4)}
+    return out
+
+
 def f32x3_probe(eng, x, n, steps, head_index):
     """Reported beside the headline, never as it: the same K steps with UKBB_PREC_F32X3 (include/ukbb_fcn.h): the FCN head's
     out0 / out1 products from three bf16 pieces per fp32 operand on the dense matrix cores, fp32 accumulation.  Same logits error
@@ -233,6 +284,7 @@ def main():
                          'profiles/r*_pmc_traffic.json whose kernel_source_sha matches the sources in this tree')
     ap.add_argument('--no-kernel-events', action='store_true',
                     help='do not bracket kernels with HIP events in the timed region (roofline becomes null)')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the config-5 (aortic U-Net fp32 / bf16) and N = 10 probes')
     ap.add_argument('--inflight-probe', action='store_true',
                     help='after the timed region also measure the same steps with two batches in flight on two streams '
                          '(extra field two_batches_in_flight; off by default so that a rocprofv3 trace of the default command '
@@ -396,6 +448,11 @@ def main():
             out['two_batches_in_flight'] = inflight_probe(arch, params, x, n, args.steps)
         if world == 1 and not args.no_f32x3_probe:
             out['f32x3'] = f32x3_probe(eng, x, n, args.steps, eng.kernel_names().index('head'))
+        if world == 1 and not args.no_other_configs:
+            try:
+                out['other_configs'] = other_configs_probe(dev)
+            except Exception as e:                                    # never lose the headline line to a side probe
+                out['other_configs'] = {'error': repr(e)[-300:]}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)

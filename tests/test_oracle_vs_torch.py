@@ -7,7 +7,7 @@ import torch
 from oracle import fcn_oracle as O
 from ukbb_cardiac_amd.arch import MODELS
 from ukbb_cardiac_amd.weights import synthetic_params
-import torch_ref as T
+from oracle import torch_oracle as T
 from ukbb_cardiac_amd.phantom import cine_phantom
 
 
@@ -100,7 +100,7 @@ def test_unet_graph_vs_torch():
 
 def test_unet_lstm_graph_vs_torch():
     """BiConvLSTM head: numpy restatement vs an independent torch formulation."""
-    from tests.torch_ref import unet_lstm_forward
+    from oracle.torch_oracle import unet_lstm_forward
     arch = MODELS['UNet-LSTM_ao']
     params = synthetic_params(arch, 1234)
     x = np.random.default_rng(8).standard_normal((2, 9, 32, 16, 1)).astype(np.float32)

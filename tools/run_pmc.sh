@@ -7,7 +7,7 @@ OUT=${1:-gpurun_out/pmc}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p "$ROOT/$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--no-cpu-baseline --no-f32x3-probe --no-kernel-events --steps 3 --warmup 1"
+ARGS="--no-cpu-baseline --no-f32x3-probe --no-other-configs --no-kernel-events --steps 3 --warmup 1"
 i=0
 for set in \
   "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \

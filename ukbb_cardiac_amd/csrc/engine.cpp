@@ -137,6 +137,9 @@ struct ukbb_fcn_handle {
     DevBuf lstm_gates, lstm_h, lstm_c, lstm_probw, lstm_aux;   // lstm_aux: int maps / orders / double weights (raw bytes)
     long long lstm_aux_key = -1;              // which tables lstm_aux holds (shape-keyed, uploaded once per shape)
 
+    // image-slice streams (experiment UKBB_SPLIT, run_plan): consecutive conv ops run as S independent image ranges on S streams
+    std::vector<hipStream_t> split_streams;
+    std::vector<hipEvent_t> split_ev;         // [0] fork, [1..S] joins
     // side stream for kernels that only feed the head (sqg_l): fork after level l, join before the head
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> ev_fork, ev_join;
@@ -154,6 +157,8 @@ struct ukbb_fcn_handle {
         for (auto e : ev) (void)hipEventDestroy(e);
         for (auto e : ev_fork) (void)hipEventDestroy(e);
         for (auto e : ev_join) (void)hipEventDestroy(e);
+        for (auto e : split_ev) (void)hipEventDestroy(e);
+        for (auto st : split_streams) (void)hipStreamDestroy(st);
         if (side) (void)hipStreamDestroy(side);
     }
 };
@@ -789,9 +794,40 @@ int run_plan(ukbb_fcn_handle *h, const float *image, int n, float *logits, float
     }
     hipStream_t s_main = s;
     bool forked = false;
+    // Experiment (r03): UKBB_SPLIT="conv3_0:conv4_2:4" runs the conv ops from..to as 4 independent image
+    // ranges on 4 streams (halo dependencies never cross images), so that the fixed cost of each of the dependent launches of one
+    // range (dispatch, L2 write-back, first-load latency, tail) is filled by the other ranges' kernels -- without any
+    // inter-workgroup waiting inside a kernel (a persistent chain with spin barriers can deadlock as soon as two such
+    // kernels share the GPU: two handles on two streams, two worker processes per GPU).  Result: profiles/r03_notes.md.
+    static const struct Split { std::string from, to; int S = 0; } split = [] {
+        Split sp; const char *e = getenv("UKBB_SPLIT");
+        if (e) { std::string v(e); size_t a1 = v.find(':'), a2 = v.rfind(':');
+                 if (a1 != std::string::npos && a2 > a1) { sp.from = v.substr(0, a1); sp.to = v.substr(a1 + 1, a2 - a1 - 1); sp.S = atoi(v.c_str() + a2 + 1); } }
+        return sp; }();
+    int sp_from = -1, sp_to = -1;
+    if (split.S > 1 && n >= 2 * split.S) {
+        for (size_t i = 0; i < h->ops.size(); ++i) {
+            if (h->ops[i].name == split.from) sp_from = (int)i;
+            if (h->ops[i].name == split.to) sp_to = (int)i;
+        }
+        for (int i = sp_from; sp_from >= 0 && i <= sp_to; ++i)
+            if (h->ops[i].kind != OP_CONV || h->ops[i].fused_first || h->ops[i].fused_logits || h->ops[i].on_side) sp_from = -1;
+        if (sp_from < 0 || sp_to < sp_from) sp_from = sp_to = -1;
+        if (sp_from >= 0 && (int)h->split_streams.size() < split.S) {
+            h->split_streams.resize(split.S, nullptr);
+            for (auto &st : h->split_streams) if (!st) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), UKBB_EDEVICE);
+            h->split_ev.resize(split.S + 1, nullptr);
+            for (auto &ev : h->split_ev) if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming), UKBB_EDEVICE);
+        }
+    }
     for (size_t i = 0; i < h->ops.size(); ++i) {
         const Op &op = h->ops[i];
         s = s_main;
+        const bool in_split = sp_from >= 0 && (int)i >= sp_from && (int)i <= sp_to;
+        if (in_split && (int)i == sp_from) {
+            HIP_TRY(hipEventRecord(h->split_ev[0], s_main), UKBB_EDEVICE);
+            for (int k = 0; k < split.S; ++k) HIP_TRY(hipStreamWaitEvent(h->split_streams[k], h->split_ev[0], 0), UKBB_EDEVICE);
+        }
         if (op.on_side) {                              // fork: side stream waits for everything issued so far
             if (!h->side) {
                 HIP_TRY(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking), UKBB_EDEVICE);
@@ -840,6 +876,23 @@ int run_plan(ukbb_fcn_handle *h, const float *image, int n, float *logits, float
                 ca.pad_y = op.pad_y; ca.pad_x = op.pad_x;
                 ca.tiles_y = (op.Ho + c.th - 1) / c.th; ca.tiles_x = (op.Wo + c.tw - 1) / c.tw;
                 ca.relu = L.relu ? 1 : 0;
+                if (in_split) {
+                    const size_t in_pi = h->act_per_image[op.in0], out_pi = h->act_per_image[op.out];
+                    const size_t in1_pi = op.in1 >= 0 ? h->act_per_image[op.in1] : 0;
+                    for (int k = 0; k < split.S && e == hipSuccess; ++k) {
+                        const int n0 = (int)((long long)k * n / split.S), n1 = (int)((long long)(k + 1) * n / split.S);
+                        ConvArgs cs = ca;
+                        cs.N = n1 - n0; cs.in0 = ca.in0 + n0 * in_pi; cs.out = ca.out + n0 * out_pi;
+                        if (ca.in1) cs.in1 = ca.in1 + n0 * in1_pi;
+                        e = launch_conv(op.cfg, cs, h->split_streams[k]);
+                    }
+                    if (e == hipSuccess && (int)i == sp_to)
+                        for (int k = 0; k < split.S; ++k) {
+                            HIP_TRY(hipEventRecord(h->split_ev[k + 1], h->split_streams[k]), UKBB_EDEVICE);
+                            HIP_TRY(hipStreamWaitEvent(s_main, h->split_ev[k + 1], 0), UKBB_EDEVICE);
+                        }
+                    break;
+                }
                 e = launch_conv(op.cfg, ca, s);
                 break;
             }

@@ -47,6 +47,9 @@ def define_flags():
                       'write finished segmentations behind it; 0 = strictly sequential subjects as in the reference.')
     fs.DEFINE_boolean('device_preproc', True, 'Sequences: z-score, padding, transposes and the argmax on the GPU '
                       '(bit-identical to the host path; --nodevice_preproc restores it).')
+    fs.DEFINE_enum('precision', 'fp32', ['fp32', 'bf16'], 'Arithmetic of the U-Net convolutions: fp32 MFMA (default) or bf16 MFMA operands with fp32 '
+                   'accumulation (UKBB_PREC_BF16, include/ukbb_fcn.h; --model UNet: bf16 activations in HBM too, 2.8x the fp32 rate, '
+                   'Dice 0.99 against fp32; BASELINE config 5).')
     fs.DEFINE_enum('label_gzip', 'small', list(nifti.LABEL_GZIP_MODES), 'Deflate of the label volumes: small = run-length tokens + dynamic Huffman '
                    '(size of zlib level 1 or below), fast = fixed Huffman (larger files), zlib = as nibabel.  Same inflated bytes.')
     fs.DEFINE_string('output_csv', '', 'Sequence mode: also write the spreadsheet of aortic/eval_aortic_area.py (same columns and arithmetic) from '
@@ -230,6 +233,8 @@ def main(argv=None):
         is_lstm = sess.engine.arch.kind == KIND_UNET_LSTM
         if is_lstm != (FLAGS.model == 'UNet-LSTM'):
             sys.exit('Error: --model %s but %s holds a %s model.' % (FLAGS.model, FLAGS.model_path, sess.engine.arch.name))
+        if FLAGS.precision != 'fp32':
+            sess.engine.set_precision(FLAGS.precision)
         print('Start evaluating on the test set ...')
 
         def forward(batch):
