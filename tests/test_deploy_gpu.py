@@ -219,3 +219,49 @@ def test_precision_flag_f32x3_writes_the_fp32_labels(tmp_path):
     assert seg['fp32'].shape == vol.shape and seg['fp32'].dtype == np.float64
     assert int((seg['fp32'] != seg['f32x3']).sum()) <= 3
     assert len(np.unique(seg['f32x3'])) > 1
+
+
+# ---- r03: aortic script with --output_csv and --precision bf16 on the engine -----------------------------------------------
+def test_aortic_unet_sequence_csv_and_bf16_precision(tmp_path):
+    """deploy_network_ao.py --model UNet in sequence mode on the device path (z-score, pack, forward, unpack on the GPU):
+    --output_csv equals aortic/eval_aortic_area.py:60-95 applied to the written seg_ao.nii.gz (as pandas writes it), and
+    --precision bf16 (BASELINE config 5 through the drop-in script) gives label volumes with Dice >= 0.98 against the fp32 run."""
+    import shutil
+    from ukbb_cardiac_amd import deploy_network_ao, measures, nifti
+    from ukbb_cardiac_amd.image_utils import np_categorical_dice
+    from ukbb_cardiac_amd.phantom import cine_phantom
+    from test_host_pipeline import _pandas_csv
+    arch, params, flat, mp = _model(tmp_path, 'UNet_ao')
+    src = tmp_path / 'src'
+    names = ['2001', '2002']
+    aff = np.diag([1.6, 1.6, 6.0, 1.0])
+    pixdim = np.array([1, 1.6, 1.6, 6.0, 0.01, 0, 0, 0], np.float32)
+    for i, nm in enumerate(names):
+        (src / nm).mkdir(parents=True)
+        T = 12 + i
+        cine = np.round(cine_phantom(T, 200, 180, seed=70 + i)[..., 0].transpose(1, 2, 0)[:, :, None, :] * 1000.0).astype(np.float32)
+        nifti.save(cine, str(src / nm / 'ao.nii.gz'), aff, pixdim)
+    seg = {}
+    for prec in ('fp32', 'bf16'):
+        work = tmp_path / prec
+        shutil.copytree(str(src), str(work))
+        csv = str(tmp_path / (prec + '.csv'))
+        deploy_network_ao.main(['--seq_name', 'ao', '--data_dir', str(work), '--model_path', mp, '--model', 'UNet', '--precision', prec,
+                                '--output_csv', csv])
+        want = []
+        for nm in names:
+            hdr = nifti.load_header(str(work / nm / 'ao.nii.gz'))
+            dx, dy = hdr['pixdim'][1:3]
+            s = nifti.load(str(work / nm / 'seg_ao.nii.gz')).get_data()
+            assert s.dtype == np.int32 and s.shape[:3] == (200, 180, 1)
+            line = []
+            for l in (1, 2):
+                A = np.sum(s == l, axis=(0, 1, 2)) * (dx * dy)
+                line += [A.max(), A.min(), float('nan')]
+            want.append(line)
+            seg[(prec, nm)] = s
+        assert open(csv).read() == _pandas_csv(str(tmp_path / 'pd.csv'), want, names, measures.AO_COLUMNS)
+    for nm in names:
+        assert len(np.unique(seg[('fp32', nm)])) == 3
+        for k in (1, 2):
+            assert np_categorical_dice(seg[('bf16', nm)], seg[('fp32', nm)], k) >= 0.98

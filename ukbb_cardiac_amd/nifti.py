@@ -62,8 +62,10 @@ class _GzWriter:
     def __exit__(self, *exc):
         try:
             self._gz.close()
-        finally:
-            self._raw.__exit__(*exc)
+        except BaseException as e:                          # a failing flush must not rename a truncated file into place
+            self._raw.__exit__(type(e), e, e.__traceback__)
+            raise
+        self._raw.__exit__(*exc)
 
 
 def _tmp_name(path):
