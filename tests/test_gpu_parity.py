@@ -582,3 +582,28 @@ def test_small_batch_plan_is_arithmetic_neutral():
     assert small_cfgs != big_cfgs and 301 in small_cfgs and 141 in small_cfgs, (small_cfgs, big_cfgs)
     assert np.array_equal(got['logits'], ref['logits'][:10]) and np.array_equal(got['pred'], ref['pred'][:10])
     assert np.array_equal(tail['logits'], ref['logits'][:10])
+
+
+@pytest.mark.parametrize('shape', [(1, 16, 16), (2, 48, 400), (3, 272, 304), (5, 64, 16), (17, 32, 48), (2, 512, 512)])
+def test_unet_bf16_at_unusual_sizes(shape):
+    """The bf16-storage plan away from the tuned 256 x 256: maps smaller than a tile, tiles that do not divide the map, one
+    16-pixel column, batches on both sides of the small-batch threshold -- logits within 5 % of the fp32 path's scale (bf16
+    rounding of every activation, as at 256 x 256), no NaN, and the fused first layer / logits in use."""
+    from ukbb_cardiac_amd.arch import MODELS
+    from ukbb_cardiac_amd.engine import Engine
+    from ukbb_cardiac_amd.phantom import cine_phantom
+    from ukbb_cardiac_amd.weights import synthetic_params
+    arch = MODELS['UNet_ao']
+    n, h, w = shape
+    img = ((cine_phantom(n, h, w, seed=h + w) - 0.3) / 0.25).astype(np.float32)
+    with Engine(arch, synthetic_params(arch, 1234)) as eng:
+        f32 = eng.run(img, want_logits=True)
+        eng.set_precision('bf16')
+        b16 = eng.run(img, want_logits=True)
+        names = eng.kernel_names()
+    assert names[0] == 'conv0_0+conv0_1' and names[-1] == 'up0_1+logits' and len(names) == 21
+    assert np.isfinite(b16['logits']).all()
+    rel = np.abs(b16['logits'] - f32['logits']).max() / np.abs(f32['logits']).max()
+    assert rel < 5e-2, rel
+    assert (b16['pred'] != f32['pred']).mean() < 0.05
+    assert np.array_equal(np.argmax(b16['prob'], -1), b16['pred'])

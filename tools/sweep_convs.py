@@ -19,7 +19,9 @@ if __name__ == '__main__':
         layer, cfgs = spec.split(':')
         row = []
         for cfg in cfgs.split(','):
-            os.environ['UKBB_CONV_CFG'] = '%s:%s' % (layer, cfg)
+            parts = layer.split('+')                                   # plan names of fused launches: conv0_0+conv0_1, up0_1+logits
+            ov = parts[1] if parts[0] == 'conv0_0' and len(parts) > 1 else parts[0]
+            os.environ['UKBB_CONV_CFG'] = '%s:%s' % (ov, cfg)
             eng = Engine(arch, params)
             if os.environ.get('PREC'):
                 eng.set_precision(os.environ['PREC'])

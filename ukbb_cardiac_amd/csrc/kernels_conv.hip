@@ -245,15 +245,27 @@ __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM,
     // consecutive channels of its pixel, which are rounded to bf16 once -- exactly what the stand-alone first-layer kernel would
     // have stored -- and written into the halo tile.  conv0_0's output (420 MB per 100 slices, written + re-read) never exists.
     constexpr bool fusedf = FUSE == 1;
+    // first stage requested before anything else: in the fused form the packed weights travel while the raw tile is fetched and
+    // the first layer is evaluated
+    if constexpr (fusedf) UKBB_PREFETCH_W(0) else UKBB_PREFETCH(0)
     if constexpr (fusedf) {
         {
             constexpr int RH = IH + 2, RW = IW + 2, RP = RH * RW, NBLK = (HP + 15) / 16;
             float *raw = ws + NCBL * SLAB;
             const float *img = a.in0 + (size_t)n * a.H * a.W;
-            for (int i = tid; i < RP; i += 256) {
+            constexpr int NRAW = (RP + 255) / 256;
+            float rv[NRAW];
+#pragma unroll
+            for (int k = 0; k < NRAW; ++k) {                   // all loads in flight at once (clamped address, select afterwards)
+                const int i = tid + 256 * k;
                 const int ry = i / RW, rx = i - ry * RW, gy = iy0 - 1 + ry, gx = ix0 - 1 + rx;
-                raw[i] = ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) ? img[(size_t)gy * a.W + gx] : 0.f;
+                const bool ok = i < RP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+                const float v = img[ok ? (size_t)gy * a.W + gx : 0];
+                rv[k] = ok ? v : 0.f;
             }
+#pragma unroll
+            for (int k = 0; k < NRAW; ++k)
+                if (tid + 256 * k < RP) raw[tid + 256 * k] = rv[k];
             const int pj = lane & 15, pg = lane >> 4;
             float wA[3]; int toff[3];
 #pragma unroll
@@ -282,7 +294,6 @@ __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM,
         }
     }
 
-    if constexpr (fusedf) UKBB_PREFETCH_W(0) else UKBB_PREFETCH(0)
     for (int ch = 0; ch < nchunk; ++ch) {
         if (ch > 0) __syncthreads();                    // all waves done reading the previous chunk
         // ---- registers -> LDS (straight 16-byte copies) ----
