@@ -705,3 +705,21 @@ def test_aortic_output_csv_equals_the_evaluation_script_formulas(tmp_path):
             line += [A.max(), A.min(), (A.max() - A.min()) / (A.min() * pp[n]) * 1e3]
         want.append(line)
     assert open(out).read() == _pandas_csv(str(tmp_path / 'pd.csv'), want, names, measures.AO_COLUMNS)
+
+
+def test_label_gzip_small_never_loses_to_zlib_on_noise(tmp_path):
+    """Noise-like label volumes (runs of 1-2 voxels, not a segmentation) are where zlib's cross-row matches beat run-length
+    tokens: 'small' then keeps the zlib level-1 stream, so its files are never larger than nibabel's, and inflate identically."""
+    import gzip
+    from ukbb_cardiac_amd import nifti
+    lab = np.random.default_rng(5).integers(0, 4, size=(96, 104, 5, 8)).astype(np.uint8)
+    sizes, raws = {}, {}
+    try:
+        for mode in ('small', 'zlib'):
+            nifti.set_label_gzip(mode)
+            p = str(tmp_path / (mode + '.nii.gz'))
+            nifti.save(lab, p, np.eye(4), as_dtype=np.float64)
+            sizes[mode], raws[mode] = os.path.getsize(p), gzip.open(p, 'rb').read()
+    finally:
+        nifti.set_label_gzip('small')
+    assert raws['small'] == raws['zlib'] and sizes['small'] <= sizes['zlib'] + 16, sizes

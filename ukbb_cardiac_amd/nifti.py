@@ -350,6 +350,7 @@ LABEL_FAST_PATH = True     # tests switch it off to compare with the zlib path
 #   'zlib'             zlib level 1 over the converted volume, as nibabel writes it
 LABEL_GZIP_MODE = 'small'
 LABEL_GZIP_MODES = ('small', 'fast', 'zlib')
+NOISE_FRACTION = 0.06      # 'small': above this compressed / raw ratio (segmentations: 0.01-0.02) zlib level 1 is tried as well
 
 
 def set_label_gzip(mode):
@@ -392,8 +393,22 @@ def _save_labels_gz(lab, datatype_code, prefix, path):
         out = np.empty(cap, np.uint8)
         got = gz(flat.ctypes.data, n, datatype_code, prefix, len(prefix), out.ctypes.data, cap, mode)
         if got >= 0:
+            blob = memoryview(out)[:got]
+            itemsize = np.dtype(_DTYPES[datatype_code]).itemsize
+            if mode == _labelgz.DYNAMIC and got > NOISE_FRACTION * (len(prefix) + n * itemsize):
+                # noise-like labels (runs of 1-2 voxels): zlib's cross-row matches can beat run-length tokens there; such a
+                # volume is not a segmentation, but 'small' keeps its promise (<= zlib level 1) by taking the smaller stream
+                z = zlib.compressobj(GZIP_LEVEL, zlib.DEFLATED, 31)
+                le = np.dtype('<' + _DTYPES[datatype_code])
+                parts = [z.compress(prefix)]
+                for i in range(0, n, 1 << 20):
+                    parts.append(z.compress(flat[i:i + (1 << 20)].astype(le).tobytes()))
+                parts.append(z.flush())
+                zb = b''.join(parts)
+                if len(zb) < got:
+                    blob = zb
             with _AtomicFile(path) as f:
-                f.write(memoryview(out)[:got])
+                f.write(blob)
             return True
         if got != -4:                                           # UKBB_ENOMEM: retry once with the guaranteed bound
             raise RuntimeError('ukbb_fcn_gzip_labels_mode failed (%d)' % got)
