@@ -88,10 +88,14 @@ ukbb_fcn_handle *ukbb_fcn_create(const ukbb_fcn_arch *arch, const float *weights
 void ukbb_fcn_destroy(ukbb_fcn_handle *h);
 
 /* Arithmetic of the MFMA convolutions (BASELINE config 5).  UKBB_PREC_FP32 (default): f32 inputs,
- * exact f32 MFMA.  UKBB_PREC_BF16: activations and weights rounded to bf16 (RNE) at the MFMA inputs,
- * fp32 accumulation, fp32 activations in HBM; layers without a bf16 tiling (C_out = 16, the first
- * layer, the heads) stay fp32.  Not bit-compatible with the reference; meant to be judged by Dice
- * against the fp32 result (common/image_utils.py:171-175). */
+ * exact f32 MFMA.  UKBB_PREC_BF16: bf16 (RNE) MFMA operands, fp32 accumulation.  On a UKBB_KIND_UNET
+ * handle (round 3) every activation between layers is ALSO stored as bf16 in HBM (rounded once, after
+ * bias + ReLU), every layer runs on the bf16 matrix instructions (16-channel layers zero-padded to the
+ * 32-row shape), the first layer (fp32 arithmetic) is evaluated inside the second one's staging and
+ * the logits conv + softmax / argmax inside the last conv's epilogue: 21 launches, 2.9x the fp32 rate
+ * at N = 100 x 256x256.  On FCN / UNet-LSTM handles only the operands are bf16 (fp32 activations in
+ * HBM; layers without such a tiling stay fp32).  Not bit-compatible with the reference; meant to be
+ * judged by Dice against the fp32 result (common/image_utils.py:171-175): 0.993 / 0.992 measured. */
 #define UKBB_PREC_FP32 0
 #define UKBB_PREC_BF16 1
 /* UKBB_PREC_F32X3 (round 2, FCN head only so far): fp32 results from bf16 matrix instructions.  Every fp32 operand x is
