@@ -352,7 +352,7 @@ int finer_sibling(int id, int ks, int stride, int c0, int c1, int cout, int Ho, 
         if (p[0] != id || find_cfg(p[1], f) || !cfg_valid(f, ks, stride, c0, c1, cout)) continue;
         const long long tiles = (long long)((Ho + c.th - 1) / c.th) * ((Wo + c.tw - 1) / c.tw) * N;
         const long long items = tiles * (cout / (c.pc == 4 ? 16 * c.wm : c.mb * c.cb * c.wm));
-        if (items <= 128) return p[1];                        // at most half the CUs at work: halve the item (r03: 160-210 items were faster left alone)
+        if (items <= device_cu_count() / 2) return p[1];      // at most half the CUs (of the current device) at work: halve the item (r03 on 256 CUs: 160-210 items were faster left alone)
     }
     return id;
 }
