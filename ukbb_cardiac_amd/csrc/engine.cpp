@@ -527,7 +527,9 @@ int add_conv(ukbb_fcn_handle *h, const std::string &lname, int in0, int in1, int
         // bf16 storage: the fused variants of the level-0 tilings (ConvConfig::fuse), first fit in measured order
         op.cfg = -1;
         const int forced = override_cfg(lname);
-        for (int cand : {forced, fuse_bf == 1 ? 296 : 298, fuse_bf == 1 ? 294 : 297, fuse_bf == 1 ? 295 : 299}) {   // r03 sweep: 8x32 / 16x16 tiles for the fused first layer (154 vs 168 us), 16x32 for the fused logits
+        // fused logits: the persistent kernel first (kernels_bf16.hip: 104-110 vs 124 us), then the tile-per-workgroup tilings in
+        // measured order; fused first layer: tile-per-workgroup only (its persistent form was no faster, r03_notes.md)
+        for (int cand : {forced, fuse_bf == 1 ? 296 : 325, fuse_bf == 1 ? 294 : 324, fuse_bf == 1 ? 295 : 298, fuse_bf == 1 ? -1 : 297, fuse_bf == 1 ? -1 : 299}) {
             ConvConfig cc;
             if (cand >= 0 && find_cfg(cand, cc) == 0 && cfg_valid(cc, L.ks, stride, c0, c1, L.cout, false, 2, fuse_bf) &&
                 (cand == forced || tile_fit_ok(cc, op.Ho, op.Wo))) { op.cfg = cand; break; }

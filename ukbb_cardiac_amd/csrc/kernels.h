@@ -107,6 +107,10 @@ struct ConvConfig {
 
 int num_conv_configs();
 const ConvConfig &conv_config(int id);
+// the persistent last-layer tilings of the bf16 U-Net (ids 324-325) live in kernels_bf16.hip; the three functions above cover them
+int num_pk16_configs();
+const ConvConfig &pk16_config(int i);
+hipError_t launch_conv16_pk(int cfg_id, const ConvArgs &a, hipStream_t s);
 // cout handled by one workgroup = mb*cb*wm
 hipError_t launch_conv(int cfg_id, const ConvArgs &a, hipStream_t s);
 

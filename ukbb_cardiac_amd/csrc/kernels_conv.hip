@@ -1343,10 +1343,13 @@ static const ConvConfig g_cfgs[] = {UKBB_CONV_CONFIGS(UKBB_CFG_ENTRY) UKBB_PC_CO
                                     {302, 3, 1, 16, 16, 8, 16, 4, 1, 1, 112640, 4, "winogradF2x2_3x3_t16x8_kc16_cout64"},
                                     {303, 3, 1, 16, 16, 8, 16, 2, 1, 1, 112640, 4, "winogradF2x2_3x3_t16x8_kc16_cout32"}};
 
-int num_conv_configs() { return (int)(sizeof(g_cfgs) / sizeof(g_cfgs[0])); }
-const ConvConfig &conv_config(int i) { return g_cfgs[i]; }
+static constexpr int N_BASE_CFGS = (int)(sizeof(g_cfgs) / sizeof(g_cfgs[0]));
+int num_conv_configs() { return N_BASE_CFGS + num_pk16_configs(); }
+const ConvConfig &conv_config(int i) { return i < N_BASE_CFGS ? g_cfgs[i] : pk16_config(i - N_BASE_CFGS); }
 
 hipError_t launch_conv(int cfg_id, const ConvArgs &a_in, hipStream_t s) {
+    for (int i = 0; i < num_pk16_configs(); ++i)
+        if (pk16_config(i).id == cfg_id) return launch_conv16_pk(cfg_id, a_in, s);
     ConvArgs a = a_in;
 #ifdef UKBB_DIAG
     { const char *e = getenv("UKBB_CONV_DIAG"); a.diag = e ? atoi(e) : 0; }
