@@ -723,3 +723,27 @@ def test_label_gzip_small_never_loses_to_zlib_on_noise(tmp_path):
     finally:
         nifti.set_label_gzip('small')
     assert raws['small'] == raws['zlib'] and sizes['small'] <= sizes['zlib'] + 16, sizes
+
+
+def test_label_gzip_clean_under_address_and_ub_sanitizers(tmp_path):
+    """csrc/label_gzip.cpp (bit writer, length-limited Huffman construction, run splitting, CRC shortcuts) built with
+    -fsanitize=address,undefined and driven through its corner-case tests in a child interpreter (GPU sanitizers are not
+    available on the pool; this is host code)."""
+    import shutil
+    import subprocess
+    import sys
+    if not shutil.which('g++'):
+        pytest.skip('no g++')
+    asan = subprocess.run(['gcc', '-print-file-name=libasan.so'], stdout=subprocess.PIPE, text=True).stdout.strip()
+    ubsan = subprocess.run(['gcc', '-print-file-name=libubsan.so'], stdout=subprocess.PIPE, text=True).stdout.strip()
+    if not (os.path.isabs(asan) and os.path.exists(asan) and os.path.isabs(ubsan) and os.path.exists(ubsan)):
+        pytest.skip('sanitizer runtimes not installed')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = str(tmp_path / 'libukbb_labelgz_asan.so')
+    subprocess.check_call(['g++', '-O1', '-g', '-std=c++17', '-fPIC', '-shared', '-fsanitize=address,undefined', '-fno-sanitize-recover=undefined',
+                           '-fno-omit-frame-pointer', '-o', lib, os.path.join(root, 'ukbb_cardiac_amd', 'csrc', 'label_gzip.cpp')])
+    env = dict(os.environ, LD_PRELOAD=asan + ' ' + ubsan, ASAN_OPTIONS='detect_leaks=0', UKBB_LABELGZ_LIB=lib)
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-p', 'no:cacheprovider', '-k',
+                        'degenerate_histograms or run_lengths_and_crc or modes_inflate_identically or never_loses_to_zlib'],
+                       env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0 and ' passed' in r.stdout and 'ERROR: AddressSanitizer' not in r.stdout and 'runtime error' not in r.stdout, r.stdout[-3000:]
