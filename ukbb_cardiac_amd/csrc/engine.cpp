@@ -273,12 +273,13 @@ int override_cfg(const std::string &layer) {
 // reference's own per-frame call, deploy_network.py:103-111: there the persistent kernels have fewer work
 // items than CUs, and tilings with smaller channel groups / tiles win).  Other image sizes of the same layer
 // type reuse the entry (e.g. the long-axis models at 176x208).
-struct Tuned { int ks, stride, cin, cout, cfg, alt, alt2; };   // alt / alt2 (or -1): the first of the three whose tiles divide the map wins
+struct Tuned { int ks, stride, cin, cout, cfg, alt, alt2, alt3 = -1; };   // alt.. (or -1): the first of the four whose tiles divide the map wins
 const Tuned g_tuned_large[] = {
     {3, 1, 16, 16, 11, -1, -1}, {3, 2, 16, 32, 120, 123, -1},  {3, 1, 32, 32, 301, -1, -1},
-    {3, 2, 32, 64, 124, 123, 142},  {3, 1, 64, 64, 300, -1, -1},  {3, 2, 64, 128, 124, 123, 142},
-    {3, 1, 128, 128, 300, -1, -1},  {3, 2, 128, 256, 124, 123, 142}, {3, 1, 256, 256, 300, -1, -1},
-};      // r02: the stride-2 layers moved to the producer/consumer kernel once its loads ran two stages ahead (profiles/r02_notes.md);
+    {3, 2, 32, 64, 124, 123, 142, 145},  {3, 1, 64, 64, 300, -1, -1},  {3, 2, 64, 128, 124, 123, 142, 145},
+    {3, 1, 128, 128, 300, -1, -1},  {3, 2, 128, 256, 124, 123, 142, 145}, {3, 1, 256, 256, 300, -1, -1},
+};      // r03: 13x16 tiles (145) divide the 208x256 pyramid (52x64, 26x32, 13x16: conv2_0 118 -> 89 us, conv3_0 / conv4_0 -6 / -5);
+        // r02: the stride-2 layers moved to the producer/consumer kernel once its loads ran two stages ahead (profiles/r02_notes.md);
         // its straight-line producer needs tiles that divide the map: 12x13 tiles for the 192x208 pyramid, 8x16 (123) for the
         // power-of-two maps of the aortic U-Net (256x256: 148 / 143 / 133 / 136 us instead of 184 / 208 / 159 / 156 at N = 100),
         // 11x13 (142) for the long-axis models' 176x208 pyramid (88x104, 44x52, 22x26, 11x13)
@@ -418,9 +419,9 @@ int choose_cfg_raw(const std::string &layer, int ks, int stride, int c0, int c1,
         for (size_t j = 0; j < ntab; ++j) {
             const Tuned &t = tab[j];
             if (t.ks == ks && t.stride == stride && t.cin == c0 && t.cout == cout) {
-                const int cand[3] = {t.cfg, t.alt, t.alt2};
+                const int cand[4] = {t.cfg, t.alt, t.alt2, t.alt3};
                 int first_ok = -1;
-                for (int k = 0; k < 3; ++k) {
+                for (int k = 0; k < 4; ++k) {
                     ConvConfig cc;
                     if (cand[k] < 0 || find_cfg(cand[k], cc) || !cfg_valid(cc, ks, stride, c0, c1, cout) || !tile_fit_ok(cc, Ho, Wo)) continue;
                     if (Ho % cc.th == 0 && Wo % cc.tw == 0) return cand[k];      // tiles divide the map: straight-line producer applies

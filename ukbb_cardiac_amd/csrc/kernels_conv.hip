@@ -1251,7 +1251,8 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
     Y(141, 3, 2, 16, 12, 13, 8, 2, 2, 1)             \
     Y(142, 3, 2, 16, 11, 13, 8, 2, 2, 2)             \
     Y(143, 3, 2, 16, 8, 13, 16, 2, 2, 1)             \
-    Y(144, 3, 2, 16, 11, 13, 16, 2, 2, 1)
+    Y(144, 3, 2, 16, 11, 13, 16, 2, 2, 1)            \
+    Y(145, 3, 2, 16, 13, 16, 8, 2, 2, 2)
 
 // bf16-operand tilings (single-role kernel, MB = 32, KC = 16).  B(id, KS, STRIDE, TH, TW, WM, WN, CB)
 #define UKBB_BF_CONFIGS(B)                 \
