@@ -116,6 +116,7 @@ struct ukbb_fcn_handle {
     // activation workspace
     std::vector<std::unique_ptr<DevBuf>> act;
     std::vector<size_t> act_per_image;        // floats per image at the planned H,W
+    std::vector<int> act_ch;                  // channels of the map (0: not a channel map); bf16 plans store maps with C > 16 channel-blocked
     std::vector<std::string> act_name;
     DevBuf io_image, io_logits, io_prob, io_pred;   // staging for forward_host
 
@@ -312,8 +313,14 @@ bool cfg_valid(const ConvConfig &c, int ks, int stride, int c0, int c1, int cout
     if (c.ks != ks || c.stride != stride) return false;
     if (c.fuse != fuse) return false;
     if ((c.pc == 2) != fused_first) return false;
-    if ((c.pc == 3) != (bf16 == 1) || (c.pc == 5) != (bf16 == 2)) return false;
-    if (c.pc == 5) cout = round_up(cout, 32);         // 16-channel layers run zero-padded on the 32-row MFMA
+    if ((c.pc == 3) != (bf16 == 1) || (c.pc == 5 || c.pc == 6) != (bf16 == 2)) return false;
+    if (c.pc == 5 || c.pc == 6) cout = round_up(cout, 32);         // 16-channel layers run zero-padded on the 32-row MFMA
+    if (c.pc == 6) {                                  // weight-stationary: the Cout group's whole packed filter + the waves' rings in LDS
+        const int nch = (c0 + c1) / 16;
+        if (ks != 3 || stride != 1 || (c1 && c1 != c0) || (c0 + c1) % 16 || (nch != 1 && nch != 2 && nch != 4 && nch != 8) || (c1 && nch < 2)) return false;
+        if (cout % (32 * c.cb)) return false;
+        return ws_lds_bytes_for(c, c0 + c1) <= 160 * 1024;
+    }
     if (c.pc == 4) {                                  // Winograd: 3x3 s1, 64-channel output groups, single source ok
         static const bool off = getenv("UKBB_NO_WINOGRAD") != nullptr;
         return !off && !fused_first && ks == 3 && stride == 1 && cout % (16 * c.wm) == 0 && c0 % 16 == 0 && c1 % 16 == 0;
@@ -469,18 +476,19 @@ int find_cfg(int id, ConvConfig &out) {
 }
 
 // ---- plan ------------------------------------------------------------------------
-int new_act(ukbb_fcn_handle *h, const std::string &name, size_t per_image) {
+int new_act(ukbb_fcn_handle *h, const std::string &name, size_t per_image, int channels = 0) {
     h->act.emplace_back(new DevBuf);
     h->act_per_image.push_back(per_image);
     h->act_name.push_back(name);
+    h->act_ch.push_back(channels);
     return (int)h->act.size() - 1;
 }
 
 int ensure_packed(ukbb_fcn_handle *h, int layer, const ConvConfig &c, const float **wpk) {
     const HostLayer &L = h->layers[layer];
     char key[128];
-    const bool bfpk = c.pc == 3 || c.pc == 5;
-    const int coutp = c.pc == 5 ? round_up(L.cout, 32) : L.cout;
+    const bool bfpk = c.pc == 3 || c.pc == 5 || c.pc == 6;
+    const int coutp = (c.pc == 5 || c.pc == 6) ? round_up(L.cout, 32) : L.cout;
     snprintf(key, sizeof key, "%s/pk%s_mb%d_kc%d_g%d", L.name.c_str(), bfpk ? "bf16" : c.pc == 4 ? "wino" : "", c.mb, c.kc, c.wm * c.cb);
     if (!dev_ptr(h, key)) {
         std::vector<float> pk(c.pc == 4 ? (size_t)16 * L.cin * L.cout : (size_t)L.ks * L.ks * L.cin * coutp);
@@ -543,8 +551,8 @@ int add_conv(ukbb_fcn_handle *h, const std::string &lname, int in0, int in1, int
     find_cfg(op.cfg, c);
     int rc = ensure_packed(h, li, c, &op.wpk);
     if (rc) return rc;
-    op.bias = (c.pc == 5 && L.cout % 32) ? dev_ptr(h, lname + "/bias_pad") : dev_ptr(h, lname + "/bias");
-    op.out = new_act(h, lname, (size_t)op.Ho * op.Wo * L.cout);
+    op.bias = ((c.pc == 5 || c.pc == 6) && L.cout % 32) ? dev_ptr(h, lname + "/bias_pad") : dev_ptr(h, lname + "/bias");
+    op.out = new_act(h, lname, (size_t)op.Ho * op.Wo * L.cout, L.cout);
     op.macs_per_image = (double)op.Ho * op.Wo * L.ks * L.ks * L.cin * L.cout;
     if (c.pc == 4) op.mfma_macs_per_image = op.macs_per_image * (16.0 / 36.0);   // F(2x2,3x3): 16 products per 4 outputs
     else if (fused_first) op.mfma_macs_per_image = op.macs_per_image;              // conv0_0 itself runs on the vector ALU
@@ -581,7 +589,7 @@ int add_tconv(ukbb_fcn_handle *h, const std::string &lname, int in0, int H, int 
     }
     op.wpk = dev_ptr(h, key);
     op.bias = dev_ptr(h, lname + "/bias4");
-    op.out = new_act(h, lname, (size_t)4 * H * W * L.cout);
+    op.out = new_act(h, lname, (size_t)4 * H * W * L.cout, L.cout);
     op.macs_per_image = (double)H * W * 9 * L.cin * L.cout;
     h->ops.push_back(op);
     *out_buf = op.out;
@@ -590,7 +598,7 @@ int add_tconv(ukbb_fcn_handle *h, const std::string &lname, int in0, int H, int 
 
 int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
     h->ops.clear();
-    h->act.clear(); h->act_per_image.clear(); h->act_name.clear();
+    h->act.clear(); h->act_per_image.clear(); h->act_name.clear(); h->act_ch.clear();
     h->cap_n = 0;
     const ukbb_fcn_arch &a = h->arch;
     char nm[64];
@@ -610,7 +618,7 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
                 if (can_fuse) continue;              // evaluated inside conv0_1's producers
                 Op op; op.kind = OP_FIRST; op.name = nm; op.layer = h->layer_index.at(nm);
                 op.H = op.Ho = H; op.W = op.Wo = W;
-                op.out = new_act(h, nm, (size_t)H * W * a.n_filter[0]);
+                op.out = new_act(h, nm, (size_t)H * W * a.n_filter[0], a.n_filter[0]);
                 op.macs_per_image = (double)H * W * 9 * a.n_filter[0];
                 op.mfma_macs_per_image = 0;          // vector ALU kernel
                 h->ops.push_back(op);
@@ -871,7 +879,7 @@ int run_plan(ukbb_fcn_handle *h, const float *image, int n, float *logits, float
                 ca.C0 = L.cin - ca.C1;
                 ca.wpk = op.wpk; ca.bias = op.bias; ca.out = h->act[op.out]->p;
                 ca.N = n; ca.H = op.H; ca.W = op.W; ca.Ho = op.Ho; ca.Wo = op.Wo; ca.Cout = L.cout;
-                if (c.pc == 5) { ca.Cout = round_up(L.cout, 32); ca.cout_store = L.cout; }
+                if (c.pc == 5 || c.pc == 6) { ca.Cout = round_up(L.cout, 32); ca.cout_store = L.cout; }
                 if (op.fused_logits) {
                     ca.lg_w = dev_ptr(h, "logits/w"); ca.lg_b = dev_ptr(h, "logits/bias");
                     ca.lg_logits = logits; ca.lg_prob = prob; ca.lg_pred = pred; ca.lg_ncls = a.n_class;
@@ -1402,7 +1410,16 @@ int64_t ukbb_fcn_get_activation(ukbb_fcn_handle *h, const char *name, float *dst
                 set_err("get_activation: device copy failed");
                 return UKBB_EDEVICE;
             }
-            for (int64_t k = 0; k < n; ++k) { const uint32_t u = (uint32_t)tmp[(size_t)k] << 16; memcpy(dst + k, &u, 4); }
+            // channel-blocked on the device ([N][C/16][H][W][16], kernels.h); handed out as NHWC like the fp32 plans' maps
+            const int64_t C = h->act_ch[i], per = (int64_t)h->act_per_image[i], hw = C > 0 ? per / C : 0;
+            for (int64_t k = 0; k < n; ++k) {
+                int64_t src = k;
+                if (C > 16 && C % 16 == 0) {
+                    const int64_t img = k / per, r = k - img * per, px = r / C, c = r - px * C;
+                    src = img * per + ((c >> 4) * hw + px) * 16 + (c & 15);
+                }
+                const uint32_t u = (uint32_t)tmp[(size_t)src] << 16; memcpy(dst + k, &u, 4);
+            }
             return n;
         }
         if (hipSetDevice(h->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||

@@ -99,7 +99,11 @@ struct ConvConfig {
                         // 2: producer/consumer with the C_in = 1 first layer fused into the producers;
                         // 3: single-role kernel with bf16 operands / fp32 accumulation (mb = 32, kc = 16);
                         // 4: Winograd F(2x2,3x3) producer/consumer kernel (kernels_wino.hip)
-                        // 5: as 3 with bf16 NHWC activations in HBM on both sides (in0 / in1 / out point at bf16 data)
+                        // 5: as 3 with bf16 activations in HBM on both sides (in0 / in1 / out point at bf16 data), CHANNEL-BLOCKED:
+                        //    [N][C/16][H][W][16] -- a 16-channel K chunk of a row of pixels is one contiguous run of 32-byte pixels
+                        //    (r04: in plain NHWC a wave's 16-byte pieces of one chunk lay 2 C bytes apart, every piece pulled a whole
+                        //    128-byte line out of L2 for 16-32 useful bytes); for C = 16 the two layouts coincide
+                        // 6: bf16 storage as 5, weight-stationary persistent kernel of independent waves (kernels_ws.hip)
     const char *name;
     int fuse;           // pc == 5 only: 1 = the C_in = 1 first layer evaluated in this conv's staging (ConvArgs::first_w / first_b,
                         // in0 = the fp32 image), 2 = the logits conv + softmax / argmax in its epilogue (ConvArgs::lg_*); else 0
@@ -111,6 +115,13 @@ const ConvConfig &conv_config(int id);
 int num_pk16_configs();
 const ConvConfig &pk16_config(int i);
 hipError_t launch_conv16_pk(int cfg_id, const ConvArgs &a, hipStream_t s);
+// weight-stationary persistent 3x3 stride-1 tilings of the bf16 U-Net (ids 400-, ConvConfig::pc == 6: bf16 storage as pc 5; th = rows per
+// tile, tw = 32, wn = independent waves per workgroup, cb = 32-channel Cout blocks per workgroup) live in kernels_ws.hip; the three
+// functions above cover them.  LDS need depends on the layer's input channels (the whole packed filter of a Cout group is resident).
+int num_ws_configs();
+const ConvConfig &ws_config(int i);
+int ws_lds_bytes_for(const ConvConfig &c, int cin);
+hipError_t launch_conv_ws(int cfg_id, const ConvArgs &a, hipStream_t s);
 // cout handled by one workgroup = mb*cb*wm
 hipError_t launch_conv(int cfg_id, const ConvArgs &a, hipStream_t s);
 

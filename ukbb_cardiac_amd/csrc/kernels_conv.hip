@@ -212,7 +212,8 @@ __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM,
         const int iy = pix / IW, ix = pix % IW;
         const int gy = iy0 + iy, gx = ix0 + ix;
         const bool ok = pix < HP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-        goff[it] = ok ? ((n * a.H + gy) * a.W + gx) : -1;      // -1: zero padding / outside the tile
+        // bf16 storage is channel-blocked ([N][C/16][H][W][16], kernels.h): the offset is relative to the image's plane
+        goff[it] = ok ? (BFIO ? gy * a.W + gx : (n * a.H + gy) * a.W + gx) : -1;      // -1: zero padding / outside the tile
     }
 
     f32x4 xr[NIT], wr[NWT];
@@ -222,6 +223,12 @@ __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM,
         const char *src_; int cs_;                                                                 \
         if (ch_ * KC < a.C0) { src_ = reinterpret_cast<const char *>(a.in0) + (size_t)(ch_ * KC) * ES; cs_ = a.C0; } \
         else                 { src_ = reinterpret_cast<const char *>(a.in1) + (size_t)(ch_ * KC - a.C0) * ES; cs_ = a.C1; } \
+        if constexpr (BFIO) {   /* plane of this 16-channel chunk of image n: [N][C/16][H][W][16] bf16 */             \
+            const int chl_ = ch_ * KC < a.C0 ? ch_ : ch_ - a.C0 / KC;                              \
+            src_ = (ch_ * KC < a.C0 ? reinterpret_cast<const char *>(a.in0) : reinterpret_cast<const char *>(a.in1)) + \
+                   ((size_t)n * (cs_ / KC) + chl_) * a.H * a.W * 32;                               \
+            cs_ = KC;                                                                              \
+        }                                                                                          \
         src_ += 16 * c4;                                                                           \
         _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                       \
             /* unconditional load from a clamped address: a branch around the load makes hipcc  */ \
@@ -451,12 +458,13 @@ __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM,
                     for (int j = 0; j < NJ; ++j) {
                         const int chn = co0 + 8 * j;
                         unsigned short *o;
+                        // channel-blocked bf16 storage: [N][C/16][H][W][16]
                         if (a.up2 == 0) {
                             if (chn >= cst) continue;
-                            o = ob + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * cst + chn;
+                            o = ob + ((((size_t)n * (cst >> 4) + (chn >> 4)) * a.Ho + oy) * a.Wo + ox) * 16 + (chn & 15);
                         } else {                      // sub-pixel scatter of a transposed conv: phase / channel of this 4-channel group
                             const int ph = chn / a.up2, co = chn % a.up2;
-                            o = ob + ((size_t)(n * 2 * a.Ho + 2 * oy + (ph >> 1)) * (2 * a.Wo) + 2 * ox + (ph & 1)) * a.up2 + co;
+                            o = ob + ((((size_t)n * (a.up2 >> 4) + (co >> 4)) * (2 * a.Ho) + 2 * oy + (ph >> 1)) * (2 * a.Wo) + 2 * ox + (ph & 1)) * 16 + (co & 15);
                         }
                         float v0 = acc[cb][pb][4 * j + 0] + bi[j].x, v1 = acc[cb][pb][4 * j + 1] + bi[j].y;
                         float v2 = acc[cb][pb][4 * j + 2] + bi[j].z, v3 = acc[cb][pb][4 * j + 3] + bi[j].w;
@@ -1345,12 +1353,16 @@ static const ConvConfig g_cfgs[] = {UKBB_CONV_CONFIGS(UKBB_CFG_ENTRY) UKBB_PC_CO
                                     {303, 3, 1, 16, 16, 8, 16, 2, 1, 1, 112640, 4, "winogradF2x2_3x3_t16x8_kc16_cout32"}};
 
 static constexpr int N_BASE_CFGS = (int)(sizeof(g_cfgs) / sizeof(g_cfgs[0]));
-int num_conv_configs() { return N_BASE_CFGS + num_pk16_configs(); }
-const ConvConfig &conv_config(int i) { return i < N_BASE_CFGS ? g_cfgs[i] : pk16_config(i - N_BASE_CFGS); }
+int num_conv_configs() { return N_BASE_CFGS + num_pk16_configs() + num_ws_configs(); }
+const ConvConfig &conv_config(int i) {
+    return i < N_BASE_CFGS ? g_cfgs[i] : i < N_BASE_CFGS + num_pk16_configs() ? pk16_config(i - N_BASE_CFGS) : ws_config(i - N_BASE_CFGS - num_pk16_configs());
+}
 
 hipError_t launch_conv(int cfg_id, const ConvArgs &a_in, hipStream_t s) {
     for (int i = 0; i < num_pk16_configs(); ++i)
         if (pk16_config(i).id == cfg_id) return launch_conv16_pk(cfg_id, a_in, s);
+    for (int i = 0; i < num_ws_configs(); ++i)
+        if (ws_config(i).id == cfg_id) return launch_conv_ws(cfg_id, a_in, s);
     ConvArgs a = a_in;
 #ifdef UKBB_DIAG
     { const char *e = getenv("UKBB_CONV_DIAG"); a.diag = e ? atoi(e) : 0; }

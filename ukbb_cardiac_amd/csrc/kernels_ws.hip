@@ -1,0 +1,454 @@
+// Weight-stationary persistent 3x3 stride-1 convolution (+ folded BN bias, ReLU) for UKBB_PREC_BF16 of the aortic U-Net:
+// bf16 NHWC activations in HBM on both sides, v_mfma_f32_32x32x16_bf16, fp32 accumulation.  Replaces conv2d_bn_relu
+// (reference common/network.py:19-25) as used by the encoder / decoder blocks of common/network_ao.py:31-55, including the
+// skip concat of :51 as a two-source K loop.
+//
+// Why (r04): the tile-per-workgroup kernel (conv_mfma_kernel<..., BFIO>) spends a workgroup's life in
+// a chain of (load -> LDS -> barrier -> 18-36 MFMAs -> barrier) stages: levels 1-3 took 44-90 us per layer for 12-24 us of
+// matrix time, every workgroup re-streamed its Cout block's packed weights from L2 (conv3_1: 236 MB per launch, nine times the
+// activation map), and the matrix pipe was busy 42 % of a workgroup's lifetime at four workgroups per CU.  Here
+//   * a workgroup OWNS one group of 32 x CB output channels for the whole launch: its packed weights for ALL input channels
+//     and taps are copied to LDS once (<= 72 KB) and never move again;
+//   * every WAVE is an independent worker that walks its own row tiles (R rows x 32 pixels) of the batch: it stages the
+//     16-channel chunks of its halo tile into a PRIVATE two-stage LDS ring (global -> registers -> LDS, two register sets, the
+//     loads running three chunks ahead of the MFMAs that consume them) and multiplies from there.  After the weight copy there
+//     is NO barrier and no inter-wave dependence at all; the latency of one wave's loads is covered by its own earlier
+//     chunks and by the other waves of the SIMD;
+//   * LDS operand traffic per MFMA is 0.5-0.75 ds_read_b128: a pixel block is one image row x 32 pixels, so the B fragment
+//     of halo row r' at column shift kw serves the three output rows r' - kh; the stage image is [k half][halo pixel] x 16 B,
+//     linear in the order the loads arrive (conflict-free ds_write_b128) and conflict-free for the fragment reads
+//     (consecutive lanes = consecutive pixels = consecutive 16-byte slots);
+//   * image borders cost nothing in the steady state: halo pieces outside the image are requested with an out-of-range
+//     buffer offset (the hardware returns 0 = the conv's zero padding), ghost tiles past a worker's last tile likewise, and
+//     stores of pixels / channels that do not exist are dropped the same way -- the loop body has no branch around a
+//     vector-memory instruction, so hipcc's counted s_waitcnt vmcnt(n) keeps the younger register set in flight.
+// Fragment layouts and packed weights are those of conv_mfma_kernel<..., BFIO> (pack_conv_weights_bf16 with ncbl = CB);
+// the accumulation order over (chunk, tap) differs (kw outermost inside a chunk), so results agree with that kernel to fp32
+// rounding of the accumulator, not bit for bit.
+#include "kernels.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+#include <vector>
+
+namespace ukbb {
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4 &a, const u32x4 &b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    const __bf16 l = (__bf16)lo, h = (__bf16)hi;       // RNE; v_cvt_pk_bf16_f32
+    return (unsigned)__builtin_bit_cast(unsigned short, l) | ((unsigned)__builtin_bit_cast(unsigned short, h) << 16);
+}
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void unroll_steps(F &&f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); unroll_steps<N, I + 1>(f); }
+}
+
+constexpr int WS_TW = 32;                               // tile width = one 32-pixel MFMA block per image row
+constexpr int WS_IW = WS_TW + 2;                        // halo row
+
+__host__ __device__ constexpr int ws_nld(int r) { return (2 * (r + 2) * WS_IW + 63) / 64; }     // 16-byte pieces per lane and stage
+// one k-half plane of a stage: halo pixels x 16 bytes, padded so that the planes lie an odd multiple of 64 bytes apart modulo 128: the
+// 8 lanes of a ds_write_b128 group (4 pixels x 2 halves) then fall on 8 different 16-byte slots
+__host__ __device__ constexpr int ws_plane_bytes(int r) { return ((r + 2) * WS_IW * 16 / 128) * 128 + 64 + ((r + 2) * WS_IW * 16 % 128 > 64 ? 128 : 0); }
+__host__ __device__ constexpr int ws_stage_bytes(int r) { return (2 * ws_plane_bytes(r) + 32 + 127) / 128 * 128; }
+__host__ __device__ constexpr int ws_lds_bytes(int r, int cb, int nw, int nch) {
+    return nch * cb * 9 * 1024 + cb * 128 + nw * 2 * ws_stage_bytes(r);
+}
+
+// R: output rows per tile; CB: 32-channel Cout blocks per workgroup (and per wave); NW: waves (= independent workers) per workgroup;
+// NCH: 16-channel chunks of the input (both sources together); TWO: chunks NCH/2.. come from the second source (C0 == C1)
+template <int R, int CB, int NW, int NCH, bool TWO>
+__global__ __launch_bounds__(NW * 64, NW / 4) void conv_ws_kernel(const ConvArgs a) {
+    constexpr int HP = (R + 2) * WS_IW, NLD = ws_nld(R), STAGE = ws_stage_bytes(R), PLANE = ws_plane_bytes(R);
+    constexpr int WSLAB = NCH * CB * 9 * 1024;          // bytes: [chunk][cb][tap][lane][16]
+    constexpr int TPB = NCH % 2 ? 2 : 1;                // tiles per unrolled loop body (the body covers an even number of chunks)
+    constexpr int U = TPB * NCH;
+    static_assert(!TWO || NCH % 2 == 0, "two sources: equal halves");
+    constexpr unsigned OOB = 0x80000000u;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char *const ws = lds;
+    float *const bias_s = reinterpret_cast<float *>(lds + WSLAB);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
+#ifdef UKBB_DIAG
+    // diagnostic build only: per-wave cycle stamps (entry, weights resident, prologue done, end of every tile) into a buffer of their own
+    unsigned long long *const stamps = a.diag ? reinterpret_cast<unsigned long long *>(const_cast<float *>(a.first_w)) + ((size_t)blockIdx.x * NW + wave) * 16 : nullptr;
+    const unsigned long long st_entry = __builtin_amdgcn_s_memtime(), st_rt0 = __builtin_amdgcn_s_memrealtime();
+#define UKBB_WS_STAMP(SLOT) { if (stamps && lane == 0 && (SLOT) < 14) stamps[SLOT] = __builtin_amdgcn_s_memtime(); }
+#else
+#define UKBB_WS_STAMP(SLOT)
+#endif
+    const int g = lane >> 5, pl = lane & 31;
+    unsigned char *const ring = lds + WSLAB + CB * 128 + wave * (2 * STAGE);
+
+    // ---- workgroup -> (Cout group, walker).  Workgroups b and b + 8 share an XCD (observed round-robin placement, speed only):
+    //      the nG workgroups that walk the same tiles with different Cout groups are given equal b % 8 so that a tile is fetched
+    //      into ONE per-XCD L2.
+    const int nG = a.Cout / (32 * CB);
+    int grp, walker;
+    const int nwalk = (int)gridDim.x / nG;              // the launcher makes the grid a multiple of nG
+    if ((int)gridDim.x % (8 * nG) == 0) {
+        const int j = (int)blockIdx.x >> 3;
+        grp = j % nG; walker = ((int)blockIdx.x & 7) + 8 * (j / nG);
+    } else {
+        grp = (int)blockIdx.x % nG; walker = (int)blockIdx.x / nG;
+    }
+    const int tiles = a.tiles_x * a.tiles_y, ntiles = a.N * tiles;
+    const int worker = walker * NW + wave, nworkers = nwalk * NW;
+    const int my = worker < ntiles ? (ntiles - worker + nworkers - 1) / nworkers : 0;
+
+    // ---- once per workgroup: this group's packed weights and bias -> LDS.  All of a thread's pieces are requested before the first is
+    //      stored (as a load -> store loop the copy was a chain of 9-18 dependent L2 round trips in front of every launch).
+    {
+        constexpr int NWP = WSLAB / 16 / (NW * 64);     // 16-byte pieces per thread: NCH * CB * 9 / NW ...
+        constexpr int NWR = WSLAB / 16 - NWP * (NW * 64);   // ... and a remainder of fewer than NW * 64 pieces
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(a.wpk) + (size_t)grp * (WSLAB / 16);
+        u32x4 wq[NWP + 1];
+#pragma unroll
+        for (int i = 0; i < NWP; ++i) wq[i] = src[tid + i * (NW * 64)];
+        if constexpr (NWR > 0) wq[NWP] = src[tid < NWR ? tid + NWP * (NW * 64) : 0];
+        const float bv = tid < CB * 32 ? a.bias[grp * CB * 32 + tid] : 0.f;
+#pragma unroll
+        for (int i = 0; i < NWP; ++i) reinterpret_cast<u32x4 *>(ws)[tid + i * (NW * 64)] = wq[i];
+        if constexpr (NWR > 0) { if (tid < NWR) reinterpret_cast<u32x4 *>(ws)[tid + NWP * (NW * 64)] = wq[NWP]; }
+        if (tid < CB * 32) bias_s[tid] = bv;
+    }
+    __syncthreads();
+    if (my == 0) return;
+#ifdef UKBB_DIAG
+    if (stamps && lane == 0) { stamps[0] = st_entry; stamps[14] = st_rt0; }
+#endif
+    UKBB_WS_STAMP(1)
+
+    // ---- per-lane geometry of the staging pieces (tile independent).  Activations are channel-blocked in HBM ([N][C/16][H][W][16],
+    //      kernels.h): the 16-channel chunk of a halo row is one contiguous run of 32-byte pixels, and lanes 2i / 2i+1 of a load
+    //      instruction fetch the two 16-byte halves of one pixel -- 1 KB of consecutive bytes per instruction.  In LDS the halves
+    //      go to their planes: piece p -> [k half p & 1][halo pixel p >> 1].
+    unsigned geo[NLD], pbase[NLD];
+    unsigned lofs[NLD];                                 // LDS byte offset of the piece inside a stage
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int p = lane + 64 * i;
+        const int gg = p & 1, px = p >> 1;
+        const int hy = px / WS_IW, hx = px - hy * WS_IW;
+        geo[i] = (unsigned)hy | ((unsigned)hx << 8) | (px < HP ? 0u : OOB);
+        pbase[i] = (unsigned)((hy * a.W + hx) * 32 + 16 * gg);
+        lofs[i] = (unsigned)((px < HP ? gg * PLANE + px * 16 : 2 * PLANE + (lane & 1) * 16));    // idle lanes: a 32-byte scratch slot behind the planes
+    }
+    const unsigned char *const in0 = reinterpret_cast<const unsigned char *>(a.in0);
+    const unsigned char *const in1 = reinterpret_cast<const unsigned char *>(a.in1);
+    const int plane_bytes = a.H * a.W * 32;             // one 16-channel plane of one image
+    const int nb0 = a.C0 / 16, nb1 = a.C1 / 16;
+
+    auto tile_coords = [&](int k, int &n, int &oy0, int &ox0) -> bool {
+        const bool valid = k < my;
+        const int t = valid ? worker + k * nworkers : 0;
+        n = t / tiles;
+        const int r = t - n * tiles, ty = r / a.tiles_x;
+        oy0 = ty * R; ox0 = (r - ty * a.tiles_x) * WS_TW;
+        return valid;
+    };
+
+    // ---- load cursor: the tile whose chunks are being requested ----
+    unsigned voff[NLD];
+    __amdgpu_buffer_rsrc_t rs0, rs1;
+    auto load_setup = [&](int k) {
+        int n, oy0, ox0;
+        const bool valid = tile_coords(k, n, oy0, ox0);
+        // range = the image's planes of that source: a chunk's plane is selected by the scalar offset of the load
+        rs0 = __builtin_amdgcn_make_buffer_rsrc((void *)(in0 + (size_t)n * nb0 * plane_bytes), 0, nb0 * plane_bytes, 0x00020000);
+        rs1 = __builtin_amdgcn_make_buffer_rsrc((void *)((TWO ? in1 : in0) + (size_t)n * (TWO ? nb1 : nb0) * plane_bytes), 0, (TWO ? nb1 : nb0) * plane_bytes, 0x00020000);
+        const int toff = ((oy0 - 1) * a.W + (ox0 - 1)) * 32;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int hy = (int)(geo[i] & 0xffu), hx = (int)((geo[i] >> 8) & 0xffu);
+            const bool ok = valid && !(geo[i] & OOB) && (unsigned)(oy0 - 1 + hy) < (unsigned)a.H && (unsigned)(ox0 - 1 + hx) < (unsigned)a.W;
+            voff[i] = ok ? pbase[i] + (unsigned)toff : OOB;
+        }
+    };
+    u32x4 xq[2][NLD];
+    auto issue = [&](auto setc, auto chc) {             // request chunk CH of the load cursor's tile into register set SET
+        constexpr int SET = decltype(setc)::value, CH = decltype(chc)::value;
+        constexpr bool second = TWO && CH >= NCH / 2;
+        const int soff = (second ? CH - NCH / 2 : CH) * plane_bytes;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) xq[SET][i] = __builtin_amdgcn_raw_buffer_load_b128(second ? rs1 : rs0, voff[i], soff, 0);
+    };
+    auto park = [&](auto setc) {                        // register set SET -> ring stage SET: the halves to their planes
+        constexpr int SET = decltype(setc)::value;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) *reinterpret_cast<u32x4 *>(ring + SET * STAGE + lofs[i]) = xq[SET][i];
+    };
+
+    // ---- compute cursor ----
+    // The LDS fragment reads are software-pipelined BY HAND across steps, chunks and tiles (left to itself hipcc reads a B fragment
+    // into one buffer and waits lgkmcnt(0) right behind it: r04 first build, 18 exposed LDS round trips per chunk, 3100 cycles for
+    // 1152 cycles of MFMA).  A step = one B fragment (halo row rp at column shift kw) and the <= 3 CB MFMAs it feeds; S steps per
+    // chunk.  At step T the read of step T + PD goes out into buffer (T + PD) % NB; the A fragments of the next (chunk, kw) group go
+    // out at the first step of the current group into the other A set.  sched_barrier pins the order (hipcc would sink the reads to
+    // their first use); its counted lgkmcnt(n) waits then leave the younger reads in flight.
+    constexpr int S = 3 * (R + 2), PD = 3, NB = 4;
+    static_assert((U * S) % NB == 0 && (U * 3) % 2 == 0, "fragment buffers rotate consistently across loop iterations");
+    f32x16 acc[CB][R], biasv[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bias_s + cb * 32 + 8 * j + 4 * g);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) biasv[cb][4 * j + i] = b4[i];
+        }
+    const unsigned char *const xs_lane = ring + g * PLANE + pl * 16;
+    const unsigned char *const ws_lane = ws + lane * 16;
+    u32x4 Bq[NB], Aq[2][CB][3];
+    auto readB = [&](auto tc) {                         // step TT of the body (>= U * S: the first steps of the next loop iteration)
+        constexpr int TT = decltype(tc)::value, T = TT % (U * S), Qn = T / S, s = T % S, kw = s / (R + 2), rp = s % (R + 2);
+        Bq[TT % NB] = *reinterpret_cast<const u32x4 *>(xs_lane + (Qn & 1) * STAGE + (rp * WS_IW + kw) * 16);
+    };
+    auto readA = [&](auto gc) {                         // (chunk, kw) group GG of the body
+        constexpr int GG = decltype(gc)::value, G = GG % (U * 3), CH = (G / 3) % NCH, kw = G % 3;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+                Aq[GG & 1][cb][kh] = *reinterpret_cast<const u32x4 *>(ws_lane + ((CH * CB + cb) * 9 + kh * 3 + kw) * 1024);
+    };
+    auto compute = [&](auto qc) {                       // position Q of the body: chunk Q % NCH from ring stage Q & 1
+        constexpr int Q = decltype(qc)::value, CH = Q % NCH;
+        unroll_steps<S>([&](auto sc) {
+            constexpr int s = decltype(sc)::value, T = Q * S + s, kw = s / (R + 2), rp = s % (R + 2), G = Q * 3 + kw;
+            readB(std::integral_constant<int, T + PD>{});
+            if constexpr (rp == 0) readA(std::integral_constant<int, G + 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            unroll_steps<3>([&](auto khc) {
+                constexpr int kh = decltype(khc)::value, r = rp - kh;
+                if constexpr (r >= 0 && r < R) {
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb) {
+                        // the folded-BN bias is the C operand of an accumulator's first MFMA of the tile (no zeroing, no bias adds)
+                        if constexpr (CH == 0 && kw == 0 && kh == 0) acc[cb][r] = mfma_bf16(Aq[G & 1][cb][kh], Bq[T % NB], biasv[cb]);
+                        else acc[cb][r] = mfma_bf16(Aq[G & 1][cb][kh], Bq[T % NB], acc[cb][r]);
+                    }
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    // ---- epilogue: ReLU (one v_max_i32 on the bit pattern), bf16 rounding (v_cvt_pk_bf16_f32), 8-byte NHWC stores.  Per-lane store offsets
+    //      are tile independent (pixel column and channel of the lane); the tile's row offsets are scalar (soffset); rows below the map
+    //      and ghost tiles store through a descriptor of range 0, columns right of the map / channels beyond the real count through an
+    //      out-of-range lane offset: dropped by the hardware, no branch.
+    const int cst = a.cout_store > 0 ? a.cout_store : a.Cout;
+    unsigned char *const outb = reinterpret_cast<unsigned char *>(a.out);
+    const int out_plane_bytes = a.Ho * a.Wo * 32, out_img_bytes = (cst / 16) * out_plane_bytes;     // channel-blocked like the inputs
+    unsigned svoff[CB][4];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int chn = (grp * CB + cb) * 32 + 8 * j + 4 * g;
+            svoff[cb][j] = chn < cst ? (unsigned)((chn >> 4) * out_plane_bytes + pl * 32 + (chn & 15) * 2) : OOB;
+        }
+    const int relu_lo = a.relu ? 0 : (int)0x80000000;   // max_i32(bits, 0) = ReLU; max_i32(bits, INT_MIN) = identity
+    auto epilogue = [&](int k) {
+        int n, oy0, ox0;
+        const bool valid = tile_coords(k, n, oy0, ox0);
+        unsigned char *const obase = outb + (size_t)n * out_img_bytes;
+        const bool colok = ox0 + pl < a.Wo;
+        unsigned vo[CB][4];
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) vo[cb][j] = colok ? svoff[cb][j] : OOB;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int oy = oy0 + r;
+            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)obase, 0, (valid && oy < a.Ho) ? out_img_bytes : 0, 0x00020000);
+            const int srow = (oy * a.Wo + ox0) * 32;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    // (elements copied to scalars first: __builtin_bit_cast applied to an ext_vector element expression reads element 0, hipcc 7.2)
+                    const float e0 = acc[cb][r][4 * j + 0], e1 = acc[cb][r][4 * j + 1], e2 = acc[cb][r][4 * j + 2], e3 = acc[cb][r][4 * j + 3];
+                    f32x2 lo2, hi2;
+                    lo2.x = __builtin_bit_cast(float, max(__builtin_bit_cast(int, e0), relu_lo));
+                    lo2.y = __builtin_bit_cast(float, max(__builtin_bit_cast(int, e1), relu_lo));
+                    hi2.x = __builtin_bit_cast(float, max(__builtin_bit_cast(int, e2), relu_lo));
+                    hi2.y = __builtin_bit_cast(float, max(__builtin_bit_cast(int, e3), relu_lo));
+                    u32x2 pk;
+                    pk.x = __builtin_bit_cast(unsigned, __builtin_convertvector(lo2, bf16x2));
+                    pk.y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi2, bf16x2));
+                    __builtin_amdgcn_raw_buffer_store_b64(pk, ro, vo[cb][j], srow, 0);
+                }
+        }
+    };
+
+    constexpr std::integral_constant<int, 0> S0{};
+    constexpr std::integral_constant<int, 1> S1{};
+    // ---- prologue: chunks 0, 1, 2 of the flattened (tile, chunk) sequence requested; chunk 0 parked ----
+    int lk = 0;                                         // tile index (among this worker's) of the load cursor
+    load_setup(0);
+    // position q of the flattened sequence = tile q / NCH, chunk q % NCH.  Requests run 3 positions ahead of the compute cursor.
+    auto request = [&](auto setc, auto posc) {          // posc: position modulo U (compile time); advances the cursor when a tile ends
+        constexpr int POS = decltype(posc)::value;
+        issue(setc, std::integral_constant<int, POS % NCH>{});
+        if constexpr (POS % NCH == NCH - 1) { ++lk; load_setup(lk); }
+    };
+    request(S0, std::integral_constant<int, 0>{});
+    request(S1, std::integral_constant<int, 1 % U>{});
+    park(S0);
+    request(S0, std::integral_constant<int, 2 % U>{});
+    readA(std::integral_constant<int, 0>{});
+    unroll_steps<PD>([&](auto tc) { readB(tc); });
+    UKBB_WS_STAMP(2)
+
+    const int bodies = (my + TPB - 1) / TPB;
+    auto body = [&](int bi) {
+        unroll_steps<U>([&](auto qc) {
+            constexpr int Q = decltype(qc)::value;      // position modulo U of the compute cursor
+            constexpr int SETN = (Q + 1) & 1;           // register set / stage of position Q + 1
+            if constexpr (SETN == 0) { park(S0); request(S0, std::integral_constant<int, (Q + 3) % U>{}); }
+            else                     { park(S1); request(S1, std::integral_constant<int, (Q + 3) % U>{}); }
+            compute(qc);
+            if constexpr (Q % NCH == NCH - 1) { epilogue(bi * TPB + Q / NCH); UKBB_WS_STAMP(3 + bi * TPB + Q / NCH) }
+        });
+    };
+    // first iteration peeled: hipcc merges the wait-count state of the loop entry with that of the back edge, and with the prologue
+    // in front of the loop the merged state made the first LDS park of every iteration wait for ALL but one outstanding
+    // vector-memory operation (both register sets in flight and the tile's stores): s_waitcnt vmcnt(8) instead of vmcnt(30)
+    body(0);
+#pragma unroll 1
+    for (int bi = 1; bi < bodies; ++bi) body(bi);
+#ifdef UKBB_DIAG
+    if (stamps && lane == 0) { stamps[13] = (unsigned long long)my; stamps[15] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+}
+
+}  // namespace
+
+// W(id, R, CB, NW): ConvConfig::pc == 6, 3x3 stride 1, mb 32, th = R, tw = 32, kc 16, wm 1, wn = NW, cb = CB
+#define UKBB_WS_CONFIGS(W)          \
+    W(400, 2, 1, 8)                 \
+    W(401, 4, 1, 4)                 \
+    W(402, 2, 2, 8)                 \
+    W(403, 4, 2, 4)
+
+#define UKBB_WS_ENTRY(ID, R, CB, NW) \
+    {ID, 3, 1, 32, R, WS_TW, 16, 1, NW, CB, 0, 6, "convBF16ws_3x3s1_r" #R "x32_cb" #CB "_w" #NW, 0},
+static const ConvConfig g_ws_cfgs[] = {UKBB_WS_CONFIGS(UKBB_WS_ENTRY)};
+
+int num_ws_configs() { return (int)(sizeof(g_ws_cfgs) / sizeof(g_ws_cfgs[0])); }
+const ConvConfig &ws_config(int i) { return g_ws_cfgs[i]; }
+int ws_lds_bytes_for(const ConvConfig &c, int cin) { return ws_lds_bytes(c.th, c.cb, c.wn, cin / 16); }
+
+namespace {
+template <int R, int CB, int NW, int NCH, bool TWO>
+hipError_t launch_ws_one(const ConvArgs &a, int grid, hipStream_t s) {
+    auto k = conv_ws_kernel<R, CB, NW, NCH, TWO>;
+    constexpr int bytes = ws_lds_bytes(R, CB, NW, NCH);
+    if constexpr (bytes > 160 * 1024) { return hipErrorInvalidValue; }
+    else {
+        static OncePerDevice lds_ok;
+        hipError_t e = allow_dynamic_lds(lds_ok, reinterpret_cast<const void *>(k), bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NW * 64), bytes, s, a);
+        return hipGetLastError();
+    }
+}
+template <int R, int CB, int NW>
+hipError_t launch_ws_cfg(const ConvArgs &a, int grid, hipStream_t s) {
+    const int nch = (a.C0 + a.C1) / 16;
+    const bool two = a.C1 > 0;
+    switch (nch) {
+        case 1: return two ? hipErrorInvalidValue : launch_ws_one<R, CB, NW, 1, false>(a, grid, s);
+        case 2: return two ? launch_ws_one<R, CB, NW, 2, true>(a, grid, s) : launch_ws_one<R, CB, NW, 2, false>(a, grid, s);
+        case 4: return two ? launch_ws_one<R, CB, NW, 4, true>(a, grid, s) : launch_ws_one<R, CB, NW, 4, false>(a, grid, s);
+        case 8: return two ? launch_ws_one<R, CB, NW, 8, true>(a, grid, s) : launch_ws_one<R, CB, NW, 8, false>(a, grid, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+}  // namespace
+
+hipError_t launch_conv_ws(int cfg_id, const ConvArgs &a_in, hipStream_t s) {
+    const ConvConfig *c = nullptr;
+    for (const ConvConfig &k : g_ws_cfgs) if (k.id == cfg_id) c = &k;
+    if (!c) return hipErrorInvalidValue;
+    ConvArgs a = a_in;
+    if (a.in0_map || a.up2 || a.first_w || a.lg_w) return hipErrorInvalidValue;
+    if (a.C1 && a.C1 != a.C0) return hipErrorInvalidValue;     // the K loop switches source at the half
+    if (a.C0 % 16 || a.Cout % (32 * c->cb) || a.pad_y != 1 || a.pad_x != 1 || a.Ho != a.H || a.Wo != a.W) return hipErrorInvalidValue;
+    if ((long long)a.H * a.W * (a.C0 > a.Cout ? a.C0 : a.Cout) * 2 >= 0x7fffffffll) return hipErrorInvalidValue;
+    a.tiles_y = (a.Ho + c->th - 1) / c->th; a.tiles_x = (a.Wo + WS_TW - 1) / WS_TW;
+    const int nG = a.Cout / (32 * c->cb);
+    const long long ntiles = (long long)a.N * a.tiles_y * a.tiles_x;
+    // one workgroup per CU; a multiple of 8 nG where the chip allows it (XCD-aware walker mapping), never more walkers than tiles need
+    int cus = device_cu_count();
+    long long want = ((ntiles + c->wn - 1) / c->wn) * nG;           // workgroups that would give every wave one tile
+    int grid = cus >= 8 * nG ? cus / (8 * nG) * (8 * nG) : cus / nG * nG;
+    if (grid < nG) grid = nG;
+    if (want < grid) grid = (int)((want + nG - 1) / nG * nG);
+#ifdef UKBB_DIAG
+    // UKBB_WS_STAMPS=<cfg id>: the 6th launch of that tiling reports where its waves spent their cycles
+    static unsigned long long *d_st = nullptr;
+    const char *sc = getenv("UKBB_WS_STAMPS");
+    const bool stamp = sc && atoi(sc) == cfg_id;
+    const int nwv = grid * c->wn;
+    if (stamp) {
+        if (!d_st && hipMalloc(reinterpret_cast<void **>(&d_st), 4096 * 16 * 8) != hipSuccess) return hipErrorOutOfMemory;
+        (void)hipMemsetAsync(d_st, 0, 4096 * 16 * 8, s);
+        a.first_w = reinterpret_cast<const float *>(d_st); a.diag = 1;
+    }
+    struct Dump {
+        bool on; hipStream_t s; unsigned long long *d; int cfg, nwv;
+        ~Dump() {
+            if (!on) return;
+            static int shots = 0;
+            if (++shots != 6) return;
+            std::vector<unsigned long long> h((size_t)nwv * 16);
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+            unsigned long long t0 = ~0ull, t1 = 0;
+            double wgt = 0, pro = 0, life = 0, tile[10] = {0}; int ntile[10] = {0}, n = 0; double clk = 0;
+            for (int w = 0; w < nwv; ++w) {
+                const unsigned long long *q = &h[(size_t)w * 16];
+                if (!q[0]) continue;
+                ++n;
+                const int my = (int)q[13];
+                unsigned long long end = q[2];
+                for (int k = 0; k < my && k < 10; ++k) { tile[k] += (double)(q[3 + k] - (k ? q[2 + k] : q[2])); ++ntile[k]; end = q[3 + k]; }
+                t0 = std::min(t0, q[0]); t1 = std::max(t1, end);
+                wgt += (double)(q[1] - q[0]); pro += (double)(q[2] - q[1]); life += (double)(end - q[0]);
+                if (q[15] > q[14]) clk += (double)(end - q[0]) / (double)(q[15] - q[14]) * 0.1;
+            }
+            if (!n) return;
+            fprintf(stderr, "[ws stamps cfg %d] %d working waves: weights resident after %.0f cyc, prologue %.0f, mean lifetime %.0f cyc, first entry -> last end %.0f cyc, clock %.2f GHz\n",
+                    cfg, n, wgt / n, pro / n, life / n, (double)(t1 - t0), clk / n);
+            for (int k = 0; k < 10; ++k) if (ntile[k]) fprintf(stderr, "[ws stamps cfg %d]   tile %d: %d waves, mean %.0f cyc\n", cfg, k, ntile[k], tile[k] / ntile[k]);
+        }
+    } dump{stamp, s, d_st, cfg_id, nwv > 4096 ? 4096 : nwv};
+#endif
+    switch (cfg_id) {
+#define UKBB_WS_CASE(ID, R, CB, NW) case ID: return launch_ws_cfg<R, CB, NW>(a, grid, s);
+        UKBB_WS_CONFIGS(UKBB_WS_CASE)
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace ukbb
