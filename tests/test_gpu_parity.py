@@ -358,9 +358,11 @@ def test_unet_bf16_dice_vs_fp32():
         eng.set_precision('bf16')
         b16 = eng.run(img, want_logits=True)
         names, cfgs = eng.kernel_names(), eng.kernel_configs()
-        # every conv / transposed conv on the bf16-storage tilings (ConvConfig::pc == 5, ids 230-299 and 320-325): nothing left in fp32
+        # every conv / transposed conv on the bf16-storage tilings (ConvConfig::pc == 5, ids 230-299 and 320-325; pc == 6, the
+        # weight-stationary ids 400-): nothing left in fp32
         # (21 launches: the first layer rides in conv0_1's staging, the logits in up0_1's epilogue)
-        assert len(cfgs) == 21 and all(230 <= c < 330 and not 300 <= c < 310 for c in cfgs), 'bf16 tilings not selected: %s' % list(zip(eng.kernel_names(), cfgs))
+        assert len(cfgs) == 21 and all((230 <= c < 330 and not 300 <= c < 310) or 400 <= c < 420 for c in cfgs), 'bf16 tilings not selected: %s' % list(zip(eng.kernel_names(), cfgs))
+        assert sum(400 <= c < 420 for c in cfgs) >= 8, 'weight-stationary tilings not in the plan: %s' % list(zip(eng.kernel_names(), cfgs))
         assert names[0] == 'conv0_0+conv0_1' and names[-1] == 'up0_1+logits'
         prob16 = eng.run(img, want_logits=True, want_prob=True)
         assert np.array_equal(prob16['logits'], b16['logits']) and np.array_equal(np.argmax(prob16['prob'], -1), b16['pred'])

@@ -376,10 +376,11 @@ int choose_cfg(const std::string &layer, int ks, int stride, int c0, int c1, int
 // PREC=bf16, profiles/r03_sweep_bf16.txt): {ks, stride, cin (both sources), cout (4 x cout for the 2x2 form of a transposed conv), cfg}.
 // Levels 2-4 sit on a 35-50 us floor per launch whatever the tiling (launch + first-load latency + tail at 100-400 tiles);
 // the table mostly avoids the bad cases (conv3_0 108 -> 47 us, up2_0 104 -> 80, conv2_0 61 -> 45).
+// r04: the weight-stationary persistent tilings (400-403, kernels_ws.hip) where a Cout group's whole filter fits LDS (K <= 1152)
 const Tuned g_tuned_bfio[] = {
-    {3, 1, 16, 16, 236, 232, -1},   {3, 1, 32, 32, 232, -1, -1},   {3, 1, 64, 64, 235, 232, -1},    {3, 1, 128, 128, 235, 232, -1},
-    {3, 1, 256, 256, 239, 232, -1}, {3, 1, 256, 128, 239, 232, -1}, {3, 1, 128, 64, 239, 232, -1},  {3, 1, 64, 32, 232, -1, -1},
-    {3, 1, 32, 16, 236, 232, -1},
+    {3, 1, 16, 16, 236, 232, -1},   {3, 1, 32, 32, 401, 232, -1},   {3, 1, 64, 64, 402, 235, 232},    {3, 1, 128, 128, 400, 235, 232},
+    {3, 1, 256, 256, 239, 232, -1}, {3, 1, 256, 128, 239, 232, -1}, {3, 1, 128, 64, 400, 239, 232},  {3, 1, 64, 32, 401, 232, -1},
+    {3, 1, 32, 16, 401, 236, 232},
     {3, 2, 16, 32, 241, -1, -1},    {3, 2, 32, 64, 242, 241, -1},   {3, 2, 64, 128, 244, 241, -1},  {3, 2, 128, 256, 244, 241, -1},
     {2, 1, 256, 512, 253, 251, -1}, {2, 1, 128, 256, 253, 251, -1}, {2, 1, 64, 128, 253, 251, -1},  {2, 1, 32, 64, 258, 253, 251},
 };

@@ -82,7 +82,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_ws_kernel(const ConvArgs
 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char *const ws = lds;
-    float *const bias_s = reinterpret_cast<float *>(lds + WSLAB);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
@@ -110,31 +109,23 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_ws_kernel(const ConvArgs
         grp = (int)blockIdx.x % nG; walker = (int)blockIdx.x / nG;
     }
     const int tiles = a.tiles_x * a.tiles_y, ntiles = a.N * tiles;
-    const int worker = walker * NW + wave, nworkers = nwalk * NW;
+    // wave-major numbering: when the tiles do not divide evenly the workers with one tile more are spread one wave per workgroup
+    // (one SIMD of a CU carries 7 tiles, the others 6) instead of filling whole workgroups (8 against 6)
+    const int worker = wave * nwalk + walker, nworkers = nwalk * NW;
     const int my = worker < ntiles ? (ntiles - worker + nworkers - 1) / nworkers : 0;
 
     // ---- once per workgroup: this group's packed weights and bias -> LDS.  All of a thread's pieces are requested before the first is
-    //      stored (as a load -> store loop the copy was a chain of 9-18 dependent L2 round trips in front of every launch).
+    //      stored (as a load -> store loop the copy was a chain of 9-18 dependent L2 round trips in front of every launch), and the
+    //      first three activation chunks are requested behind them BEFORE the weights are waited for (one round trip, not two).
+    constexpr int NWP = WSLAB / 16 / (NW * 64);         // 16-byte pieces per thread: NCH * CB * 9 / NW ...
+    constexpr int NWR = WSLAB / 16 - NWP * (NW * 64);   // ... and a remainder of fewer than NW * 64 pieces
+    u32x4 wq[NWP + 1];
     {
-        constexpr int NWP = WSLAB / 16 / (NW * 64);     // 16-byte pieces per thread: NCH * CB * 9 / NW ...
-        constexpr int NWR = WSLAB / 16 - NWP * (NW * 64);   // ... and a remainder of fewer than NW * 64 pieces
         const u32x4 *src = reinterpret_cast<const u32x4 *>(a.wpk) + (size_t)grp * (WSLAB / 16);
-        u32x4 wq[NWP + 1];
 #pragma unroll
         for (int i = 0; i < NWP; ++i) wq[i] = src[tid + i * (NW * 64)];
         if constexpr (NWR > 0) wq[NWP] = src[tid < NWR ? tid + NWP * (NW * 64) : 0];
-        const float bv = tid < CB * 32 ? a.bias[grp * CB * 32 + tid] : 0.f;
-#pragma unroll
-        for (int i = 0; i < NWP; ++i) reinterpret_cast<u32x4 *>(ws)[tid + i * (NW * 64)] = wq[i];
-        if constexpr (NWR > 0) { if (tid < NWR) reinterpret_cast<u32x4 *>(ws)[tid + NWP * (NW * 64)] = wq[NWP]; }
-        if (tid < CB * 32) bias_s[tid] = bv;
     }
-    __syncthreads();
-    if (my == 0) return;
-#ifdef UKBB_DIAG
-    if (stamps && lane == 0) { stamps[0] = st_entry; stamps[14] = st_rt0; }
-#endif
-    UKBB_WS_STAMP(1)
 
     // ---- per-lane geometry of the staging pieces (tile independent).  Activations are channel-blocked in HBM ([N][C/16][H][W][16],
     //      kernels.h): the 16-channel chunk of a halo row is one contiguous run of 32-byte pixels, and lanes 2i / 2i+1 of a load
@@ -210,7 +201,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_ws_kernel(const ConvArgs
     for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bias_s + cb * 32 + 8 * j + 4 * g);
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(a.bias + (grp * CB + cb) * 32 + 8 * j + 4 * g);
 #pragma unroll
             for (int i = 0; i < 4; ++i) biasv[cb][4 * j + i] = b4[i];
         }
@@ -313,6 +304,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_ws_kernel(const ConvArgs
     };
     request(S0, std::integral_constant<int, 0>{});
     request(S1, std::integral_constant<int, 1 % U>{});
+    {
+#pragma unroll
+        for (int i = 0; i < NWP; ++i) reinterpret_cast<u32x4 *>(ws)[tid + i * (NW * 64)] = wq[i];
+        if constexpr (NWR > 0) { if (tid < NWR) reinterpret_cast<u32x4 *>(ws)[tid + NWP * (NW * 64)] = wq[NWP]; }
+    }
+    __syncthreads();                                    // the only barrier of the kernel: weights resident
+    if (my == 0) return;
+#ifdef UKBB_DIAG
+    if (stamps && lane == 0) { stamps[0] = st_entry; stamps[14] = st_rt0; }
+#endif
+    UKBB_WS_STAMP(1)
     park(S0);
     request(S0, std::integral_constant<int, 2 % U>{});
     readA(std::integral_constant<int, 0>{});
