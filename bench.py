@@ -69,6 +69,84 @@ def _timed(fn, slices_per_call, target_seconds, max_calls):
             return slices_per_call * calls / dt, slices_per_call * calls, dt
 
 
+def cpu_quota():
+    """What this process may actually use of the host's CPUs: the scheduler affinity mask and the cgroup CPU bandwidth limit
+    (a GPU box can show 128-256 logical CPUs while the container is capped at a fraction of them)."""
+    q = {'logical_cpus': os.cpu_count()}
+    try:
+        q['sched_affinity_cpus'] = len(os.sched_getaffinity(0))
+    except Exception:
+        q['sched_affinity_cpus'] = None
+    q['cgroup_cpu_max'] = None
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+        except Exception:
+            continue
+        if path.endswith('cpu.max'):
+            q['cgroup_cpu_max'] = ' '.join(txt)
+            if txt and txt[0] != 'max' and len(txt) > 1 and float(txt[1]) > 0:
+                q['cgroup_cpus'] = round(float(txt[0]) / float(txt[1]), 2)
+        else:
+            try:
+                period = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                q['cgroup_cpu_max'] = '%s %d' % (txt[0], int(period))
+                if float(txt[0]) > 0 and period > 0:
+                    q['cgroup_cpus'] = round(float(txt[0]) / period, 2)
+            except Exception:
+                pass
+        break
+    return q
+
+
+def smi_sclk_mhz():
+    """Best effort: the shader clock rocm-smi reports right now (None when the tool or the permission is missing)."""
+    import re
+    import subprocess
+    try:
+        r = subprocess.run(['rocm-smi', '--showclocks'], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=10)
+        m = re.search(r'sclk clock level:?\s*\d*:?\s*\(?(\d+)\s*Mhz', r.stdout, flags=re.I)
+        return int(m.group(1)) if m else None
+    except Exception:
+        return None
+
+
+def sustained_probe(step, n, dev_index, seconds=3.0, est_ms=1.3):
+    """Reported beside the headline: the SAME step looped for >= `seconds` of GPU time (a cohort runs for hours, the headline
+    region is a 26 ms burst), with the shader clock the chip held DURING the loop: a one-wave probe (ukbb_fcn_clock_probe:
+    s_memtime against the 100 MHz s_memrealtime) on a stream of its own while the steps are queued on the bench stream."""
+    import torch
+    from ukbb_cardiac_amd import _lib
+    side = torch.cuda.Stream(torch.device('cuda', dev_index))
+    chunk = max(8, int(0.25 / (est_ms * 1e-3)))                       # about a quarter second of steps per enqueue round
+    clocks, smi = [], []
+    done = 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while True:
+        for _ in range(chunk):
+            step()
+        done += chunk
+        # the probe's wave runs next to the queued steps; its host-side wait returns after ~0.2 ms, the bench stream stays full
+        try:
+            clocks.append(_lib.clock_probe_mhz(dev_index, side.cuda_stream, 200))
+        except Exception:
+            pass
+        if time.perf_counter() - t0 >= seconds:
+            break
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    s = smi_sclk_mhz()                                                 # right behind the loop (the tool itself takes ~0.1-1 s)
+    clocks.sort()
+    med = clocks[len(clocks) // 2] if clocks else None
+    return {'value': round(n * done / dt, 1), 'unit': 'slices/s', 'steps': done, 'seconds': round(dt, 3), 'ms_per_step': round(dt / done * 1e3, 4),
+            'shader_clock_mhz_in_loop': None if med is None else round(med, 1),
+            'shader_clock_samples_mhz': [round(c) for c in clocks],
+            'rocm_smi_sclk_mhz_after_loop': s,
+            'note': 'same step, same resident batch, looped for %.1f s; clock = median of one-wave s_memtime / s_memrealtime probes that ran '
+                    'beside the queued steps' % dt}
+
+
 def physical_cores():
     try:
         import psutil
@@ -157,7 +235,9 @@ def cpu_baseline():
     name = max(ok, key=lambda k: ok[k]['value'])
     best = ok[name]
     return {'value': best['value'], 'unit': best['unit'], 'cores': best['cores'], 'kind': 'port',
-            'sample': 'fastest of the CPU legs (%s): %s' % (name, best['sample']), 'legs': legs}
+            'sample': 'fastest of the CPU legs (%s): %s' % (name, best['sample']), 'legs': legs,
+            # what the host let this job use: a weak CPU figure on a 128-core box is usually a container quota
+            'cpu_quota': cpu_quota()}
 
 
 def inflight_probe(arch, params, x, n, steps):
@@ -289,6 +369,12 @@ def main():
                     help='after the timed region also measure the same steps with two batches in flight on two streams '
                          '(extra field two_batches_in_flight; off by default so that a rocprofv3 trace of the default command '
                          'holds single-stream launches only)')
+    ap.add_argument('--sustained-seconds', type=float, default=3.0,
+                    help='after the timed steps loop the same step for this long and report it as out["sustained"] with the shader clock '
+                         'observed during the loop (0 = skip)')
+    ap.add_argument('--rehearsal', action='store_true',
+                    help='allow several ranks on one GPU (the 1-GPU rehearsal of the N > 1 launch); without it two ranks that report '
+                         'the same PCI bus id make the run fail')
     ap.add_argument('--cpu-leg', choices=['torch', 'c'], default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_leg:
@@ -374,6 +460,27 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed_max = float(t.item())
+    # per-rank evidence for whoever reads the N > 1 line: which device each rank ran on and how long ITS K steps took
+    props = torch.cuda.get_device_properties(dev_index)
+    bus = None
+    if all(hasattr(props, k) for k in ('pci_domain_id', 'pci_bus_id', 'pci_device_id')):
+        bus = '%04x:%02x:%02x' % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
+    mine = {'rank': rank, 'local_rank': local_rank, 'device_index': dev_index, 'device_name': props.name, 'pci_bus_id': bus,
+            'uuid': str(getattr(props, 'uuid', '')) or None, 'visible_devices': ndev, 'pid': os.getpid(),
+            'ms_per_step': round(elapsed / args.steps * 1e3, 4)}
+    ranks = [mine]
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
+    ids = [r['pci_bus_id'] or r['uuid'] or 'dev%d' % r['device_index'] for r in ranks]
+    shared = len(set(ids)) < len(ids)
+    if shared and not args.rehearsal:
+        if rank == 0:
+            print('bench.py: %d ranks but only %d distinct GPUs %s -- pass --rehearsal if that is intended (not a scaling measurement)'
+                  % (world, len(set(ids)), sorted(set(ids))), file=sys.stderr, flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        sys.exit(3)
 
     m3, m1 = fcn_macs_per_slice(arch, H, W)
     roofline = None
@@ -441,9 +548,23 @@ def main():
             'e2e_effective_tflops_reference_graph': round(value * flops_per_slice / 1e12, 2),
             'e2e_effective_frac_reference_graph': round(value * flops_per_slice / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world), 4),
             'roofline': roofline,
+            'backend': ('gloo' if oversub else 'nccl (RCCL)') if world > 1 else None,
+            'ranks': ranks, 'per_rank_ms_per_step': [r['ms_per_step'] for r in ranks],
         }
         if detail:
             out['roofline_detail'] = detail
+        if world == 1 and args.sustained_seconds > 0:
+            try:
+                sus = sustained_probe(step, n, dev_index, args.sustained_seconds, elapsed_max / args.steps * 1e3)
+                out['sustained'] = sus
+                if roofline and sus.get('shader_clock_mhz_in_loop'):
+                    ghz = sus['shader_clock_mhz_in_loop'] / 1e3
+                    peak_obs = props.multi_processor_count * 4 * 64 * ghz / 1e3       # CUs x SIMDs x FLOP/clk x GHz -> TFLOP/s
+                    roofline['peak_at_observed_clock'] = round(peak_obs, 1)
+                    roofline['frac_at_observed_clock'] = round(roofline['achieved'] / peak_obs, 4)
+                    roofline['observed_clock_mhz'] = sus['shader_clock_mhz_in_loop']
+            except Exception as e:
+                out['sustained'] = {'error': repr(e)[-300:]}
         if world == 1 and args.inflight_probe:
             out['two_batches_in_flight'] = inflight_probe(arch, params, x, n, args.steps)
         if world == 1 and not args.no_f32x3_probe:

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define UKBB_FCN_ABI_VERSION 4
+#define UKBB_FCN_ABI_VERSION 5
 #define UKBB_FCN_MAX_LEVEL 8
 
 #define UKBB_OK 0
@@ -258,6 +258,12 @@ int ukbb_fcn_kernel_times(ukbb_fcn_handle *h, double *sum_ms, int64_t *count, in
  * "up3".."up0" (UNet decoder outputs).  Returns the number of floats, or a
  * negative error; with dst == NULL only the size is returned. */
 int64_t ukbb_fcn_get_activation(ukbb_fcn_handle *h, const char *name, float *dst, int64_t cap);
+
+/* Shader clock the chip holds RIGHT NOW (bench.py, next to its roofline: the MFMA peak scales with it).  Launches one wave on
+ * `stream` that spins for about spin_us microseconds and compares the shader-cycle counter (s_memtime) with the constant 100 MHz
+ * counter (s_memrealtime); waits for that wave only.  Run it on a stream of its own while the measured work is queued on another:
+ * a single extra wave does not disturb it.  *mhz = the shader clock in MHz.  No reference counterpart (measurement only). */
+int ukbb_fcn_clock_probe(int device, void *stream, int spin_us, double *mhz);
 
 #ifdef __cplusplus
 }

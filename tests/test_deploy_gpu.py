@@ -181,8 +181,11 @@ def test_bench_two_rank_launch_rehearsal():
     env-driven ranks, one JSON line from rank 0 only, n_gpus = 2, value = slices of BOTH ranks over the max-over-ranks time."""
     import json
     port = 29600 + os.getpid() % 300
-    r = _run(['-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
-              os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2', '--no-cpu-baseline'])
+    cmd = ['-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
+              os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2', '--no-cpu-baseline']
+    import torch
+    one_gpu = torch.cuda.device_count() < 2
+    r = _run(cmd + (['--rehearsal'] if one_gpu else []))
     assert r.returncode == 0, r.stdout[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -190,9 +193,19 @@ def test_bench_two_rank_launch_rehearsal():
     assert j['n_gpus'] == 2 and j['steps'] == 4 and j['scaling'] == 'weak' and j['config']['slices_per_gpu_per_step'] == 64
     assert abs(j['value'] - 2 * 64 * 4 / (j['ms_per_step'] * 4e-3)) <= 0.01 * j['value']
     assert 'cpu_baseline' not in j                        # rank 0 at N = 1 only
-    import torch
-    if torch.cuda.device_count() < 2:
-        assert 'REHEARSAL' in j['config']['parallelism']
+    # r04: per-rank evidence -- every rank's device, bus id and own time; the headline time is the slowest rank's
+    assert [q['rank'] for q in j['ranks']] == [0, 1] and len(j['per_rank_ms_per_step']) == 2
+    assert all(q['device_name'] and q['visible_devices'] >= 1 and q['ms_per_step'] > 0 for q in j['ranks'])
+    assert max(j['per_rank_ms_per_step']) <= j['ms_per_step'] * 1.001
+    assert len({q['pid'] for q in j['ranks']}) == 2
+    if one_gpu:
+        assert 'REHEARSAL' in j['config']['parallelism'] and j['backend'] == 'gloo'
+        assert j['ranks'][0]['pci_bus_id'] == j['ranks'][1]['pci_bus_id']
+        # without the flag two ranks on one GPU are refused: a scaling line cannot come from shared devices by accident
+        refused = _run(cmd)
+        assert refused.returncode != 0 and '--rehearsal' in refused.stdout
+    else:
+        assert j['backend'].startswith('nccl') and len({q['pci_bus_id'] for q in j['ranks']}) == 2
     # a mismatch between --gpus and the launched world size is refused
     bad = _run([os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'])
     assert bad.returncode != 0 and 'torch.distributed.run' in bad.stdout

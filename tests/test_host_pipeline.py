@@ -679,7 +679,7 @@ def test_output_csv_equals_the_evaluation_script_on_the_written_files(tmp_path):
 
 def test_aortic_output_csv_equals_the_evaluation_script_formulas(tmp_path):
     """deploy_network_ao.py --output_csv [--pressure_csv]: aortic/eval_aortic_area.py:60-95 on the written files (the script's
-    quality control is not applied -- stated in the flag's help)."""
+    quality control switched off here: test_aortic_output_csv_applies_the_count_only_quality_control covers it)."""
     from ukbb_cardiac_amd import measures
     names = ['1001', '1002', '1003']
     (tmp_path / 'd').mkdir()
@@ -690,7 +690,7 @@ def test_aortic_output_csv_equals_the_evaluation_script_formulas(tmp_path):
                     '1001,40,44,1\n1002,,38,2\n1003,5,7,3\n')
     out = str(tmp_path / 'ao.csv')
     F, _ = DA.define_flags().parse(['--data_dir', str(tmp_path / 'd'), '--model', 'UNet', '--model_path', 'x', '--io_threads', '0',
-                                    '--output_csv', out, '--pressure_csv', str(pcsv)])
+                                    '--output_csv', out, '--pressure_csv', str(pcsv), '--noaortic_qc'])
     DA.run(F, stub_forward, log=lambda *_: None)
     pp = {'1001': 42.0, '1002': 38.0, '1003': float('nan')}
     want = []
@@ -705,6 +705,80 @@ def test_aortic_output_csv_equals_the_evaluation_script_formulas(tmp_path):
             line += [A.max(), A.min(), (A.max() - A.min()) / (A.min() * pp[n]) * 1e3]
         want.append(line)
     assert open(out).read() == _pandas_csv(str(tmp_path / 'pd.csv'), want, names, measures.AO_COLUMNS)
+
+
+def test_aorta_qc_from_counts_follows_the_script_criteria():
+    """cardiac_utils.aorta_pass_quality_control criteria 1, 4, 5 (reference common/cardiac_utils.py:1741-1749,1782-1795) on per-frame
+    areas: order per label (AAo first), the wrap-around of criterion 4 (frame 0 against the last frame), the script's messages."""
+    from ukbb_cardiac_amd.measures import aorta_qc_from_counts
+    T = 6
+    good = np.stack([np.full(T, 500), np.array([100, 110, 120, 130, 120, 105]), np.array([80, 82, 85, 90, 86, 81])], axis=1)
+    assert aorta_qc_from_counts(good) == (True, '')
+    c = good.copy(); c[3, 2] = 0                                   # DAo vanishes in frame 3
+    assert aorta_qc_from_counts(c) == (False, 'The area of DAo is 0 at time frame 3.')
+    c = good.copy(); c[2, 1] = 0; c[3, 2] = 0                      # AAo is checked first
+    assert aorta_qc_from_counts(c) == (False, 'The area of AAo is 0 at time frame 2.')
+    c = good.copy(); c[4, 1] = 260                                 # 260 / 130 = 2: abrupt change at frame 4 (>= 2)
+    assert aorta_qc_from_counts(c) == (False, 'There is abrupt change of area at time frame 4.')
+    c = good.copy(); c[:, 1] = [100, 120, 144, 172, 190, 201]      # smooth steps, but frame 0 / LAST frame = 100 / 201 <= 0.5:
+    assert aorta_qc_from_counts(c) == (False, 'There is abrupt change of area at time frame 0.')      # the script's A[t-1] wraps
+    c = good.copy(); c[:, 2] = [100, 120, 144, 172, 190, 150]      # every step < 2x, wrap 100/150 fine, max / min = 1.9 -> passes
+    assert aorta_qc_from_counts(c) == (True, '')
+    c[:, 2] = [100, 130, 165, 200, 160, 125]                       # max / min = 2.0 with no abrupt step: criterion 5
+    assert aorta_qc_from_counts(c) == (False, 'There is large change of area between maximum and minimum areas.')
+
+
+def test_aortic_output_csv_applies_the_count_only_quality_control(tmp_path):
+    """deploy_network_ao.py --output_csv drops the subjects eval_aortic_area.py:68-69 would drop on criteria 1 / 4 / 5, prints the
+    script's message, keeps the others; a subject missing from the pressure spreadsheet is reported, not silently left empty."""
+    from ukbb_cardiac_amd import measures
+    names = ['2001', '2002', '2003']
+    (tmp_path / 'd').mkdir()
+    for i, n in enumerate(names):
+        _write_subject(tmp_path / 'd', n, 'ao', (40, 36, 1, 6), 11 + i)
+    # a forward whose labels depend on the subject: 2002 loses its DAo in frame 2, the others get steady discs
+    def forward(batch):
+        n = batch.shape[0]
+        pred = np.zeros(batch.shape[:3], np.int32)
+        cy, cx = batch.shape[1] // 2, batch.shape[2] // 2          # the 40 x 36 cine sits centred in the 256 x 256 pad (deploy_network_ao.py:105-107)
+        pred[:, cy - 16:cy - 6, cx - 14:cx - 4] = 1
+        pred[:, cy + 2:cy + 12, cx + 2:cx + 10] = 2
+        prob = np.zeros(batch.shape[:3] + (3,), np.float32)
+        np.put_along_axis(prob, pred[..., None], 1.0, axis=-1)
+        return {'prob': prob, 'pred': pred}
+    state = {'subject': None, 'frame': 0}
+    lines = []
+    def log(*a):                                               # the script prints the subject's name before it works on it (:137)
+        line = ' '.join(str(x) for x in a)
+        lines.append(line)
+        if line in names:
+            state['subject'], state['frame'] = line, 0
+    def forward_2002_breaks(batch):
+        out = forward(batch)
+        for k in range(batch.shape[0]):
+            if state['subject'] == '2002' and state['frame'] + k == 2:
+                out['pred'][k][out['pred'][k] == 2] = 0
+                out['prob'][k] = 0.0
+                np.put_along_axis(out['prob'][k], out['pred'][k][..., None], 1.0, axis=-1)
+        state['frame'] += batch.shape[0]
+        return out
+    pcsv = tmp_path / 'p.csv'
+    pcsv.write_text('eid,Central pulse pressure during PWA,Central pulse pressure during PWA\n,12678-2.0,12678-2.1\n2001,40,44\n2002,30,30\n')
+    out = str(tmp_path / 'ao.csv')
+    F, _ = DA.define_flags().parse(['--data_dir', str(tmp_path / 'd'), '--model', 'UNet', '--model_path', 'x', '--io_threads', '0',
+                                    '--output_csv', out, '--pressure_csv', str(pcsv)])
+    DA.run(F, forward_2002_breaks, log=log)
+    rows = open(out).read().splitlines()
+    assert [r.split(',')[0] for r in rows[1:]] == ['2001', '2003']
+    assert any('The area of DAo is 0 at time frame 2.' in l for l in lines)
+    assert any('2003' in l and 'pressure spreadsheet' in l for l in lines)
+    assert rows[1].split(',')[3] != '' and rows[2].split(',')[3] == ''       # distensibility: 2001 has a pulse pressure, 2003 has none
+    assert measures.AO_COLUMNS[0] in rows[0]
+    # --noaortic_qc: every segmented subject gets its row
+    F2, _ = DA.define_flags().parse(['--data_dir', str(tmp_path / 'd'), '--model', 'UNet', '--model_path', 'x', '--io_threads', '0',
+                                     '--output_csv', out, '--noaortic_qc'])
+    DA.run(F2, forward_2002_breaks, log=log)
+    assert [r.split(',')[0] for r in open(out).read().splitlines()[1:]] == names
 
 
 def test_label_gzip_small_never_loses_to_zlib_on_noise(tmp_path):
@@ -747,3 +821,32 @@ def test_label_gzip_clean_under_address_and_ub_sanitizers(tmp_path):
                         'degenerate_histograms or run_lengths_and_crc or modes_inflate_identically or never_loses_to_zlib'],
                        env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0 and ' passed' in r.stdout and 'ERROR: AddressSanitizer' not in r.stdout and 'runtime error' not in r.stdout, r.stdout[-3000:]
+
+
+def test_stale_tmp_files_of_dead_writers_are_swept_and_noise_fallback_keeps_the_header(tmp_path):
+    """(a) a worker killed mid-write leaves ``<name>.tmp.<pid>.<tid>`` behind; the next writer of that target removes it
+    (files of live processes stay); (b) when 'small' keeps the zlib stream on a noise-like volume the file still starts with the
+    10-byte header of the other writers (no name, no time, OS = 255), so it is cmp-identical to a --label_gzip zlib run."""
+    import gzip
+    import subprocess
+    import sys
+    from ukbb_cardiac_amd import nifti
+    target = tmp_path / 'seg_sa.nii.gz'
+    p = subprocess.Popen([sys.executable, '-c', 'pass']); p.wait()        # a pid that no longer exists
+    dead = tmp_path / ('seg_sa.nii.gz.tmp.%d.12345' % p.pid)
+    dead.write_bytes(b'x' * 100)
+    alive = tmp_path / ('seg_sa.nii.gz.tmp.%d.777' % os.getppid())       # the parent is alive: not ours to touch
+    alive.write_bytes(b'y')
+    lab = np.random.default_rng(7).integers(0, 4, size=(48, 40, 3, 4)).astype(np.uint8)
+    raws = {}
+    try:
+        for mode in ('small', 'zlib'):
+            nifti.set_label_gzip(mode)
+            nifti.save(lab, str(target), np.eye(4), as_dtype=np.float64)
+            raws[mode] = target.read_bytes()
+            assert not dead.exists() and alive.exists()
+    finally:
+        nifti.set_label_gzip('small')
+    assert raws['small'][:10] == raws['zlib'][:10] == bytes([0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 4, 0xff])
+    assert gzip.decompress(raws['small']) == gzip.decompress(raws['zlib'])
+    assert raws['small'] == raws['zlib']                                  # noise: 'small' kept zlib's stream, byte for byte the zlib-mode file

@@ -12,7 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('UKBB_FCN_LIB') or os.path.join(_HERE, 'libukbb_fcn.so')   # override: A/B builds of the kernels
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_LEVEL = 8
 
 # every symbol include/ukbb_fcn.h declares
@@ -25,7 +25,7 @@ EXPORTS = [
     'ukbb_fcn_select_kth', 'ukbb_fcn_rescale_pack', 'ukbb_fcn_unpack_labels',
     'ukbb_fcn_roi_compact', 'ukbb_fcn_pairwise_sum', 'ukbb_fcn_zscore_pack',
     'ukbb_fcn_gzip_labels_bound', 'ukbb_fcn_gzip_labels', 'ukbb_fcn_gzip_labels_mode',
-    'ukbb_fcn_forward_seq', 'ukbb_fcn_forward_cine',
+    'ukbb_fcn_forward_seq', 'ukbb_fcn_forward_cine', 'ukbb_fcn_clock_probe',
 ]
 
 
@@ -105,6 +105,7 @@ def _load():
     lib.ukbb_fcn_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int, C.c_int]
     lib.ukbb_fcn_get_activation.restype = C.c_int64
     lib.ukbb_fcn_get_activation.argtypes = [vp, C.c_char_p, f32p, C.c_int64]
+    lib.ukbb_fcn_clock_probe.argtypes = [C.c_int, vp, C.c_int, C.POINTER(C.c_double)]
     if lib.ukbb_fcn_abi_version() != ABI_VERSION:
         raise ImportError('libukbb_fcn.so ABI %d != binding ABI %d: rebuild' % (lib.ukbb_fcn_abi_version(), ABI_VERSION))
     return lib
@@ -125,6 +126,13 @@ def check(rc: int, what: str):
     if rc < 0:
         raise UkbbFcnError('%s failed (%d): %s' % (what, rc, last_error()))
     return rc
+
+
+def clock_probe_mhz(device: int = 0, stream: int = 0, spin_us: int = 200) -> float:
+    """Shader clock the chip holds right now (ukbb_fcn_clock_probe): one wave spinning on `stream` for spin_us microseconds."""
+    mhz = C.c_double(0.0)
+    check(lib.ukbb_fcn_clock_probe(int(device), C.c_void_p(stream), int(spin_us), C.byref(mhz)), 'ukbb_fcn_clock_probe')
+    return float(mhz.value)
 
 
 def f32ptr(a: np.ndarray):

@@ -124,6 +124,7 @@ struct ukbb_fcn_handle {
     int precision = 0;                        // 0: fp32; 1: bf16 operands for the MFMA convs (fp32 accumulate); 2: fp32 from bf16 pieces (head)
     int plan_h = 0, plan_w = 0, cap_n = 0;
     bool plan_small = false;                  // plan built with the small-batch tilings
+    int plan_n = 0;                           // ... for this largest batch
     int max_n = 0;                            // largest batch this handle was asked for (reserve / forward): the small-batch plan is
                                               // used only while that stays <= SMALL_BATCH, so a large-batch caller's tail batches do
                                               // not flip the plan (a rebuild re-allocates the workspace) back and forth
@@ -139,8 +140,6 @@ struct ukbb_fcn_handle {
     long long lstm_aux_key = -1;              // which tables lstm_aux holds (shape-keyed, uploaded once per shape)
 
     // image-slice streams (experiment UKBB_SPLIT, run_plan): consecutive conv ops run as S independent image ranges on S streams
-    std::vector<hipStream_t> split_streams;
-    std::vector<hipEvent_t> split_ev;         // [0] fork, [1..S] joins
     // side stream for kernels that only feed the head (sqg_l): fork after level l, join before the head
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> ev_fork, ev_join;
@@ -158,8 +157,6 @@ struct ukbb_fcn_handle {
         for (auto e : ev) (void)hipEventDestroy(e);
         for (auto e : ev_fork) (void)hipEventDestroy(e);
         for (auto e : ev_join) (void)hipEventDestroy(e);
-        for (auto e : split_ev) (void)hipEventDestroy(e);
-        for (auto st : split_streams) (void)hipStreamDestroy(st);
         if (side) (void)hipStreamDestroy(side);
     }
 };
@@ -279,7 +276,7 @@ const Tuned g_tuned_large[] = {
     {3, 1, 16, 16, 11, -1, -1}, {3, 2, 16, 32, 120, 123, -1},  {3, 1, 32, 32, 301, -1, -1},
     {3, 2, 32, 64, 124, 123, 142, 145},  {3, 1, 64, 64, 300, -1, -1},  {3, 2, 64, 128, 124, 123, 142, 145},
     {3, 1, 128, 128, 300, -1, -1},  {3, 2, 128, 256, 124, 123, 142, 145}, {3, 1, 256, 256, 300, -1, -1},
-};      // r03: 13x16 tiles (145) divide the 208x256 pyramid (52x64, 26x32, 13x16: conv2_0 118 -> 89 us, conv3_0 / conv4_0 -6 / -5);
+};      // r03: 13x16 tiles (145) divide the 208x256 pyramid (52x64, 26x32, 13x16: conv2_0 112 -> 86 us, conv3_0 / conv4_0 -6 / -7 at N = 64);
         // r02: the stride-2 layers moved to the producer/consumer kernel once its loads ran two stages ahead (profiles/r02_notes.md);
         // its straight-line producer needs tiles that divide the map: 12x13 tiles for the 192x208 pyramid, 8x16 (123) for the
         // power-of-two maps of the aortic U-Net (256x256: 148 / 143 / 133 / 136 us instead of 184 / 208 / 159 / 156 at N = 100),
@@ -519,6 +516,20 @@ int ensure_packed(ukbb_fcn_handle *h, int layer, const ConvConfig &c, const floa
 // on the other graphs: bf16 operands, fp32 storage (r01).
 int bf16_mode(const ukbb_fcn_handle *h) { return h->precision != 1 ? 0 : h->arch.kind == UKBB_KIND_UNET ? 2 : 1; }
 
+// bf16 storage: the fused variants of the level-0 tilings (ConvConfig::fuse: 1 = first layer in the staging, 2 = logits in the
+// epilogue), first fit in measured order; -1 if none fits (the plan then keeps that layer as a launch of its own).
+int pick_fused_bf_cfg(const std::string &lname, int ks, int stride, int c0, int c1, int cout, int Ho, int Wo, int fuse_bf) {
+    const int forced = override_cfg(lname);
+    // fused logits: the persistent kernel first (kernels_bf16.hip: 104-110 vs 124 us), then the tile-per-workgroup tilings in
+    // measured order; fused first layer: tile-per-workgroup only (its persistent form was no faster, r03_notes.md)
+    for (int cand : {forced, fuse_bf == 1 ? 296 : 325, fuse_bf == 1 ? 294 : 324, fuse_bf == 1 ? 295 : 298, fuse_bf == 1 ? -1 : 297, fuse_bf == 1 ? -1 : 299}) {
+        ConvConfig cc;
+        if (cand >= 0 && find_cfg(cand, cc) == 0 && cfg_valid(cc, ks, stride, c0, c1, cout, false, 2, fuse_bf) &&
+            (cand == forced || tile_fit_ok(cc, Ho, Wo))) return cand;
+    }
+    return -1;
+}
+
 int add_conv(ukbb_fcn_handle *h, const std::string &lname, int in0, int in1, int c1, int H, int W, int stride,
              int n_hint, int *out_buf, bool fused_first = false, bool fused_logits = false) {
     const int li = h->layer_index.at(lname);
@@ -533,18 +544,8 @@ int add_conv(ukbb_fcn_handle *h, const std::string &lname, int in0, int in1, int
     const int c0 = L.cin - c1;
     op.fused_first = fused_first;
     const int fuse_bf = bf16_mode(h) != 2 ? 0 : fused_first ? 1 : fused_logits ? 2 : 0;
-    if (fuse_bf) {
-        // bf16 storage: the fused variants of the level-0 tilings (ConvConfig::fuse), first fit in measured order
-        op.cfg = -1;
-        const int forced = override_cfg(lname);
-        // fused logits: the persistent kernel first (kernels_bf16.hip: 104-110 vs 124 us), then the tile-per-workgroup tilings in
-        // measured order; fused first layer: tile-per-workgroup only (its persistent form was no faster, r03_notes.md)
-        for (int cand : {forced, fuse_bf == 1 ? 296 : 325, fuse_bf == 1 ? 294 : 324, fuse_bf == 1 ? 295 : 298, fuse_bf == 1 ? -1 : 297, fuse_bf == 1 ? -1 : 299}) {
-            ConvConfig cc;
-            if (cand >= 0 && find_cfg(cand, cc) == 0 && cfg_valid(cc, L.ks, stride, c0, c1, L.cout, false, 2, fuse_bf) &&
-                (cand == forced || tile_fit_ok(cc, op.Ho, op.Wo))) { op.cfg = cand; break; }
-        }
-    } else
+    if (fuse_bf) op.cfg = pick_fused_bf_cfg(lname, L.ks, stride, c0, c1, L.cout, op.Ho, op.Wo, fuse_bf);
+    else
     op.cfg = choose_cfg(lname, L.ks, stride, c0, c1, L.cout, op.Ho, op.Wo, n_hint, fused_first, bf16_mode(h));
     op.fused_logits = fuse_bf == 2;
     if (op.cfg < 0) { set_err("no conv tiling for layer %s (ks %d stride %d cin %d+%d cout %d)", lname.c_str(), L.ks, stride, c0, c1, L.cout); return UKBB_EARCH; }
@@ -614,7 +615,9 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
             snprintf(nm, sizeof nm, "conv%d_%d", l, i);
             const int stride = (l > 0 && i == 0) ? 2 : 1;
             static const bool no_fuse = getenv("UKBB_NO_FUSE_FIRST") != nullptr;    // A/B knob
-            const bool can_fuse = !no_fuse && a.n_block[0] >= 2 && a.n_filter[0] == 16;
+            // bf16 storage: only if a fused tiling fits conv0_1 at this size (otherwise conv0_0 runs as its own launch, bf16 out)
+            const bool can_fuse = !no_fuse && a.n_block[0] >= 2 && a.n_filter[0] == 16 &&
+                                  (bf16_mode(h) != 2 || pick_fused_bf_cfg("conv0_1", 3, 1, 16, 0, 16, H, W, 1) >= 0);
             if (l == 0 && i == 0) {
                 if (can_fuse) continue;              // evaluated inside conv0_1's producers
                 Op op; op.kind = OP_FIRST; op.name = nm; op.layer = h->layer_index.at(nm);
@@ -693,7 +696,7 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
                 static const bool no_fuse_lg = getenv("UKBB_NO_FUSE_LOGITS") != nullptr;    // A/B knob
                 // bf16 storage: logits + softmax / argmax ride in the epilogue of the very last conv (its output is never stored)
                 const bool flg = a.kind == UKBB_KIND_UNET && bf16_mode(h) == 2 && !no_fuse_lg && l == 0 && i == a.n_block[0] - 1 &&
-                                 i > 0 && a.n_filter[0] == 16;
+                                 i > 0 && a.n_filter[0] == 16 && pick_fused_bf_cfg(nm, 3, 1, 16, 0, 16, lh[0], lw[0], 2) >= 0;
                 rc = (i == 0) ? add_conv(h, nm, level_out[l], t, a.n_filter[l], lh[l], lw[l], 1, n_hint, &x)
                               : add_conv(h, nm, x, -1, 0, lh[l], lw[l], 1, n_hint, &x, false, flg);
                 if (rc) return rc;
@@ -731,7 +734,7 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
             }
         }
     }
-    h->plan_h = H; h->plan_w = W; h->plan_small = n_hint <= SMALL_BATCH;
+    h->plan_h = H; h->plan_w = W; h->plan_small = n_hint <= SMALL_BATCH; h->plan_n = n_hint;
     h->plan_bfio = bf16_mode(h) == 2;
     // events
     for (auto e : h->ev) (void)hipEventDestroy(e);
@@ -765,7 +768,9 @@ int prepare(ukbb_fcn_handle *h, int n, int H, int W) {
     if (rc) return rc;
     HIP_TRY(hipSetDevice(h->device), UKBB_EDEVICE);
     if (n > h->max_n) h->max_n = n;
-    if (H != h->plan_h || W != h->plan_w || (h->max_n <= SMALL_BATCH) != h->plan_small) {
+    // the finer siblings of the small-batch plan are chosen from the work items at the largest batch seen (finer_sibling): while the
+    // handle stays in the small regime a larger batch re-plans (a handle first used at N = 1 must not keep halved items at N = 16)
+    if (H != h->plan_h || W != h->plan_w || (h->max_n <= SMALL_BATCH) != h->plan_small || (h->plan_small && h->max_n > h->plan_n)) {
         HIP_TRY(hipDeviceSynchronize(), UKBB_EDEVICE);
         rc = build_plan(h, H, W, h->max_n);
         if (rc) { h->plan_h = h->plan_w = 0; return rc; }
@@ -806,40 +811,9 @@ int run_plan(ukbb_fcn_handle *h, const float *image, int n, float *logits, float
     }
     hipStream_t s_main = s;
     bool forked = false;
-    // Experiment (r03): UKBB_SPLIT="conv3_0:conv4_2:4" runs the conv ops from..to as 4 independent image
-    // ranges on 4 streams (halo dependencies never cross images), so that the fixed cost of each of the dependent launches of one
-    // range (dispatch, L2 write-back, first-load latency, tail) is filled by the other ranges' kernels -- without any
-    // inter-workgroup waiting inside a kernel (a persistent chain with spin barriers can deadlock as soon as two such
-    // kernels share the GPU: two handles on two streams, two worker processes per GPU).  Result: profiles/r03_notes.md.
-    static const struct Split { std::string from, to; int S = 0; } split = [] {
-        Split sp; const char *e = getenv("UKBB_SPLIT");
-        if (e) { std::string v(e); size_t a1 = v.find(':'), a2 = v.rfind(':');
-                 if (a1 != std::string::npos && a2 > a1) { sp.from = v.substr(0, a1); sp.to = v.substr(a1 + 1, a2 - a1 - 1); sp.S = atoi(v.c_str() + a2 + 1); } }
-        return sp; }();
-    int sp_from = -1, sp_to = -1;
-    if (split.S > 1 && n >= 2 * split.S) {
-        for (size_t i = 0; i < h->ops.size(); ++i) {
-            if (h->ops[i].name == split.from) sp_from = (int)i;
-            if (h->ops[i].name == split.to) sp_to = (int)i;
-        }
-        for (int i = sp_from; sp_from >= 0 && i <= sp_to; ++i)
-            if (h->ops[i].kind != OP_CONV || h->ops[i].fused_first || h->ops[i].fused_logits || h->ops[i].on_side) sp_from = -1;
-        if (sp_from < 0 || sp_to < sp_from) sp_from = sp_to = -1;
-        if (sp_from >= 0 && (int)h->split_streams.size() < split.S) {
-            h->split_streams.resize(split.S, nullptr);
-            for (auto &st : h->split_streams) if (!st) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), UKBB_EDEVICE);
-            h->split_ev.resize(split.S + 1, nullptr);
-            for (auto &ev : h->split_ev) if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming), UKBB_EDEVICE);
-        }
-    }
     for (size_t i = 0; i < h->ops.size(); ++i) {
         const Op &op = h->ops[i];
         s = s_main;
-        const bool in_split = sp_from >= 0 && (int)i >= sp_from && (int)i <= sp_to;
-        if (in_split && (int)i == sp_from) {
-            HIP_TRY(hipEventRecord(h->split_ev[0], s_main), UKBB_EDEVICE);
-            for (int k = 0; k < split.S; ++k) HIP_TRY(hipStreamWaitEvent(h->split_streams[k], h->split_ev[0], 0), UKBB_EDEVICE);
-        }
         if (op.on_side) {                              // fork: side stream waits for everything issued so far
             if (!h->side) {
                 HIP_TRY(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking), UKBB_EDEVICE);
@@ -888,23 +862,6 @@ int run_plan(ukbb_fcn_handle *h, const float *image, int n, float *logits, float
                 ca.pad_y = op.pad_y; ca.pad_x = op.pad_x;
                 ca.tiles_y = (op.Ho + c.th - 1) / c.th; ca.tiles_x = (op.Wo + c.tw - 1) / c.tw;
                 ca.relu = L.relu ? 1 : 0;
-                if (in_split) {
-                    const size_t in_pi = h->act_per_image[op.in0], out_pi = h->act_per_image[op.out];
-                    const size_t in1_pi = op.in1 >= 0 ? h->act_per_image[op.in1] : 0;
-                    for (int k = 0; k < split.S && e == hipSuccess; ++k) {
-                        const int n0 = (int)((long long)k * n / split.S), n1 = (int)((long long)(k + 1) * n / split.S);
-                        ConvArgs cs = ca;
-                        cs.N = n1 - n0; cs.in0 = ca.in0 + n0 * in_pi; cs.out = ca.out + n0 * out_pi;
-                        if (ca.in1) cs.in1 = ca.in1 + n0 * in1_pi;
-                        e = launch_conv(op.cfg, cs, h->split_streams[k]);
-                    }
-                    if (e == hipSuccess && (int)i == sp_to)
-                        for (int k = 0; k < split.S; ++k) {
-                            HIP_TRY(hipEventRecord(h->split_ev[k + 1], h->split_streams[k]), UKBB_EDEVICE);
-                            HIP_TRY(hipStreamWaitEvent(s_main, h->split_ev[k + 1], 0), UKBB_EDEVICE);
-                        }
-                    break;
-                }
                 e = launch_conv(op.cfg, ca, s);
                 break;
             }

@@ -249,8 +249,8 @@ __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM,
     // input channels are relu(BN(conv3x3(image))) (network_ao.py:31-35 with l = 0, i = 0) evaluated here for every halo pixel:
     // the raw (IH+2) x (IW+2) tile goes to LDS, then per 16 halo pixels three v_mfma_f32_16x16x4_f32 (fp32-exact; A = the
     // [16 x 12] folded filter with taps 9..11 zero, B = the lane's pixel at tap k, bias as the C operand) give a lane 4
-    // consecutive channels of its pixel, which are rounded to bf16 once -- exactly what the stand-alone first-layer kernel would
-    // have stored -- and written into the halo tile.  conv0_0's output (420 MB per 100 slices, written + re-read) never exists.
+    // consecutive channels of its pixel, which are rounded to bf16 once -- what the stand-alone first-layer kernel would have
+    // stored up to the fp32 summation order (MFMA with the bias as C against an fmaf chain plus bias) -- and written into the halo tile.  conv0_0's output (420 MB per 100 slices, written + re-read) never exists.
     constexpr bool fusedf = FUSE == 1;
     // first stage requested before anything else: in the fused form the packed weights travel while the raw tile is fetched and
     // the first layer is evaluated

@@ -471,6 +471,33 @@ int ukbb_fcn_pairwise_sum(const float *d_a, uint64_t n, int squared_dev, float m
     return UKBB_OK;
 }
 
+// ---- shader clock under load (measurement only) ----
+static __global__ void clock_probe_kernel(unsigned long long *out, unsigned long long spin_ticks) {
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < spin_ticks) { __builtin_amdgcn_s_sleep(32); r1 = __builtin_amdgcn_s_memrealtime(); }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = r1 - r0; }
+}
+
+int ukbb_fcn_clock_probe(int device, void *stream, int spin_us, double *mhz) {
+    if (!mhz || spin_us < 1 || spin_us > 1000000) { set_error("clock_probe: bad arguments"); return UKBB_EINVAL; }
+    unsigned long long *d = nullptr, h[2] = {0, 0};
+    hipStream_t s = (hipStream_t)stream;
+    if (hipSetDevice(device) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&d), 16) != hipSuccess) {
+        set_error("clock_probe: no HIP device %d (there is no CPU fallback)", device);
+        return UKBB_EDEVICE;
+    }
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, s, d, (unsigned long long)spin_us * 100ull);   // s_memrealtime: 100 MHz
+    const bool ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, s) == hipSuccess &&
+                    hipStreamSynchronize(s) == hipSuccess;
+    (void)hipFree(d);
+    if (!ok || h[1] == 0) { set_error("clock_probe: device error"); return UKBB_EDEVICE; }
+    *mhz = (double)h[0] / (double)h[1] * 100.0;
+    return UKBB_OK;
+}
+
 int ukbb_fcn_zscore_pack(const float *d_vol, int X, int Y, int Z, int T, int64_t sx, int64_t sy, int64_t sz, int64_t st,
                          float mu, float den, int X2, int Y2, int x_pre, int y_pre, float *d_batch, void *stream) {
     if (!d_vol || !d_batch || X < 1 || Y < 1 || Z < 1 || T < 1 || x_pre < 0 || y_pre < 0 || X2 < X + x_pre || Y2 < Y + y_pre ||

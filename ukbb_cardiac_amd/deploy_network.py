@@ -54,7 +54,7 @@ def define_flags():
     fs.DEFINE_enum('precision', 'fp32', ['fp32', 'f32x3'], 'Arithmetic of the matrix products: fp32 MFMA (default) or fp32 results from three '
                    'bf16 pieces per operand (UKBB_PREC_F32X3, include/ukbb_fcn.h; same labels, faster head).')
     fs.DEFINE_enum('label_gzip', 'small', list(nifti.LABEL_GZIP_MODES), 'Deflate of the label volumes: small = run-length tokens + dynamic Huffman '
-                   '(size of zlib level 1 or below, ~20x less CPU), fast = fixed Huffman (2-4x larger files), zlib = as nibabel. Same inflated bytes.')
+                   '(typically below the size of zlib level 1, ~20x less CPU), fast = fixed Huffman (2-4x larger files), zlib = as nibabel. Same inflated bytes.')
     fs.DEFINE_string('output_csv', '', '--seq_name sa, sequence mode: also write the spreadsheet of short_axis/eval_ventricular_volume.py '
                      '(same columns, same arithmetic) from the per-frame class counts the GPU leaves behind -- no second pass over '
                      'seg_sa.nii.gz.  Subjects already segmented by an earlier run are measured from their files.')

@@ -51,10 +51,13 @@ def define_flags():
                    'accumulation (UKBB_PREC_BF16, include/ukbb_fcn.h; --model UNet: bf16 activations in HBM too, 2.8x the fp32 rate, '
                    'Dice 0.99 against fp32; BASELINE config 5).')
     fs.DEFINE_enum('label_gzip', 'small', list(nifti.LABEL_GZIP_MODES), 'Deflate of the label volumes: small = run-length tokens + dynamic Huffman '
-                   '(size of zlib level 1 or below), fast = fixed Huffman (larger files), zlib = as nibabel.  Same inflated bytes.')
+                   '(typically below the size of zlib level 1; never above it on segmentation-like volumes), fast = fixed Huffman (larger files), zlib = as nibabel.  Same inflated bytes.')
     fs.DEFINE_string('output_csv', '', 'Sequence mode: also write the spreadsheet of aortic/eval_aortic_area.py (same columns and arithmetic) from '
-                     'the per-frame class counts the GPU leaves behind.  The evaluation script\'s quality control '
-                     '(cardiac_utils.aorta_pass_quality_control) is NOT applied: every segmented subject gets a row.')
+                     'the per-frame class counts the GPU leaves behind.  Of the evaluation script\'s quality control '
+                     '(cardiac_utils.aorta_pass_quality_control, eval_aortic_area.py:68-69) the criteria that need only the areas are applied '
+                     '(1: zero area in a frame, 4: abrupt change between adjacent frames, 5: max / min >= 2) and a failing subject is dropped with '
+                     'the script\'s message; criteria 2 (image noise) and 3 (connected components) are NOT applied.')
+    fs.DEFINE_boolean('aortic_qc', True, 'With --output_csv: apply the count-only quality-control criteria above (false: every segmented subject gets a row).')
     fs.DEFINE_string('pressure_csv', '', 'With --output_csv: the blood-pressure spreadsheet of eval_aortic_area.py:41-46 for the distensibility columns '
                      '(left empty without it).')
     fs.DEFINE_integer('num_shards', env_cnt, 'Number of workers sharing data_dir.')
@@ -62,14 +65,18 @@ def define_flags():
     return fs
 
 
-def _pp(central_pp, data):
+def _pp(central_pp, data, log=print):
     """central_pp.loc[int(data)] of eval_aortic_area.py:80; None (no distensibility) when no spreadsheet was given."""
     if not central_pp:
         return None
     try:
-        return central_pp.get(str(int(data)), float('nan'))
+        key = str(int(data))
     except ValueError:
-        return central_pp.get(str(data), float('nan'))
+        key = str(data)
+    if key not in central_pp:
+        # the reference's central_pp.loc[int(data)] raises KeyError here and the whole evaluation stops; this script keeps the areas
+        log('  Warning: subject {0} is not in the pressure spreadsheet: distensibility left empty.'.format(data))
+    return central_pp.get(key, float('nan'))
 
 
 def run(FLAGS, forward, log=print, cine_forward=None, engine=None):
@@ -93,6 +100,15 @@ def run(FLAGS, forward, log=print, cine_forward=None, engine=None):
             raise ValueError('--output_csv writes the table of aortic/eval_aortic_area.py: it needs sequence mode')
         csv_rows = {}
         central_pp = measures.read_central_pp(FLAGS.pressure_csv) if getattr(FLAGS, 'pressure_csv', '') else {}
+
+        def _qc_row(counts, pixdim, pp):
+            """The subject's table line, or None when the count-only quality control drops it (the script's own message is printed)."""
+            if getattr(FLAGS, 'aortic_qc', True):
+                ok, why = measures.aorta_qc_from_counts(counts)
+                if not ok:
+                    log(why)
+                    return None
+            return measures.ao_row(counts, pixdim, pp)
     # Sequence mode with --io_threads > 0: the next cines are read (inflated) by reader threads while the GPU works on this one,
     # and the segmentation files are written behind it; order of subjects, log lines and files are those of the sequential loop.
     nthr = int(getattr(FLAGS, 'io_threads', 0)) if FLAGS.process_seq else 0
@@ -167,7 +183,7 @@ def run(FLAGS, forward, log=print, cine_forward=None, engine=None):
             if csv_rows is not None:
                 if counts is None:
                     counts = measures.counts_from_labels(pred, 3)
-                csv_rows[data] = measures.ao_row(counts, nim.header['pixdim'], _pp(central_pp, data))
+                csv_rows[data] = _qc_row(counts, nim.header['pixdim'], _pp(central_pp, data, log))
         else:
             if FLAGS.model == 'UNet-LSTM':                             # reference: deploy_network_ao.py:202-205
                 log('UNet-LSTM does not support frame-wise segmentation. Please use the -process_seq flag.')
@@ -201,11 +217,15 @@ def run(FLAGS, forward, log=print, cine_forward=None, engine=None):
             data_dir = os.path.join(FLAGS.data_dir, data)
             image_name, seg_name = os.path.join(data_dir, 'ao.nii.gz'), os.path.join(data_dir, 'seg_ao.nii.gz')
             if data in csv_rows:
-                rows.append((data, csv_rows[data]))
+                row = csv_rows[data]
             elif os.path.exists(image_name) and os.path.exists(seg_name):
+                log(data)
                 seg = nifti.load(seg_name).get_data()
-                rows.append((data, measures.ao_row(measures.counts_from_labels(seg, 3), nifti.load_header(image_name)['pixdim'],
-                                                   _pp(central_pp, data))))
+                row = _qc_row(measures.counts_from_labels(seg, 3), nifti.load_header(image_name)['pixdim'], _pp(central_pp, data, log))
+            else:
+                continue
+            if row is not None:                                 # None: dropped by the quality control, as eval_aortic_area.py:68-69
+                rows.append((data, row))
         path = measures.shard_csv_name(FLAGS.output_csv, FLAGS.shard_index, FLAGS.num_shards)
         measures.write_csv(path, measures.AO_COLUMNS, rows)
         log('Aortic areas of {0} subjects written to {1}'.format(len(rows), path))

@@ -71,6 +71,29 @@ def ao_row(counts, pixdim, central_pp=None):
             v['DAo']['max area'], v['DAo']['min area'], v['DAo'].get('distensibility', nan)]
 
 
+def aorta_qc_from_counts(counts):
+    """The criteria of cardiac_utils.aorta_pass_quality_control (reference common/cardiac_utils.py:1739-1796, called by
+    aortic/eval_aortic_area.py:68-69) that need nothing but the per-frame areas, in the script's order per label (AAo = 1, then
+    DAo = 2): 1 -- the area is 0 in no frame (:1741-1749); 4 -- no adjacent-frame area ratio >= 2 or <= 0.5, frame 0 against the LAST
+    frame as the script's A[t-1] does (:1782-1788); 5 -- max / min area < 2 (:1790-1795).  Criteria 2 (intensity ratio) and 3
+    (connected components) need the image / the label map itself and are NOT applied here.
+    counts: [T, 3].  Returns (passed, message) with the script's own message for the first failing criterion."""
+    counts = np.asarray(counts)
+    T = counts.shape[0]
+    for l_name, l in (('AAo', 1), ('DAo', 2)):
+        A = counts[:, l]
+        for t in range(T):
+            if A[t] == 0:
+                return False, 'The area of {0} is 0 at time frame {1}.'.format(l_name, t)
+        for t in range(T):
+            ratio = A[t] / float(A[t - 1])
+            if ratio >= 2 or ratio <= 0.5:
+                return False, 'There is abrupt change of area at time frame {0}.'.format(t)
+        if np.max(A) / np.min(A) >= 2:
+            return False, 'There is large change of area between maximum and minimum areas.'
+    return True, ''
+
+
 def counts_from_labels(seg, n_class):
     """[T, n_class] voxel counts of a (X,Y,Z,T) label volume: what np.sum(seg == k, axis=(0, 1, 2)) gives the scripts."""
     seg = np.asarray(seg)

@@ -72,6 +72,35 @@ def _tmp_name(path):
     return '%s.tmp.%d.%d' % (path, os.getpid(), threading.get_ident())
 
 
+def _sweep_stale_tmp(path):
+    """Remove ``<path>.tmp.<pid>.<thread>`` files whose writing process no longer exists: what a worker killed mid-write (the case
+    _AtomicFile exists for) leaves behind; without this, reruns accumulate multi-megabyte partial files in the subject directories.
+    Files of live processes (another worker writing the same target right now) are left alone."""
+    d, base = os.path.split(path)
+    prefix = base + '.tmp.'
+    try:
+        names = os.listdir(d or '.')
+    except OSError:
+        return
+    for nm in names:
+        if not nm.startswith(prefix):
+            continue
+        pid = nm[len(prefix):].split('.')[0]
+        if not pid.isdigit() or int(pid) == os.getpid():
+            continue
+        try:
+            os.kill(int(pid), 0)                               # signal 0: existence check only
+            continue                                            # alive: not ours to touch
+        except ProcessLookupError:
+            pass
+        except OSError:                                         # e.g. EPERM: exists under another user
+            continue
+        try:
+            os.remove(os.path.join(d, nm))
+        except OSError:
+            pass
+
+
 class _AtomicFile:
     """Binary output file that only appears under its final name once it is complete: written as
     ``<path>.tmp.<pid>.<thread>`` and ``os.replace``d into place on a clean exit, removed otherwise.  A worker
@@ -80,6 +109,7 @@ class _AtomicFile:
 
     def __init__(self, path):
         self.path, self.tmp = str(path), _tmp_name(str(path))
+        _sweep_stale_tmp(self.path)
         self.f = open(self.tmp, 'wb')
 
     def write(self, b):
@@ -344,8 +374,9 @@ def save(img_or_data, path, affine=None, pixdim=None, as_dtype=None):
 # ---- label volumes: run-length gzip writer of the C library ---------------------------------------------------------
 LABEL_FAST_PATH = True     # tests switch it off to compare with the zlib path
 # How a label volume's .nii.gz is deflated (deploy scripts: --label_gzip).  All three inflate to the same bytes.
-#   'small' (default)  run-length tokens, dynamic Huffman codes from the exact token histogram: the size of zlib level 1 or
-#                      below, ~20x less CPU than zlib for the float64 volumes of the sequence loop
+#   'small' (default)  run-length tokens, dynamic Huffman codes from the exact token histogram: typically below the size of zlib
+#                      level 1 (checked against zlib only above NOISE_FRACTION, where the zlib stream is kept if smaller),
+#                      ~20x less CPU than zlib for the float64 volumes of the sequence loop
 #   'fast'             run-length tokens, fixed Huffman codes: no counting pass, files 2-4x larger
 #   'zlib'             zlib level 1 over the converted volume, as nibabel writes it
 LABEL_GZIP_MODE = 'small'
@@ -398,12 +429,20 @@ def _save_labels_gz(lab, datatype_code, prefix, path):
             if mode == _labelgz.DYNAMIC and got > NOISE_FRACTION * (len(prefix) + n * itemsize):
                 # noise-like labels (runs of 1-2 voxels): zlib's cross-row matches can beat run-length tokens there; such a
                 # volume is not a segmentation, but 'small' keeps its promise (<= zlib level 1) by taking the smaller stream
-                z = zlib.compressobj(GZIP_LEVEL, zlib.DEFLATED, 31)
+                # raw deflate between the SAME 10-byte header the other two writers emit (GzipFile(mtime=0, filename='') and
+                # csrc/label_gzip.cpp: no name, no time, OS = 255) and the CRC-32 / ISIZE trailer: files of the three paths
+                # stay comparable with cmp
+                z = zlib.compressobj(GZIP_LEVEL, zlib.DEFLATED, -15)
                 le = np.dtype('<' + _DTYPES[datatype_code])
-                parts = [z.compress(prefix)]
+                xfl = 4 if GZIP_LEVEL == 1 else 2 if GZIP_LEVEL == 9 else 0
+                parts = [bytes([0x1f, 0x8b, 8, 0, 0, 0, 0, 0, xfl, 0xff]), z.compress(prefix)]
+                crc, size = zlib.crc32(prefix), len(prefix)
                 for i in range(0, n, 1 << 20):
-                    parts.append(z.compress(flat[i:i + (1 << 20)].astype(le).tobytes()))
+                    piece = flat[i:i + (1 << 20)].astype(le).tobytes()
+                    crc, size = zlib.crc32(piece, crc), size + len(piece)
+                    parts.append(z.compress(piece))
                 parts.append(z.flush())
+                parts.append(int(crc & 0xffffffff).to_bytes(4, 'little') + int(size & 0xffffffff).to_bytes(4, 'little'))
                 zb = b''.join(parts)
                 if len(zb) < got:
                     blob = zb
