@@ -314,7 +314,11 @@ bool cfg_valid(const ConvConfig &c, int ks, int stride, int c0, int c1, int cout
     if (c.pc == 5 || c.pc == 6) cout = round_up(cout, 32);         // 16-channel layers run zero-padded on the 32-row MFMA
     if (c.pc == 6) {                                  // weight-stationary: the Cout group's whole packed filter + the waves' rings in LDS
         const int nch = (c0 + c1) / 16;
-        if (ks != 3 || stride != 1 || (c1 && c1 != c0) || (c0 + c1) % 16 || (nch != 1 && nch != 2 && nch != 4 && nch != 8) || (c1 && nch < 2)) return false;
+        if (stride != 1 || (c0 + c1) % 16) return false;
+        if (ks == 2) {                                // transposed conv as 2x2 sub-pixel conv: cout = 4 x real channels (16, or multiples of 32)
+            const int real = cout / 4;
+            if (c1 || cout % 64 || (real != 16 && real % 32) || (real == 16 ? nch != 2 : (nch != 4 && nch != 8))) return false;
+        } else if (ks != 3 || (c1 && c1 != c0) || (nch != 1 && nch != 2 && nch != 4 && nch != 8) || (c1 && nch < 2)) return false;
         if (cout % (32 * c.cb)) return false;
         return ws_lds_bytes_for(c, c0 + c1) <= 160 * 1024;
     }
@@ -379,7 +383,7 @@ const Tuned g_tuned_bfio[] = {
     {3, 1, 256, 256, 239, 232, -1}, {3, 1, 256, 128, 239, 232, -1}, {3, 1, 128, 64, 400, 239, 232},  {3, 1, 64, 32, 401, 232, -1},
     {3, 1, 32, 16, 401, 236, 232},
     {3, 2, 16, 32, 241, -1, -1},    {3, 2, 32, 64, 242, 241, -1},   {3, 2, 64, 128, 244, 241, -1},  {3, 2, 128, 256, 244, 241, -1},
-    {2, 1, 256, 512, 253, 251, -1}, {2, 1, 128, 256, 253, 251, -1}, {2, 1, 64, 128, 253, 251, -1},  {2, 1, 32, 64, 258, 253, 251},
+    {2, 1, 256, 512, 253, 251, -1}, {2, 1, 128, 256, 411, 253, 251}, {2, 1, 64, 128, 411, 253, 251},  {2, 1, 32, 64, 410, 258, 253},
 };
 
 int choose_cfg_raw(const std::string &layer, int ks, int stride, int c0, int c1, int cout, int Ho, int Wo, int N,
@@ -575,22 +579,34 @@ int add_tconv(ukbb_fcn_handle *h, const std::string &lname, int in0, int H, int 
     ConvConfig c;
     find_cfg(op.cfg, c);
     char key[128];
-    const bool bfpk = c.pc == 3 || c.pc == 5;
-    snprintf(key, sizeof key, "%s/pk2x2%s_mb%d_kc%d_g%d", L.name.c_str(), bfpk ? "bf16" : "", c.mb, c.kc, c.wm * c.cb);
+    const bool bfpk = c.pc == 3 || c.pc == 5 || c.pc == 6;
+    const bool paired = c.pc == 6;                    // weight-stationary tilings: virtual channels in the paired block order (wst_pack_order)
+    snprintf(key, sizeof key, "%s/pk2x2%s%s_mb%d_kc%d_g%d", L.name.c_str(), bfpk ? "bf16" : "", paired ? "ws" : "", c.mb, c.kc, c.wm * c.cb);
+    const std::string bkey = lname + (paired ? "/bias4ws" : "/bias4");
     if (!dev_ptr(h, key)) {
-        std::vector<float> w2((size_t)4 * L.cin * 4 * L.cout), pk(w2.size());
+        const int vc = 4 * L.cout;
+        std::vector<float> w2((size_t)4 * L.cin * vc), pk(w2.size());
         tconv_as_conv2x2(L.w.data(), L.cin, L.cout, w2.data());
-        if (bfpk) pack_conv_weights_bf16(w2.data(), 2, L.cin, 4 * L.cout, c.wm * c.cb, pk.data());
-        else pack_conv_weights(w2.data(), 2, L.cin, 4 * L.cout, c.mb, c.kc, c.wm * c.cb, pk.data());
+        std::vector<float> b4((size_t)vc);
+        for (int ph = 0; ph < 4; ++ph) std::copy(L.b.begin(), L.b.end(), b4.begin() + (size_t)ph * L.cout);
+        if (paired) {
+            std::vector<float> w2p(w2.size()), b4p(b4.size());
+            for (int v = 0; v < vc; ++v) {
+                const int src = wst_pack_order(L.cout, v);
+                b4p[v] = b4[src];
+                for (size_t r = 0; r < (size_t)4 * L.cin; ++r) w2p[r * vc + v] = w2[r * vc + src];
+            }
+            w2.swap(w2p); b4.swap(b4p);
+        }
+        if (bfpk) pack_conv_weights_bf16(w2.data(), 2, L.cin, vc, c.wm * c.cb, pk.data());
+        else pack_conv_weights(w2.data(), 2, L.cin, vc, c.mb, c.kc, c.wm * c.cb, pk.data());
         int rc = upload(h, key, pk);
         if (rc) return rc;
-        std::vector<float> b4((size_t)4 * L.cout);
-        for (int ph = 0; ph < 4; ++ph) std::copy(L.b.begin(), L.b.end(), b4.begin() + (size_t)ph * L.cout);
-        rc = upload(h, lname + "/bias4", b4);
+        rc = upload(h, bkey, b4);
         if (rc) return rc;
     }
     op.wpk = dev_ptr(h, key);
-    op.bias = dev_ptr(h, lname + "/bias4");
+    op.bias = dev_ptr(h, bkey);
     op.out = new_act(h, lname, (size_t)4 * H * W * L.cout, L.cout);
     op.macs_per_image = (double)H * W * 9 * L.cin * L.cout;
     h->ops.push_back(op);

@@ -121,6 +121,7 @@ hipError_t launch_conv16_pk(int cfg_id, const ConvArgs &a, hipStream_t s);
 int num_ws_configs();
 const ConvConfig &ws_config(int i);
 int ws_lds_bytes_for(const ConvConfig &c, int cin);
+int wst_pack_order(int cout, int v);    // transposed-conv tilings (ids 410-, ks 2): source column of packed virtual channel v
 hipError_t launch_conv_ws(int cfg_id, const ConvArgs &a, hipStream_t s);
 // cout handled by one workgroup = mb*cb*wm
 hipError_t launch_conv(int cfg_id, const ConvArgs &a, hipStream_t s);

@@ -25,6 +25,14 @@
 // Fragment layouts and packed weights are those of conv_mfma_kernel<..., BFIO> (pack_conv_weights_bf16 with ncbl = CB);
 // the accumulation order over (chunk, tap) differs (kw outermost inside a chunk), so results agree with that kernel to fp32
 // rounding of the accumulator, not bit for bit.
+//
+// KIND = 1 is the same machine for conv2d_transpose 3x3 stride 2 'SAME' + BN + ReLU (reference common/network.py:28-34 as used
+// by network_ao.py:48-49) in its 4-phase sub-pixel form (kernels.h, tconv_as_conv2x2): a tile is R INPUT rows x 32 input pixels
+// (2R x 64 outputs), the halo is one row above and one column left, the four 2x2 taps (a, b) read input (m + a - 1, x + b - 1),
+// and output phase (py, px) uses tap (a, b) only if (py == 0 || a == 1) && (px == 0 || b == 1): 9 of the 16 (tap, phase) pairs.
+// A workgroup owns TWO 32-row blocks of the 4 x Cout phase-major "virtual" channels, paired so that every workgroup has about the
+// same work -- {phase 00, phase 11} (4 + 1 taps) or {phase 01, phase 10} (2 + 2) of one 32-channel slice; for Cout = 16 the
+// blocks are {00 + 01} and {10 + 11} -- and the zero (tap, phase) pairs are skipped at COMPILE time (one specialisation per pairing).
 #include "kernels.h"
 
 #include <algorithm>
@@ -58,23 +66,44 @@ __device__ __forceinline__ void unroll_steps(F &&f) {
 }
 
 constexpr int WS_TW = 32;                               // tile width = one 32-pixel MFMA block per image row
-constexpr int WS_IW = WS_TW + 2;                        // halo row
-
-__host__ __device__ constexpr int ws_nld(int r) { return (2 * (r + 2) * WS_IW + 63) / 64; }     // 16-byte pieces per lane and stage
+// KIND 0: 3x3 stride 1 (halo R + 2 rows x 34 pixels, 9 taps); KIND 1: transposed conv as 2x2 sub-pixel conv (R + 1 rows x 33 pixels, 4 taps)
+__host__ __device__ constexpr int ws_hr(int kind, int r) { return kind == 0 ? r + 2 : r + 1; }
+__host__ __device__ constexpr int ws_iw(int kind) { return kind == 0 ? WS_TW + 2 : WS_TW + 1; }
+__host__ __device__ constexpr int ws_taps(int kind) { return kind == 0 ? 9 : 4; }
+__host__ __device__ constexpr int ws_hp(int kind, int r) { return ws_hr(kind, r) * ws_iw(kind); }
+__host__ __device__ constexpr int ws_nld(int kind, int r) { return (2 * ws_hp(kind, r) + 63) / 64; }     // 16-byte pieces per lane and stage
 // one k-half plane of a stage: halo pixels x 16 bytes, padded so that the planes lie an odd multiple of 64 bytes apart modulo 128: the
 // 8 lanes of a ds_write_b128 group (4 pixels x 2 halves) then fall on 8 different 16-byte slots
-__host__ __device__ constexpr int ws_plane_bytes(int r) { return ((r + 2) * WS_IW * 16 / 128) * 128 + 64 + ((r + 2) * WS_IW * 16 % 128 > 64 ? 128 : 0); }
-__host__ __device__ constexpr int ws_stage_bytes(int r) { return (2 * ws_plane_bytes(r) + 32 + 127) / 128 * 128; }
-__host__ __device__ constexpr int ws_lds_bytes(int r, int cb, int nw, int nch) {
-    return nch * cb * 9 * 1024 + cb * 128 + nw * 2 * ws_stage_bytes(r);
+__host__ __device__ constexpr int ws_plane_bytes(int kind, int r) {
+    return (ws_hp(kind, r) * 16 / 128) * 128 + 64 + (ws_hp(kind, r) * 16 % 128 > 64 ? 128 : 0);
+}
+__host__ __device__ constexpr int ws_stage_bytes(int kind, int r) { return (2 * ws_plane_bytes(kind, r) + 32 + 127) / 128 * 128; }
+__host__ __device__ constexpr int ws_lds_bytes(int kind, int r, int cb, int nw, int nch) {
+    return nch * cb * ws_taps(kind) * 1024 + cb * 128 + nw * 2 * ws_stage_bytes(kind, r);
 }
 
-// R: output rows per tile; CB: 32-channel Cout blocks per workgroup (and per wave); NW: waves (= independent workers) per workgroup;
-// NCH: 16-channel chunks of the input (both sources together); TWO: chunks NCH/2.. come from the second source (C0 == C1)
-template <int R, int CB, int NW, int NCH, bool TWO>
-__global__ __launch_bounds__(NW * 64, NW / 4) void conv_ws_kernel(const ConvArgs a) {
-    constexpr int HP = (R + 2) * WS_IW, NLD = ws_nld(R), STAGE = ws_stage_bytes(R), PLANE = ws_plane_bytes(R);
-    constexpr int WSLAB = NCH * CB * 9 * 1024;          // bytes: [chunk][cb][tap][lane][16]
+// Transposed conv (KIND 1): does block `blk` of pairing TM use tap (a, b)?  TM 0: blocks {phase 00, phase 11}; TM 1: {01, 10};
+// TM 2 (Cout = 16, a block holds two phases): {00 + 01, 10 + 11}.  Phase (py, px) uses (a, b) iff (py == 0 || a == 1) && (px == 0 || b == 1).
+__host__ __device__ constexpr bool wst_needed(int tm, int blk, int a, int b) {
+    return tm == 0 ? (blk == 0 ? true : (a == 1 && b == 1))
+         : tm == 1 ? (blk == 0 ? b == 1 : a == 1)
+                   : (blk == 0 ? true : a == 1);
+}
+// first tap of a block in step order (b outer, a inner): its MFMA takes the bias as C
+__host__ __device__ constexpr bool wst_first(int tm, int blk, int a, int b) {
+    for (int bb = 0; bb < 2; ++bb)
+        for (int aa = 0; aa < 2; ++aa)
+            if (wst_needed(tm, blk, aa, bb)) return aa == a && bb == b;
+    return false;
+}
+
+// KIND: 0 = 3x3 stride 1, 1 = transposed conv (sub-pixel 2x2); TM: KIND 1 only, the block pairing (wst_needed)
+template <int KIND, int R, int CB, int NW, int NCH, bool TWO, int TM>
+__device__ __forceinline__ void ws_main(const ConvArgs &a, const int grp, const int walker, const int nwalk) {
+    constexpr int WS_IW = ws_iw(KIND), HR = ws_hr(KIND, R), TAPS = ws_taps(KIND);
+    constexpr int HP = HR * WS_IW, NLD = ws_nld(KIND, R), STAGE = ws_stage_bytes(KIND, R), PLANE = ws_plane_bytes(KIND, R);
+    constexpr int WSLAB = NCH * CB * TAPS * 1024;       // bytes: [chunk][cb][tap][lane][16]
+    static_assert(KIND == 0 || CB == 2, "transposed conv: two paired blocks per workgroup");
     constexpr int TPB = NCH % 2 ? 2 : 1;                // tiles per unrolled loop body (the body covers an even number of chunks)
     constexpr int U = TPB * NCH;
     static_assert(!TWO || NCH % 2 == 0, "two sources: equal halves");
@@ -96,18 +125,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_ws_kernel(const ConvArgs
     const int g = lane >> 5, pl = lane & 31;
     unsigned char *const ring = lds + WSLAB + CB * 128 + wave * (2 * STAGE);
 
-    // ---- workgroup -> (Cout group, walker).  Workgroups b and b + 8 share an XCD (observed round-robin placement, speed only):
-    //      the nG workgroups that walk the same tiles with different Cout groups are given equal b % 8 so that a tile is fetched
-    //      into ONE per-XCD L2.
-    const int nG = a.Cout / (32 * CB);
-    int grp, walker;
-    const int nwalk = (int)gridDim.x / nG;              // the launcher makes the grid a multiple of nG
-    if ((int)gridDim.x % (8 * nG) == 0) {
-        const int j = (int)blockIdx.x >> 3;
-        grp = j % nG; walker = ((int)blockIdx.x & 7) + 8 * (j / nG);
-    } else {
-        grp = (int)blockIdx.x % nG; walker = (int)blockIdx.x / nG;
-    }
     const int tiles = a.tiles_x * a.tiles_y, ntiles = a.N * tiles;
     // wave-major numbering: when the tiles do not divide evenly the workers with one tile more are spread one wave per workgroup
     // (one SIMD of a CU carries 7 tiles, the others 6) instead of filling whole workgroups (8 against 6)
@@ -194,8 +211,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_ws_kernel(const ConvArgs
     // chunk.  At step T the read of step T + PD goes out into buffer (T + PD) % NB; the A fragments of the next (chunk, kw) group go
     // out at the first step of the current group into the other A set.  sched_barrier pins the order (hipcc would sink the reads to
     // their first use); its counted lgkmcnt(n) waits then leave the younger reads in flight.
-    constexpr int S = 3 * (R + 2), PD = 3, NB = 4;
-    static_assert((U * S) % NB == 0 && (U * 3) % 2 == 0, "fragment buffers rotate consistently across loop iterations");
+    // KIND 0: step = (kw, halo row rp): S = 3 HR, an A group = the three kh taps of column kw.
+    // KIND 1: step = (b, halo row rp): S = 2 HR, an A group = the two taps (a, b), a = 0, 1.
+    constexpr int NGRP = KIND == 0 ? 3 : 2, NAF = KIND == 0 ? 3 : 2;
+    constexpr int S = NGRP * HR, PD = 3, NB = 4;
+    static_assert((U * S) % NB == 0 && (U * NGRP) % 2 == 0, "fragment buffers rotate consistently across loop iterations");
     f32x16 acc[CB][R], biasv[CB];
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
@@ -207,35 +227,44 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_ws_kernel(const ConvArgs
         }
     const unsigned char *const xs_lane = ring + g * PLANE + pl * 16;
     const unsigned char *const ws_lane = ws + lane * 16;
-    u32x4 Bq[NB], Aq[2][CB][3];
+    u32x4 Bq[NB], Aq[2][CB][NAF];
     auto readB = [&](auto tc) {                         // step TT of the body (>= U * S: the first steps of the next loop iteration)
-        constexpr int TT = decltype(tc)::value, T = TT % (U * S), Qn = T / S, s = T % S, kw = s / (R + 2), rp = s % (R + 2);
+        constexpr int TT = decltype(tc)::value, T = TT % (U * S), Qn = T / S, s = T % S, kw = s / HR, rp = s % HR;
         Bq[TT % NB] = *reinterpret_cast<const u32x4 *>(xs_lane + (Qn & 1) * STAGE + (rp * WS_IW + kw) * 16);
     };
-    auto readA = [&](auto gc) {                         // (chunk, kw) group GG of the body
-        constexpr int GG = decltype(gc)::value, G = GG % (U * 3), CH = (G / 3) % NCH, kw = G % 3;
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
-                Aq[GG & 1][cb][kh] = *reinterpret_cast<const u32x4 *>(ws_lane + ((CH * CB + cb) * 9 + kh * 3 + kw) * 1024);
+    auto readA = [&](auto gc) {                         // (chunk, kw | b) group GG of the body
+        constexpr int GG = decltype(gc)::value, G = GG % (U * NGRP), CH = (G / NGRP) % NCH, kw = G % NGRP;
+        unroll_steps<CB>([&](auto cbc) {
+            constexpr int cb = decltype(cbc)::value;
+            unroll_steps<NAF>([&](auto kc) {
+                constexpr int kh = decltype(kc)::value;     // KIND 1: kh = a, kw = b
+                constexpr int tap = KIND == 0 ? kh * 3 + kw : kh * 2 + kw;
+                if constexpr (KIND == 0 || wst_needed(TM, cb, kh, kw))
+                    Aq[GG & 1][cb][kh] = *reinterpret_cast<const u32x4 *>(ws_lane + ((CH * CB + cb) * TAPS + tap) * 1024);
+            });
+        });
     };
     auto compute = [&](auto qc) {                       // position Q of the body: chunk Q % NCH from ring stage Q & 1
         constexpr int Q = decltype(qc)::value, CH = Q % NCH;
         unroll_steps<S>([&](auto sc) {
-            constexpr int s = decltype(sc)::value, T = Q * S + s, kw = s / (R + 2), rp = s % (R + 2), G = Q * 3 + kw;
+            constexpr int s = decltype(sc)::value, T = Q * S + s, kw = s / HR, rp = s % HR, G = Q * NGRP + kw;
             readB(std::integral_constant<int, T + PD>{});
             if constexpr (rp == 0) readA(std::integral_constant<int, G + 1>{});
             __builtin_amdgcn_sched_barrier(0);
-            unroll_steps<3>([&](auto khc) {
+            unroll_steps<NAF>([&](auto khc) {
                 constexpr int kh = decltype(khc)::value, r = rp - kh;
                 if constexpr (r >= 0 && r < R) {
-#pragma unroll
-                    for (int cb = 0; cb < CB; ++cb) {
+                    unroll_steps<CB>([&](auto cbc) {
+                        constexpr int cb = decltype(cbc)::value;
                         // the folded-BN bias is the C operand of an accumulator's first MFMA of the tile (no zeroing, no bias adds)
-                        if constexpr (CH == 0 && kw == 0 && kh == 0) acc[cb][r] = mfma_bf16(Aq[G & 1][cb][kh], Bq[T % NB], biasv[cb]);
-                        else acc[cb][r] = mfma_bf16(Aq[G & 1][cb][kh], Bq[T % NB], acc[cb][r]);
-                    }
+                        if constexpr (KIND == 0) {
+                            if constexpr (CH == 0 && kw == 0 && kh == 0) acc[cb][r] = mfma_bf16(Aq[G & 1][cb][kh], Bq[T % NB], biasv[cb]);
+                            else acc[cb][r] = mfma_bf16(Aq[G & 1][cb][kh], Bq[T % NB], acc[cb][r]);
+                        } else if constexpr (wst_needed(TM, cb, kh, kw)) {
+                            if constexpr (CH == 0 && wst_first(TM, cb, kh, kw)) acc[cb][r] = mfma_bf16(Aq[G & 1][cb][kh], Bq[T % NB], biasv[cb]);
+                            else acc[cb][r] = mfma_bf16(Aq[G & 1][cb][kh], Bq[T % NB], acc[cb][r]);
+                        }
+                    });
                 }
             });
             __builtin_amdgcn_sched_barrier(0);
@@ -245,17 +274,27 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_ws_kernel(const ConvArgs
     //      are tile independent (pixel column and channel of the lane); the tile's row offsets are scalar (soffset); rows below the map
     //      and ghost tiles store through a descriptor of range 0, columns right of the map / channels beyond the real count through an
     //      out-of-range lane offset: dropped by the hardware, no branch.
-    const int cst = a.cout_store > 0 ? a.cout_store : a.Cout;
     unsigned char *const outb = reinterpret_cast<unsigned char *>(a.out);
-    const int out_plane_bytes = a.Ho * a.Wo * 32, out_img_bytes = (cst / 16) * out_plane_bytes;     // channel-blocked like the inputs
+    // KIND 0: cst real channels at the input's resolution.  KIND 1: a.up2 real channels at twice the resolution; the accumulator rows
+    // are (phase, channel) pairs: the phase picks the output pixel (2 m + py, 2 x + px), the channel the plane and the offset in it.
+    const int cst = KIND == 1 ? a.up2 : a.cout_store > 0 ? a.cout_store : a.Cout;
+    const int OW = KIND == 1 ? 2 * a.Wo : a.Wo, OH = KIND == 1 ? 2 * a.Ho : a.Ho;
+    const int out_plane_bytes = OH * OW * 32, out_img_bytes = (cst / 16) * out_plane_bytes;     // channel-blocked like the inputs
     unsigned svoff[CB][4];
-#pragma unroll
-    for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int chn = (grp * CB + cb) * 32 + 8 * j + 4 * g;
-            svoff[cb][j] = chn < cst ? (unsigned)((chn >> 4) * out_plane_bytes + pl * 32 + (chn & 15) * 2) : OOB;
-        }
+    unroll_steps<CB>([&](auto cbc) {
+        constexpr int cb = decltype(cbc)::value;
+        unroll_steps<4>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (KIND == 0) {
+                const int chn = (grp * CB + cb) * 32 + 8 * j + 4 * g;
+                svoff[cb][j] = chn < cst ? (unsigned)((chn >> 4) * out_plane_bytes + pl * 32 + (chn & 15) * 2) : OOB;
+            } else {
+                constexpr int ph = TM == 0 ? (cb == 0 ? 0 : 3) : TM == 1 ? (cb == 0 ? 1 : 2) : 2 * cb + (j >> 1);
+                const int co = TM == 2 ? 8 * (j & 1) + 4 * g : (grp >> 1) * 32 + 8 * j + 4 * g;
+                svoff[cb][j] = (unsigned)((co >> 4) * out_plane_bytes + (2 * pl + (ph & 1)) * 32 + (co & 15) * 2);
+            }
+        });
+    });
     const int relu_lo = a.relu ? 0 : (int)0x80000000;   // max_i32(bits, 0) = ReLU; max_i32(bits, INT_MIN) = identity
     auto epilogue = [&](int k) {
         int n, oy0, ox0;
@@ -267,15 +306,20 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_ws_kernel(const ConvArgs
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
             for (int j = 0; j < 4; ++j) vo[cb][j] = colok ? svoff[cb][j] : OOB;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
+        unroll_steps<R>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
             const int oy = oy0 + r;
             const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)obase, 0, (valid && oy < a.Ho) ? out_img_bytes : 0, 0x00020000);
-            const int srow = (oy * a.Wo + ox0) * 32;
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
+            unroll_steps<CB>([&](auto cbc) {
+                constexpr int cb = decltype(cbc)::value;
+                unroll_steps<4>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    int srow;
+                    if constexpr (KIND == 0) srow = (oy * a.Wo + ox0) * 32;
+                    else {
+                        constexpr int ph = TM == 0 ? (cb == 0 ? 0 : 3) : TM == 1 ? (cb == 0 ? 1 : 2) : 2 * cb + (j >> 1);
+                        srow = ((2 * oy + (ph >> 1)) * OW + 2 * ox0) * 32;
+                    }
                     // (elements copied to scalars first: __builtin_bit_cast applied to an ext_vector element expression reads element 0, hipcc 7.2)
                     const float e0 = acc[cb][r][4 * j + 0], e1 = acc[cb][r][4 * j + 1], e2 = acc[cb][r][4 * j + 2], e3 = acc[cb][r][4 * j + 3];
                     f32x2 lo2, hi2;
@@ -287,8 +331,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_ws_kernel(const ConvArgs
                     pk.x = __builtin_bit_cast(unsigned, __builtin_convertvector(lo2, bf16x2));
                     pk.y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi2, bf16x2));
                     __builtin_amdgcn_raw_buffer_store_b64(pk, ro, vo[cb][j], srow, 0);
-                }
-        }
+                });
+            });
+        });
     };
 
     constexpr std::integral_constant<int, 0> S0{};
@@ -343,6 +388,38 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_ws_kernel(const ConvArgs
 #endif
 }
 
+// ---- workgroup -> (Cout group, walker).  Workgroups b and b + 8 share an XCD (observed round-robin placement, speed only):
+//      the nG workgroups that walk the same tiles with different Cout groups are given equal b % 8 so that a tile is fetched
+//      into ONE per-XCD L2.
+__device__ __forceinline__ void ws_place(int nG, int &grp, int &walker, int &nwalk) {
+    nwalk = (int)gridDim.x / nG;                        // the launcher makes the grid a multiple of nG
+    if ((int)gridDim.x % (8 * nG) == 0) {
+        const int j = (int)blockIdx.x >> 3;
+        grp = j % nG; walker = ((int)blockIdx.x & 7) + 8 * (j / nG);
+    } else {
+        grp = (int)blockIdx.x % nG; walker = (int)blockIdx.x / nG;
+    }
+}
+
+// R: output rows per tile; CB: 32-channel Cout blocks per workgroup (and per wave); NW: waves (= independent workers) per workgroup;
+// NCH: 16-channel chunks of the input (both sources together); TWO: chunks NCH/2.. come from the second source (C0 == C1)
+template <int R, int CB, int NW, int NCH, bool TWO>
+__global__ __launch_bounds__(NW * 64, NW / 4) void conv_ws_kernel(const ConvArgs a) {
+    int grp, walker, nwalk;
+    ws_place(a.Cout / (32 * CB), grp, walker, nwalk);
+    ws_main<0, R, CB, NW, NCH, TWO, 0>(a, grp, walker, nwalk);
+}
+
+// transposed conv: R input rows per tile; C16: Cout = 16 (a block holds two phases), else the block pairing alternates with the group
+template <int R, int NW, int NCH, bool C16>
+__global__ __launch_bounds__(NW * 64, NW / 4) void tconv_ws_kernel(const ConvArgs a) {
+    int grp, walker, nwalk;
+    ws_place(a.Cout / 64, grp, walker, nwalk);
+    if constexpr (C16) ws_main<1, R, 2, NW, NCH, false, 2>(a, grp, walker, nwalk);
+    else if (grp & 1) ws_main<1, R, 2, NW, NCH, false, 1>(a, grp, walker, nwalk);       // workgroup-uniform branch
+    else ws_main<1, R, 2, NW, NCH, false, 0>(a, grp, walker, nwalk);
+}
+
 }  // namespace
 
 // W(id, R, CB, NW): ConvConfig::pc == 6, 3x3 stride 1, mb 32, th = R, tw = 32, kc 16, wm 1, wn = NW, cb = CB
@@ -351,27 +428,47 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_ws_kernel(const ConvArgs
     W(401, 4, 1, 4)                 \
     W(402, 2, 2, 8)                 \
     W(403, 4, 2, 4)
+// T(id, R, NW): the transposed conv as 2x2 sub-pixel conv (ks 2), th = R input rows, two paired 32-row blocks per workgroup (cb 2)
+#define UKBB_WST_CONFIGS(T)         \
+    T(410, 4, 4)                    \
+    T(411, 2, 8)                    \
+    T(412, 2, 4)
 
 #define UKBB_WS_ENTRY(ID, R, CB, NW) \
     {ID, 3, 1, 32, R, WS_TW, 16, 1, NW, CB, 0, 6, "convBF16ws_3x3s1_r" #R "x32_cb" #CB "_w" #NW, 0},
-static const ConvConfig g_ws_cfgs[] = {UKBB_WS_CONFIGS(UKBB_WS_ENTRY)};
+#define UKBB_WST_ENTRY(ID, R, NW) \
+    {ID, 2, 1, 32, R, WS_TW, 16, 1, NW, 2, 0, 6, "tconvBF16ws_2x2_r" #R "x32_cb2_w" #NW, 0},
+static const ConvConfig g_ws_cfgs[] = {UKBB_WS_CONFIGS(UKBB_WS_ENTRY) UKBB_WST_CONFIGS(UKBB_WST_ENTRY)};
+
+// Order of the 4 x cout phase-major virtual channels (phase = 2 py + px, then channel) in the packed filter / bias of the transposed
+// conv tilings: dst column v takes source column wst_pack_order(cout, v).  cout = 16: unchanged (blocks {00 + 01}, {10 + 11}).
+// cout % 32 == 0: workgroup (group) 2 i holds {phase 00, phase 11} of channels 32 i .., group 2 i + 1 holds {01, 10} (tconv_ws_kernel).
+int wst_pack_order(int cout, int v) {
+    if (cout == 16) return v;
+    const int nb = v / 32, r = v % 32, grp = nb / 2, k = nb % 2, i = grp / 2;
+    const int ph = (grp & 1) ? (k == 0 ? 1 : 2) : (k == 0 ? 0 : 3);
+    return ph * cout + i * 32 + r;
+}
 
 int num_ws_configs() { return (int)(sizeof(g_ws_cfgs) / sizeof(g_ws_cfgs[0])); }
 const ConvConfig &ws_config(int i) { return g_ws_cfgs[i]; }
-int ws_lds_bytes_for(const ConvConfig &c, int cin) { return ws_lds_bytes(c.th, c.cb, c.wn, cin / 16); }
+int ws_lds_bytes_for(const ConvConfig &c, int cin) { return ws_lds_bytes(c.ks == 2 ? 1 : 0, c.th, c.cb, c.wn, cin / 16); }
 
 namespace {
+template <class K>
+hipError_t launch_ws_kernel(K k, int bytes, int threads, const ConvArgs &a, int grid, hipStream_t s, OncePerDevice &lds_ok) {
+    hipError_t e = allow_dynamic_lds(lds_ok, reinterpret_cast<const void *>(k), bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(threads), bytes, s, a);
+    return hipGetLastError();
+}
 template <int R, int CB, int NW, int NCH, bool TWO>
 hipError_t launch_ws_one(const ConvArgs &a, int grid, hipStream_t s) {
-    auto k = conv_ws_kernel<R, CB, NW, NCH, TWO>;
-    constexpr int bytes = ws_lds_bytes(R, CB, NW, NCH);
+    constexpr int bytes = ws_lds_bytes(0, R, CB, NW, NCH);
     if constexpr (bytes > 160 * 1024) { return hipErrorInvalidValue; }
     else {
         static OncePerDevice lds_ok;
-        hipError_t e = allow_dynamic_lds(lds_ok, reinterpret_cast<const void *>(k), bytes);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NW * 64), bytes, s, a);
-        return hipGetLastError();
+        return launch_ws_kernel(conv_ws_kernel<R, CB, NW, NCH, TWO>, bytes, NW * 64, a, grid, s, lds_ok);
     }
 }
 template <int R, int CB, int NW>
@@ -386,6 +483,25 @@ hipError_t launch_ws_cfg(const ConvArgs &a, int grid, hipStream_t s) {
         default: return hipErrorInvalidValue;
     }
 }
+template <int R, int NW, int NCH, bool C16>
+hipError_t launch_wst_one(const ConvArgs &a, int grid, hipStream_t s) {
+    constexpr int bytes = ws_lds_bytes(1, R, 2, NW, NCH);
+    if constexpr (bytes > 160 * 1024) { return hipErrorInvalidValue; }
+    else {
+        static OncePerDevice lds_ok;
+        return launch_ws_kernel(tconv_ws_kernel<R, NW, NCH, C16>, bytes, NW * 64, a, grid, s, lds_ok);
+    }
+}
+template <int R, int NW>
+hipError_t launch_wst_cfg(const ConvArgs &a, int grid, hipStream_t s) {
+    const int nch = a.C0 / 16;
+    if (a.up2 == 16) return nch == 2 ? launch_wst_one<R, NW, 2, true>(a, grid, s) : hipErrorInvalidValue;
+    switch (nch) {
+        case 4: return launch_wst_one<R, NW, 4, false>(a, grid, s);
+        case 8: return launch_wst_one<R, NW, 8, false>(a, grid, s);
+        default: return hipErrorInvalidValue;
+    }
+}
 }  // namespace
 
 hipError_t launch_conv_ws(int cfg_id, const ConvArgs &a_in, hipStream_t s) {
@@ -393,10 +509,18 @@ hipError_t launch_conv_ws(int cfg_id, const ConvArgs &a_in, hipStream_t s) {
     for (const ConvConfig &k : g_ws_cfgs) if (k.id == cfg_id) c = &k;
     if (!c) return hipErrorInvalidValue;
     ConvArgs a = a_in;
-    if (a.in0_map || a.up2 || a.first_w || a.lg_w) return hipErrorInvalidValue;
-    if (a.C1 && a.C1 != a.C0) return hipErrorInvalidValue;     // the K loop switches source at the half
+    const bool tconv = c->ks == 2;
+    if (a.in0_map || a.first_w || a.lg_w) return hipErrorInvalidValue;
+    if (tconv) {
+        // virtual channels = 4 phases x up2 real ones, packed in the paired block order of wst_pack_order(); one source
+        if (a.up2 < 16 || a.up2 % 16 || (a.up2 > 16 && a.up2 % 32) || a.Cout != 4 * a.up2 || a.C1 || a.in1) return hipErrorInvalidValue;
+    } else {
+        if (a.up2) return hipErrorInvalidValue;
+        if (a.C1 && a.C1 != a.C0) return hipErrorInvalidValue;     // the K loop switches source at the half
+    }
     if (a.C0 % 16 || a.Cout % (32 * c->cb) || a.pad_y != 1 || a.pad_x != 1 || a.Ho != a.H || a.Wo != a.W) return hipErrorInvalidValue;
-    if ((long long)a.H * a.W * (a.C0 > a.Cout ? a.C0 : a.Cout) * 2 >= 0x7fffffffll) return hipErrorInvalidValue;
+    const long long out_ch = tconv ? 4ll * a.up2 : a.Cout;         // bytes of the largest map of one image must fit a buffer range
+    if ((long long)a.H * a.W * (a.C0 > out_ch ? a.C0 : out_ch) * 2 >= 0x7fffffffll) return hipErrorInvalidValue;
     a.tiles_y = (a.Ho + c->th - 1) / c->th; a.tiles_x = (a.Wo + WS_TW - 1) / WS_TW;
     const int nG = a.Cout / (32 * c->cb);
     const long long ntiles = (long long)a.N * a.tiles_y * a.tiles_x;
@@ -449,6 +573,8 @@ hipError_t launch_conv_ws(int cfg_id, const ConvArgs &a_in, hipStream_t s) {
     switch (cfg_id) {
 #define UKBB_WS_CASE(ID, R, CB, NW) case ID: return launch_ws_cfg<R, CB, NW>(a, grid, s);
         UKBB_WS_CONFIGS(UKBB_WS_CASE)
+#define UKBB_WST_CASE(ID, R, NW) case ID: return launch_wst_cfg<R, NW>(a, grid, s);
+        UKBB_WST_CONFIGS(UKBB_WST_CASE)
         default: return hipErrorInvalidValue;
     }
 }
