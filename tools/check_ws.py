@@ -46,12 +46,16 @@ if __name__ == '__main__':
     for spec in sys.argv[4:]:
         layer, cfgs = spec.split(':')
         for cfg in cfgs.split(','):
-            out, ocfg, oact = run(arch, params, img, '%s:%s' % (layer, cfg))
+            ov = layer.split('+')[1] if layer.startswith('conv0_0+') else layer.split('+')[0]     # fused launches: conv0_0+conv0_1, up0_1+logits
+            out, ocfg, oact = run(arch, params, img, '%s:%s' % (ov, cfg))
             if ocfg.get(layer) != int(cfg):
                 print('%-8s cfg %s: NOT TAKEN (ran %s)' % (layer, cfg, ocfg.get(layer)))
                 bad += 1
                 continue
-            a, b = oact[layer], bact[layer]
+            if layer.endswith('+logits'):                              # the layer's own output is never stored: compare the logits
+                a, b = out['logits'], base['logits']
+            else:
+                a, b = oact[layer], bact[layer]
             d = np.abs(a - b)
             scale = float(np.abs(b).max())
             nz = int((d > 0).sum())

@@ -82,7 +82,7 @@ struct DevBuf {
     }
 };
 
-enum OpKind { OP_FIRST, OP_CONV, OP_HEAD, OP_TCONV, OP_LOGITS, OP_SQG, OP_SQG_MULTI };
+enum OpKind { OP_FIRST, OP_CONV, OP_HEAD, OP_TCONV, OP_LOGITS, OP_SQG, OP_SQG_MULTI, OP_TAIL };
 
 struct Op {                    // one kernel launch of the plan
     OpKind kind;
@@ -526,7 +526,7 @@ int pick_fused_bf_cfg(const std::string &lname, int ks, int stride, int c0, int 
     const int forced = override_cfg(lname);
     // fused logits: the persistent kernel first (kernels_bf16.hip: 104-110 vs 124 us), then the tile-per-workgroup tilings in
     // measured order; fused first layer: tile-per-workgroup only (its persistent form was no faster, r03_notes.md)
-    for (int cand : {forced, fuse_bf == 1 ? 296 : 325, fuse_bf == 1 ? 294 : 324, fuse_bf == 1 ? 295 : 298, fuse_bf == 1 ? -1 : 297, fuse_bf == 1 ? -1 : 299}) {
+    for (int cand : {forced, fuse_bf == 1 ? 296 : 404, fuse_bf == 1 ? 294 : 325, fuse_bf == 1 ? 295 : 324, fuse_bf == 1 ? -1 : 298, fuse_bf == 1 ? -1 : 297, fuse_bf == 1 ? -1 : 299}) {
         ConvConfig cc;
         if (cand >= 0 && find_cfg(cand, cc) == 0 && cfg_valid(cc, ks, stride, c0, c1, cout, false, 2, fuse_bf) &&
             (cand == forced || tile_fit_ok(cc, Ho, Wo))) return cand;
@@ -707,6 +707,29 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
             int rc = add_tconv(h, nm, up, lh[l + 1], lw[l + 1], n_hint, &t);
             if (rc) return rc;
             int x = -1;
+            // bf16 storage, level 0 with the standard two 16-channel convs: up0_0, up0_1, logits and softmax / argmax as ONE launch
+            // (kernels_tail.hip); UKBB_NO_FUSE_TAIL=1 keeps the separate launches (A/B knob)
+            const bool no_tail = getenv("UKBB_NO_FUSE_TAIL") != nullptr;      // read at every plan build (tools/check_tail.py switches it inside one process)
+            if (l == 0 && a.kind == UKBB_KIND_UNET && bf16_mode(h) == 2 && !no_tail && a.n_block[0] == 2 && a.n_filter[0] == 16 &&
+                a.n_class >= 2 && a.n_class <= 4 && override_cfg("up0_0") < 0 && override_cfg("up0_1") < 0) {
+                const int l0 = h->layer_index.at("up0_0"), l1 = h->layer_index.at("up0_1");
+                const HostLayer &L0 = h->layers[l0], &L1 = h->layers[l1];
+                if (!dev_ptr(h, "tail/wA0")) {
+                    std::vector<float> p0((size_t)9 * 64 * 4), p1((size_t)5 * 64 * 4);
+                    pack_tail_weights(L0.w.data(), L1.w.data(), p0.data(), p1.data());
+                    int rc = upload(h, "tail/wA0", p0);
+                    if (rc) return rc;
+                    rc = upload(h, "tail/wA1", p1);
+                    if (rc) return rc;
+                }
+                Op op; op.kind = OP_TAIL; op.name = "up0_0+up0_1+logits"; op.layer = l0; op.in0 = level_out[0]; op.in1 = t;
+                op.H = op.Ho = lh[0]; op.W = op.Wo = lw[0];
+                op.macs_per_image = (double)lh[0] * lw[0] * (9.0 * L0.cin * L0.cout + 9.0 * L1.cin * L1.cout + (double)a.n_filter[0] * a.n_class);
+                h->ops.push_back(op);
+                h->feat_buf = -1;
+                up = -1;
+                continue;
+            }
             for (int i = 0; i < a.n_block[l]; ++i) {
                 snprintf(nm, sizeof nm, "up%d_%d", l, i);
                 static const bool no_fuse_lg = getenv("UKBB_NO_FUSE_LOGITS") != nullptr;    // A/B knob
@@ -721,7 +744,9 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
             h->act_name[up] = std::string("up") + std::to_string(l);
         }
         h->feat_buf = up;                              // net['conv0_up']: what UNet_LSTM_Model feeds the LSTM (:343-347)
-        if (a.kind == UKBB_KIND_UNET && h->ops.back().kind == OP_CONV && h->ops.back().fused_logits) {
+        if (a.kind == UKBB_KIND_UNET && h->ops.back().kind == OP_TAIL) {
+            // logits, softmax / argmax are part of the fused tail launch
+        } else if (a.kind == UKBB_KIND_UNET && h->ops.back().kind == OP_CONV && h->ops.back().fused_logits) {
             Op &last = h->ops.back();
             last.name += "+logits";
             last.macs_per_image += (double)H * W * a.n_filter[0] * a.n_class;
@@ -937,6 +962,17 @@ int run_plan(ukbb_fcn_handle *h, const float *image, int n, float *logits, float
                 ca.tiles_y = (op.Ho + c.th - 1) / c.th; ca.tiles_x = (op.Wo + c.tw - 1) / c.tw;
                 ca.relu = 1; ca.up2 = L.cout;
                 e = launch_conv(op.cfg, ca, s);
+                break;
+            }
+            case OP_TAIL: {
+                TailArgs ta{};
+                ta.in0 = h->act[op.in0]->p; ta.in1 = h->act[op.in1]->p;
+                ta.wA0 = dev_ptr(h, "tail/wA0"); ta.wA1 = dev_ptr(h, "tail/wA1");
+                ta.b0 = dev_ptr(h, "up0_0/bias"); ta.b1 = dev_ptr(h, "up0_1/bias");
+                ta.lg_w = dev_ptr(h, "logits/w"); ta.lg_b = dev_ptr(h, "logits/bias");
+                ta.logits = logits; ta.prob = prob; ta.pred = pred;
+                ta.N = n; ta.H = op.H; ta.W = op.W; ta.ncls = a.n_class;
+                e = launch_unet_tail(ta, s);
                 break;
             }
             case OP_LOGITS: {

@@ -28,6 +28,9 @@ inline hipError_t allow_dynamic_lds(OncePerDevice &once, const void *kernel, int
 // round to the same float, and the lower index wins although its logit is smaller.  Only in that case (rare: |logits| of the
 // top two below ~1 and almost equal) the probabilities are formed to decide; the common path costs a subtract and a compare
 // per class.  ``p`` (optional) receives the probabilities, formed the same way, so argmax(p) == return value always.
+// (r04: callers pass either a real array or the literal nullptr.  Handed `cond ? array : nullptr`, hipcc kept the array in SCRATCH
+// memory -- 15-36 scratch instructions in the epilogues of the head / fused-logits kernels, whose reloads sit in the same vmcnt queue
+// as the prefetched tiles.  softmax_argmax_opt() below is the call shape for an optional output.)
 template <int NCLS>
 __device__ __forceinline__ int softmax_argmax(const float (&lg)[NCLS], float *p) {
     int best = 0; float m = lg[0];
@@ -50,6 +53,15 @@ __device__ __forceinline__ int softmax_argmax(const float (&lg)[NCLS], float *p)
         }
     }
     return best;
+}
+
+// pred (and, only if `want_prob`, the probabilities into p) without an escaping conditional pointer: two straight-line instantiations
+template <int NCLS>
+__device__ __forceinline__ int softmax_argmax_opt(const float (&lg)[NCLS], bool want_prob, float (&p)[NCLS]) {
+    if (want_prob) return softmax_argmax<NCLS>(lg, p);
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c) p[c] = 0.f;
+    return softmax_argmax<NCLS>(lg, nullptr);
 }
 
 // ---------------------------------------------------------------------------
@@ -210,6 +222,20 @@ void pack_head_x3(const float *w /*[k_in][64 out]*/, int k_in /*32 | 64*/, float
 // out as HWIO by the engine):  out[2m+py] = sum_a x[m+a-1] * w[kh(py,a)],
 //   py = 0: a=0 -> kh=2, a=1 -> kh=0 ;  py = 1: a=1 -> kh=1 (a=0: no tap).
 void tconv_as_conv2x2(const float *w, int cin, int cout, float *dst);
+
+// Fused tail of the bf16 U-Net (kernels_tail.hip): up0_0 -> up0_1 -> logits -> softmax / argmax in one launch (network_ao.py:51-63,159-160)
+struct TailArgs {
+    const float *in0, *in1;     // bf16 [N][H][W][16]: the level-0 skip map (conv0) and the transposed conv's output (up0_t)
+    const float *wA0, *wA1;     // pack_tail_weights(): MFMA A fragments of up0_0 (9 taps) and up0_1 (5 tap pairs)
+    const float *b0, *b1;       // folded BN shifts [16]
+    const float *lg_w, *lg_b;   // logits conv [16][n_class], [n_class]
+    float *logits, *prob;       // optional [N,H,W,n_class]
+    int32_t *pred;              // optional [N,H,W]
+    int N, H, W, ncls;
+    unsigned long long *stamps;  // diagnostic builds only (-DUKBB_DIAG, env UKBB_TAIL_STAMPS): per-wave phase cycle sums
+};
+hipError_t launch_unet_tail(const TailArgs &a, hipStream_t s);
+void pack_tail_weights(const float *w0 /*[3][3][32][16] folded*/, const float *w1 /*[3][3][16][16] folded*/, float *dst0 /*9*64*4*/, float *dst1 /*5*64*4*/);
 
 struct LogitsArgs {         // 1x1 conv C -> n_class + bias, softmax / argmax (network_ao.py:63,159-160)
     const float *in;        // [N,H,W,C]

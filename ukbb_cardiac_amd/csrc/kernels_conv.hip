@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM,
                         float l[NC], p[NC];
 #pragma unroll
                         for (int c = 0; c < NC; ++c) l[c] = lgv[c];
-                        const int best = softmax_argmax<NC>(l, a.lg_prob ? p : nullptr);
+                        const int best = softmax_argmax_opt<NC>(l, a.lg_prob != nullptr, p);
                         if (a.lg_pred) a.lg_pred[px] = best;
 #pragma unroll
                         for (int c = 0; c < NC; ++c) {

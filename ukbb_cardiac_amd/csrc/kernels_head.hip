@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256, OCC) void fcn_head_kernel(const HeadArgs a) {
                 for (int c = 0; c < NCLS; ++c) a.logits[q * NCLS + c] = lg[c];
             }
             float pr[NCLS];
-            const int best = softmax_argmax<NCLS>(lg, a.prob ? pr : nullptr);
+            const int best = softmax_argmax_opt<NCLS>(lg, a.prob != nullptr, pr);
             if (a.pred) a.pred[q] = best;
             if (a.prob) {
 #pragma unroll
@@ -902,7 +902,7 @@ __global__ __launch_bounds__(768) void fcn_head_pc_kernel(const HeadArgs a) {
                     for (int c = 0; c < NCLS; ++c) a.logits[q * NCLS + c] = lg[c];
                 }
                 float pr[NCLS];
-                const int best = softmax_argmax<NCLS>(lg, a.prob ? pr : nullptr);
+                const int best = softmax_argmax_opt<NCLS>(lg, a.prob != nullptr, pr);
                 if (a.pred) a.pred[q] = best;
                 if (a.prob) {
 #pragma unroll
@@ -1092,7 +1092,7 @@ __global__ __launch_bounds__(256) void logits_kernel(const LogitsArgs a) {
             for (int c = 0; c < NCLS; ++c) a.logits[q * NCLS + c] = lg[c];
         }
         float pr[NCLS];
-        const int best = softmax_argmax<NCLS>(lg, a.prob ? pr : nullptr);
+        const int best = softmax_argmax_opt<NCLS>(lg, a.prob != nullptr, pr);
         if (a.pred) a.pred[q] = best;
         if (a.prob) {
 #pragma unroll

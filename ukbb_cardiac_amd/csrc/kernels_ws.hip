@@ -98,8 +98,11 @@ __host__ __device__ constexpr bool wst_first(int tm, int blk, int a, int b) {
 }
 
 // KIND: 0 = 3x3 stride 1, 1 = transposed conv (sub-pixel 2x2); TM: KIND 1 only, the block pairing (wst_needed)
-template <int KIND, int R, int CB, int NW, int NCH, bool TWO, int TM>
+// LG (KIND 0, one block of 16 real channels): the 1x1 logits conv + softmax / argmax of network_ao.py:63,159-160 in the epilogue; the
+//     conv's own output is rounded to bf16 as a store would have done and never written (as conv_mfma_kernel<..., FUSE = 2>)
+template <int KIND, int R, int CB, int NW, int NCH, bool TWO, int TM, bool LG = false>
 __device__ __forceinline__ void ws_main(const ConvArgs &a, const int grp, const int walker, const int nwalk) {
+    static_assert(!LG || (KIND == 0 && CB == 1), "fused logits: 3x3 conv with one Cout block");
     constexpr int WS_IW = ws_iw(KIND), HR = ws_hr(KIND, R), TAPS = ws_taps(KIND);
     constexpr int HP = HR * WS_IW, NLD = ws_nld(KIND, R), STAGE = ws_stage_bytes(KIND, R), PLANE = ws_plane_bytes(KIND, R);
     constexpr int WSLAB = NCH * CB * TAPS * 1024;       // bytes: [chunk][cb][tap][lane][16]
@@ -296,9 +299,90 @@ __device__ __forceinline__ void ws_main(const ConvArgs &a, const int grp, const 
         });
     });
     const int relu_lo = a.relu ? 0 : (int)0x80000000;   // max_i32(bits, 0) = ReLU; max_i32(bits, INT_MIN) = identity
+    // fused logits ON THE MATRIX PIPE (as vector FMAs the 16 -> n_class product, with its cross-half shuffles, cost ~120 VALU
+    // instructions per 32-pixel row against the row's 9 MFMAs and made this layer VALU-bound): one more K = 16 product per row with
+    // A = the logits weights (rows = classes), B = the lane's own 8 activations rounded to bf16 -- the K order is permuted so that
+    // k-slot 8 g + i IS the channel the accumulator layout gives lane half g (4 g + i for i < 4, 8 + 4 g + i - 4 above): no data
+    // moves between lanes.  The fp32 weights enter as bf16 hi + lo pieces (two MFMAs), so the product is exact to ~2^-17 of a weight;
+    // the bias is the C operand.  Lane half 0 then holds the row's n_class logits of its pixel in registers 0..3.
+    u32x4 lgA[2];
+    f32x16 lgC;
+    if constexpr (LG) {
+        const int m = lane & 31;
+        unsigned hi[8], lo[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ch = i < 4 ? 4 * g + i : 8 + 4 * g + (i - 4);
+            const float w = m < a.lg_ncls ? a.lg_w[ch * a.lg_ncls + m] : 0.f;
+            f32x2 t; t.x = w; t.y = 0.f;
+            const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2)) & 0xffffu;
+            t.x = w - __builtin_bit_cast(float, hb << 16);
+            hi[i] = hb; lo[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2)) & 0xffffu;
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) { lgA[0][d] = hi[2 * d] | (hi[2 * d + 1] << 16); lgA[1][d] = lo[2 * d] | (lo[2 * d + 1] << 16); }
+#pragma unroll
+        // (rows >= n_class carry distinct values -row: lane half 1 runs softmax_argmax on rows 4..7, and equal values there sent the whole
+        //  wave through its tie path -- expf and a division -- on every call)
+        for (int q = 0; q < 16; ++q) { const int row = 8 * (q >> 2) + 4 * g + (q & 3); lgC[q] = row < a.lg_ncls ? a.lg_b[row] : -(float)row; }
+    }
     auto epilogue = [&](int k) {
         int n, oy0, ox0;
         const bool valid = tile_coords(k, n, oy0, ox0);
+        if constexpr (LG) {
+            const int ox = ox0 + pl;
+            const int npx = a.Ho * a.Wo;
+            const __amdgpu_buffer_rsrc_t ro_pred = __builtin_amdgcn_make_buffer_rsrc((void *)(a.lg_pred + (size_t)n * npx), 0, a.lg_pred ? npx * 4 : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t ro_lg = __builtin_amdgcn_make_buffer_rsrc((void *)(a.lg_logits + (size_t)n * npx * a.lg_ncls), 0, a.lg_logits ? npx * a.lg_ncls * 4 : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t ro_pr = __builtin_amdgcn_make_buffer_rsrc((void *)(a.lg_prob + (size_t)n * npx * a.lg_ncls), 0, a.lg_prob ? npx * a.lg_ncls * 4 : 0, 0x00020000);
+            unroll_steps<R>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                const int oy = oy0 + r;
+                u32x4 bq;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {                      // k-slots 2 d, 2 d + 1 = accumulator registers 4 (d >> 1) + 2 (d & 1) + {0, 1}
+                    const float e0 = acc[0][r][4 * (d >> 1) + 2 * (d & 1)], e1 = acc[0][r][4 * (d >> 1) + 2 * (d & 1) + 1];
+                    f32x2 v2;
+                    v2.x = __builtin_bit_cast(float, max(__builtin_bit_cast(int, e0), relu_lo));
+                    v2.y = __builtin_bit_cast(float, max(__builtin_bit_cast(int, e1), relu_lo));
+                    bq[d] = __builtin_bit_cast(unsigned, __builtin_convertvector(v2, bf16x2));      // what a bf16 store would have held
+                }
+                f32x16 lg = mfma_bf16(lgA[1], bq, lgC);            // smaller term first
+                lg = mfma_bf16(lgA[0], bq, lg);
+                // Outputs through buffer stores whose lane offset is out of range for lanes that own no pixel and whose range is 0 for
+                // an output that was not asked for: NO branch around a vector-memory instruction (with the stores inside an if, hipcc
+                // made the next park wait for vmcnt(0) -- the three tiles of loads in flight drained at every tile, 6000 cycles per tile
+                // for 1150 cycles of MFMA).
+                const bool own = g == 0 && valid && oy < a.Ho && ox < a.Wo;
+                const unsigned px = (unsigned)((oy * a.Wo + ox));
+                auto finish = [&](auto nc) {
+                    constexpr int NC = decltype(nc)::value;
+                    float l[NC];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) l[c] = lg[c];
+                    // the probabilities only on the (uniform) path that stores them: handed to softmax_argmax through a pointer that
+                    // may be null, the array lived in scratch memory and its reload sat in the vmcnt queue behind the prefetched tiles
+                    if (a.lg_prob) {
+                        float p[NC];
+                        const int best = softmax_argmax<NC>(l, p);
+                        __builtin_amdgcn_raw_buffer_store_b32((unsigned)best, ro_pred, own ? px * 4u : OOB, 0, 0);
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, p[c]), ro_pr, own ? (px * NC + c) * 4u : OOB, 0, 0);
+                    } else {
+                        const int best = softmax_argmax<NC>(l, nullptr);
+                        __builtin_amdgcn_raw_buffer_store_b32((unsigned)best, ro_pred, own ? px * 4u : OOB, 0, 0);
+                    }
+                    if (a.lg_logits) {
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, l[c]), ro_lg, own ? (px * NC + c) * 4u : OOB, 0, 0);
+                    }
+                };
+                if (a.lg_ncls == 2) finish(std::integral_constant<int, 2>{});
+                else if (a.lg_ncls == 3) finish(std::integral_constant<int, 3>{});
+                else finish(std::integral_constant<int, 4>{});
+            });
+            return;
+        }
         unsigned char *const obase = outb + (size_t)n * out_img_bytes;
         const bool colok = ox0 + pl < a.Wo;
         unsigned vo[CB][4];
@@ -403,11 +487,11 @@ __device__ __forceinline__ void ws_place(int nG, int &grp, int &walker, int &nwa
 
 // R: output rows per tile; CB: 32-channel Cout blocks per workgroup (and per wave); NW: waves (= independent workers) per workgroup;
 // NCH: 16-channel chunks of the input (both sources together); TWO: chunks NCH/2.. come from the second source (C0 == C1)
-template <int R, int CB, int NW, int NCH, bool TWO>
+template <int R, int CB, int NW, int NCH, bool TWO, bool LG = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void conv_ws_kernel(const ConvArgs a) {
     int grp, walker, nwalk;
     ws_place(a.Cout / (32 * CB), grp, walker, nwalk);
-    ws_main<0, R, CB, NW, NCH, TWO, 0>(a, grp, walker, nwalk);
+    ws_main<0, R, CB, NW, NCH, TWO, 0, LG>(a, grp, walker, nwalk);
 }
 
 // transposed conv: R input rows per tile; C16: Cout = 16 (a block holds two phases), else the block pairing alternates with the group
@@ -428,6 +512,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void tconv_ws_kernel(const ConvArg
     W(401, 4, 1, 4)                 \
     W(402, 2, 2, 8)                 \
     W(403, 4, 2, 4)
+// L(id, R, NW): 16 -> 16 channels with the logits conv + softmax / argmax in the epilogue (ConvConfig::fuse == 2), cb 1
+#define UKBB_WSL_CONFIGS(L)         \
+    L(404, 4, 4)                    \
+    L(405, 2, 8)                    \
+    L(406, 4, 8)
 // T(id, R, NW): the transposed conv as 2x2 sub-pixel conv (ks 2), th = R input rows, two paired 32-row blocks per workgroup (cb 2)
 #define UKBB_WST_CONFIGS(T)         \
     T(410, 4, 4)                    \
@@ -438,7 +527,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void tconv_ws_kernel(const ConvArg
     {ID, 3, 1, 32, R, WS_TW, 16, 1, NW, CB, 0, 6, "convBF16ws_3x3s1_r" #R "x32_cb" #CB "_w" #NW, 0},
 #define UKBB_WST_ENTRY(ID, R, NW) \
     {ID, 2, 1, 32, R, WS_TW, 16, 1, NW, 2, 0, 6, "tconvBF16ws_2x2_r" #R "x32_cb2_w" #NW, 0},
-static const ConvConfig g_ws_cfgs[] = {UKBB_WS_CONFIGS(UKBB_WS_ENTRY) UKBB_WST_CONFIGS(UKBB_WST_ENTRY)};
+#define UKBB_WSL_ENTRY(ID, R, NW) \
+    {ID, 3, 1, 32, R, WS_TW, 16, 1, NW, 1, 0, 6, "convBF16ws_3x3s1+logits_r" #R "x32_cb1_w" #NW, 2},
+static const ConvConfig g_ws_cfgs[] = {UKBB_WS_CONFIGS(UKBB_WS_ENTRY) UKBB_WSL_CONFIGS(UKBB_WSL_ENTRY) UKBB_WST_CONFIGS(UKBB_WST_ENTRY)};
 
 // Order of the 4 x cout phase-major virtual channels (phase = 2 py + px, then channel) in the packed filter / bias of the transposed
 // conv tilings: dst column v takes source column wst_pack_order(cout, v).  cout = 16: unchanged (blocks {00 + 01}, {10 + 11}).
@@ -483,6 +574,13 @@ hipError_t launch_ws_cfg(const ConvArgs &a, int grid, hipStream_t s) {
         default: return hipErrorInvalidValue;
     }
 }
+template <int R, int NW>
+hipError_t launch_wsl_cfg(const ConvArgs &a, int grid, hipStream_t s) {
+    if (a.C0 != 16 || a.C1 || a.Cout != 32 || a.cout_store != 16 || !a.lg_w || !a.lg_b || a.lg_ncls < 2 || a.lg_ncls > 4) return hipErrorInvalidValue;
+    constexpr int bytes = ws_lds_bytes(0, R, 1, NW, 1);
+    static OncePerDevice lds_ok;
+    return launch_ws_kernel(conv_ws_kernel<R, 1, NW, 1, false, true>, bytes, NW * 64, a, grid, s, lds_ok);
+}
 template <int R, int NW, int NCH, bool C16>
 hipError_t launch_wst_one(const ConvArgs &a, int grid, hipStream_t s) {
     constexpr int bytes = ws_lds_bytes(1, R, 2, NW, NCH);
@@ -510,7 +608,7 @@ hipError_t launch_conv_ws(int cfg_id, const ConvArgs &a_in, hipStream_t s) {
     if (!c) return hipErrorInvalidValue;
     ConvArgs a = a_in;
     const bool tconv = c->ks == 2;
-    if (a.in0_map || a.first_w || a.lg_w) return hipErrorInvalidValue;
+    if (a.in0_map || a.first_w || (a.lg_w != nullptr) != (c->fuse == 2)) return hipErrorInvalidValue;
     if (tconv) {
         // virtual channels = 4 phases x up2 real ones, packed in the paired block order of wst_pack_order(); one source
         if (a.up2 < 16 || a.up2 % 16 || (a.up2 > 16 && a.up2 % 32) || a.Cout != 4 * a.up2 || a.C1 || a.in1) return hipErrorInvalidValue;
@@ -573,6 +671,8 @@ hipError_t launch_conv_ws(int cfg_id, const ConvArgs &a_in, hipStream_t s) {
     switch (cfg_id) {
 #define UKBB_WS_CASE(ID, R, CB, NW) case ID: return launch_ws_cfg<R, CB, NW>(a, grid, s);
         UKBB_WS_CONFIGS(UKBB_WS_CASE)
+#define UKBB_WSL_CASE(ID, R, NW) case ID: return launch_wsl_cfg<R, NW>(a, grid, s);
+        UKBB_WSL_CONFIGS(UKBB_WSL_CASE)
 #define UKBB_WST_CASE(ID, R, NW) case ID: return launch_wst_cfg<R, NW>(a, grid, s);
         UKBB_WST_CONFIGS(UKBB_WST_CASE)
         default: return hipErrorInvalidValue;
