@@ -82,7 +82,7 @@ struct DevBuf {
     }
 };
 
-enum OpKind { OP_FIRST, OP_CONV, OP_HEAD, OP_TCONV, OP_LOGITS, OP_SQG, OP_SQG_MULTI, OP_TAIL };
+enum OpKind { OP_FIRST, OP_CONV, OP_HEAD, OP_TCONV, OP_LOGITS, OP_SQG, OP_SQG_MULTI, OP_TAIL, OP_STEM };
 
 struct Op {                    // one kernel launch of the plan
     OpKind kind;
@@ -634,6 +634,31 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
             // bf16 storage: only if a fused tiling fits conv0_1 at this size (otherwise conv0_0 runs as its own launch, bf16 out)
             const bool can_fuse = !no_fuse && a.n_block[0] >= 2 && a.n_filter[0] == 16 &&
                                   (bf16_mode(h) != 2 || pick_fused_bf_cfg("conv0_1", 3, 1, 16, 0, 16, H, W, 1) >= 0);
+            // bf16 storage with the standard 1 -> 16 -> 16 stem: conv0_0 and conv0_1 as ONE launch of kernels_stem.hip
+            // (UKBB_NO_FUSE_STEM=1: the r03 form, conv0_0 evaluated in conv0_1's staging)
+            const bool stem = a.kind == UKBB_KIND_UNET && bf16_mode(h) == 2 && getenv("UKBB_NO_FUSE_STEM") == nullptr && a.n_block[0] >= 2 &&
+                              a.n_filter[0] == 16 && override_cfg("conv0_1") < 0;
+            if (l == 0 && i == 0 && stem) continue;
+            if (l == 0 && i == 1 && stem) {
+                const int l0 = h->layer_index.at("conv0_0"), l1 = h->layer_index.at("conv0_1");
+                const HostLayer &L0 = h->layers[l0], &L1 = h->layers[l1];
+                if (!dev_ptr(h, "stem/wA0")) {
+                    std::vector<float> p0((size_t)64 * 4), dummy((size_t)9 * 64 * 4), p1((size_t)5 * 64 * 4), w0z((size_t)9 * 32 * 16, 0.f);
+                    pack_stem_weights(L0.w.data(), p0.data());
+                    pack_tail_weights(w0z.data(), L1.w.data(), dummy.data(), p1.data());
+                    int rc = upload(h, "stem/wA0", p0);
+                    if (rc) return rc;
+                    rc = upload(h, "stem/wA1", p1);
+                    if (rc) return rc;
+                }
+                Op op; op.kind = OP_STEM; op.name = "conv0_0+conv0_1"; op.layer = l1;
+                op.H = op.Ho = H; op.W = op.Wo = W;
+                op.out = new_act(h, "conv0_1", (size_t)H * W * L1.cout, L1.cout);
+                op.macs_per_image = (double)H * W * 9 * (L0.cin * L0.cout + L1.cin * L1.cout);
+                h->ops.push_back(op);
+                cur = op.out;
+                continue;
+            }
             if (l == 0 && i == 0) {
                 if (can_fuse) continue;              // evaluated inside conv0_1's producers
                 Op op; op.kind = OP_FIRST; op.name = nm; op.layer = h->layer_index.at(nm);
@@ -962,6 +987,14 @@ int run_plan(ukbb_fcn_handle *h, const float *image, int n, float *logits, float
                 ca.tiles_y = (op.Ho + c.th - 1) / c.th; ca.tiles_x = (op.Wo + c.tw - 1) / c.tw;
                 ca.relu = 1; ca.up2 = L.cout;
                 e = launch_conv(op.cfg, ca, s);
+                break;
+            }
+            case OP_STEM: {
+                StemArgs sa{};
+                sa.image = image; sa.wA0 = dev_ptr(h, "stem/wA0"); sa.wA1 = dev_ptr(h, "stem/wA1");
+                sa.b0 = dev_ptr(h, "conv0_0/bias"); sa.b1 = dev_ptr(h, "conv0_1/bias");
+                sa.out = h->act[op.out]->p; sa.N = n; sa.H = op.H; sa.W = op.W;
+                e = launch_unet_stem(sa, s);
                 break;
             }
             case OP_TAIL: {

@@ -237,6 +237,17 @@ struct TailArgs {
 hipError_t launch_unet_tail(const TailArgs &a, hipStream_t s);
 void pack_tail_weights(const float *w0 /*[3][3][32][16] folded*/, const float *w1 /*[3][3][16][16] folded*/, float *dst0 /*9*64*4*/, float *dst1 /*5*64*4*/);
 
+// Fused stem of the bf16 U-Net (kernels_stem.hip): conv0_0 -> conv0_1 in one launch (network_ao.py:31-35 with l = 0)
+struct StemArgs {
+    const float *image;         // fp32 [N][H][W]
+    const float *wA0, *wA1;     // pack_stem_weights() (conv0_0) and the second output of pack_tail_weights() (conv0_1: 5 tap pairs)
+    const float *b0, *b1;       // folded BN shifts [16]
+    float *out;                 // bf16 [N][H][W][16]
+    int N, H, W;
+};
+hipError_t launch_unet_stem(const StemArgs &a, hipStream_t s);
+void pack_stem_weights(const float *w0 /*[3][3][1][16] folded*/, float *dst0 /*64*4*/);
+
 struct LogitsArgs {         // 1x1 conv C -> n_class + bias, softmax / argmax (network_ao.py:63,159-160)
     const float *in;        // [N,H,W,C]
     const float *w;         // [C][n_class]
