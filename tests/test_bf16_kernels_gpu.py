@@ -1,0 +1,44 @@
+"""r04 kernels of the aortic U-Net in UKBB_PREC_BF16, each against the kernel(s) it replaces on the same inputs (through the C ABI):
+the weight-stationary conv / transposed-conv tilings (kernels_ws.hip), the fused tail (kernels_tail.hip) and the fused stem
+(kernels_stem.hip).  The comparisons are those of tools/check_ws.py, check_tail.py and check_stem.py, run as the tools themselves."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _tool(name, *args):
+    env = dict(os.environ)
+    env['PYTHONPATH'] = ROOT + os.pathsep + env.get('PYTHONPATH', '')
+    for k in ('UKBB_CONV_CFG', 'UKBB_NO_FUSE_TAIL', 'UKBB_NO_FUSE_STEM'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', name)] + [str(a) for a in args], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == 'OK', r.stdout[-3000:]
+    return r.stdout
+
+
+def test_weight_stationary_tilings_match_the_tile_per_workgroup_kernels():
+    """Every ws tiling on every layer type it serves, at a size with ragged tiles (64 x 96: 48-, 24-, 12-pixel rows) and at 256 x 256:
+    the layer's own output differs from the r03 kernel's by at most a bf16 ulp on a handful of elements (same products, other fp32
+    summation order); two sources (skip concat), 16-channel layers on the zero-padded block, all three transposed-conv pairings."""
+    out = _tool('check_ws.py', 2, 64, 96, 'conv1_1:400,401', 'conv2_1:400,401,402,403', 'conv3_1:400,401', 'up1_0:400,401', 'up2_0:400,401',
+                'up0_0:400,401', 'up0_t:410,411,412', 'up1_t:410,411,412', 'up2_t:410,411,412', 'up0_1+logits:404,405,406')
+    assert 'NOT TAKEN' not in out
+    _tool('check_ws.py', 3, 256, 256, 'conv1_1:401', 'conv2_1:402', 'conv3_1:400', 'up1_0:401', 'up2_0:400', 'up0_t:410', 'up1_t:411', 'up2_t:411')
+
+
+def test_fused_tail_matches_the_unfused_plan():
+    """up0_0 -> up0_1 -> logits -> argmax in one launch against the three-kernel plan: logits to ~1e-3 of their scale (a bf16 ulp of a few
+    intermediate values), labels equal away from ties, prob / pred-only paths consistent; ragged tiles (W = 96, 80, 16) and borders."""
+    _tool('check_tail.py', 2, 64, 96, 3, 256, 256, 1, 48, 80, 2, 16, 16, 1, 32, 272)
+
+
+def test_fused_stem_matches_the_r03_form():
+    """conv0_0 + conv0_1 in one launch (image rounded to bf16) against conv0_0 in fp32 inside conv0_1's staging: the level-0 map's error
+    against the fp32 path stays at the bf16 level, Dice against fp32 unchanged."""
+    _tool('check_stem.py', 2, 64, 96, 3, 256, 256, 1, 48, 80, 2, 16, 16)

@@ -359,11 +359,11 @@ def test_unet_bf16_dice_vs_fp32():
         b16 = eng.run(img, want_logits=True)
         names, cfgs = eng.kernel_names(), eng.kernel_configs()
         # every conv / transposed conv on the bf16-storage tilings (ConvConfig::pc == 5, ids 230-299 and 320-325; pc == 6, the
-        # weight-stationary ids 400-): nothing left in fp32
-        # (21 launches: the first layer rides in conv0_1's staging, the logits in up0_1's epilogue)
-        assert len(cfgs) == 21 and all((230 <= c < 330 and not 300 <= c < 310) or 400 <= c < 420 for c in cfgs), 'bf16 tilings not selected: %s' % list(zip(eng.kernel_names(), cfgs))
-        assert sum(400 <= c < 420 for c in cfgs) >= 8, 'weight-stationary tilings not in the plan: %s' % list(zip(eng.kernel_names(), cfgs))
-        assert names[0] == 'conv0_0+conv0_1' and names[-1] == 'up0_1+logits'
+        # weight-stationary ids 400-), the stem and the tail as the fused launches of kernels_stem.hip / kernels_tail.hip (no tiling
+        # id): nothing left in fp32.  20 launches: conv0_0 + conv0_1, 17 convs / transposed convs, up0_0 + up0_1 + logits
+        assert names[0] == 'conv0_0+conv0_1' and names[-1] == 'up0_0+up0_1+logits' and cfgs[0] == -1 and cfgs[-1] == -1
+        assert len(cfgs) == 20 and all((230 <= c < 330 and not 300 <= c < 310) or 400 <= c < 420 for c in cfgs[1:-1]), 'bf16 tilings not selected: %s' % list(zip(names, cfgs))
+        assert sum(400 <= c < 420 for c in cfgs) >= 10, 'weight-stationary tilings not in the plan: %s' % list(zip(names, cfgs))
         prob16 = eng.run(img, want_logits=True, want_prob=True)
         assert np.array_equal(prob16['logits'], b16['logits']) and np.array_equal(np.argmax(prob16['prob'], -1), b16['pred'])
         eng.set_precision('fp32')
@@ -590,7 +590,7 @@ def test_small_batch_plan_is_arithmetic_neutral():
 def test_unet_bf16_at_unusual_sizes(shape):
     """The bf16-storage plan away from the tuned 256 x 256: maps smaller than a tile, tiles that do not divide the map, one
     16-pixel column, batches on both sides of the small-batch threshold -- logits within 5 % of the fp32 path's scale (bf16
-    rounding of every activation, as at 256 x 256), no NaN, and the fused first layer / logits in use."""
+    rounding of every activation, as at 256 x 256), no NaN, and the fused stem / tail launches in use."""
     from ukbb_cardiac_amd.arch import MODELS
     from ukbb_cardiac_amd.engine import Engine
     from ukbb_cardiac_amd.phantom import cine_phantom
@@ -603,7 +603,7 @@ def test_unet_bf16_at_unusual_sizes(shape):
         eng.set_precision('bf16')
         b16 = eng.run(img, want_logits=True)
         names = eng.kernel_names()
-    assert names[0] == 'conv0_0+conv0_1' and names[-1] == 'up0_1+logits' and len(names) == 21
+    assert names[0] == 'conv0_0+conv0_1' and names[-1] == 'up0_0+up0_1+logits' and len(names) == 20      # r04: fused stem and tail at every size
     assert np.isfinite(b16['logits']).all()
     rel = np.abs(b16['logits'] - f32['logits']).max() / np.abs(f32['logits']).max()
     assert rel < 5e-2, rel

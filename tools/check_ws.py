@@ -18,6 +18,8 @@ LEVEL_NAME = {'conv0_1': 'conv0', 'conv1_1': 'conv1', 'conv2_1': 'conv2', 'conv3
 
 
 def run(arch, params, img, override=None):
+    os.environ['UKBB_NO_FUSE_TAIL'] = '1'                # layer-by-layer plans on both sides: the fused stem / tail have tools of their own
+    os.environ['UKBB_NO_FUSE_STEM'] = '1'
     if override:
         os.environ['UKBB_CONV_CFG'] = override
     else:
