@@ -489,6 +489,7 @@ def main():
         ms, cnt = eng.kernel_times(reset=True)
         eng.set_timing(False)
         names, macs, xmacs = eng.kernel_names(), eng.kernel_macs(), eng.kernel_mfma_macs()
+        pmacs = eng.kernel_mfma_macs_issued()          # incl. padding slots of partly filled tiles / Winograd regions
         dom_avg = ms[dom] / max(cnt[dom], 1)          # measured inside the timed region
         avg = list(warm_avg)
         tf = lambda mac, t_ms: 2.0 * mac / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0
@@ -503,7 +504,7 @@ def main():
                     # instruction in profiles/): the head runs only the level-0 slice of the 160->64 conv at full
                     # resolution, the other four slices run at low resolution inside the sqg kernels (and are counted
                     # there), Winograd layers run 16/36 of the direct multiplies.
-                    'flop_per_launch': 2.0 * xmacs[dom],
+                    'flop_per_launch': 2.0 * xmacs[dom], 'executed_incl_padding_flop_per_launch': 2.0 * pmacs[dom],
                     # the same launch priced with the FLOPs of the reference graph's layers it replaces (can exceed 1;
                     # not a utilisation)
                     'effective_frac_reference_graph': round(credited / PEAK_FP32_MFMA_TFLOPS, 4),
@@ -527,6 +528,10 @@ def main():
                             'us_per_step': round(tall * 1e3, 1)},
             'per_kernel_us': {nm: round(a * 1e3, 1) for nm, a in zip(names, avg)},
             'per_kernel_frac': {nm: round(tf(m, a) / PEAK_FP32_MFMA_TFLOPS, 3) for nm, m, a in zip(names, xmacs, avg)},
+            # what the matrix pipe really issues: partly filled tiles and Winograd regions run all their slots (the 24x26 / 12x13 maps
+            # of levels 3-4 fill 81 % / 87.5 % of their regions); = SQ_INSTS_MFMA x FLOP per instruction of the counter passes
+            'per_kernel_executed_incl_padding_frac': {nm: round(tf(m, a) / PEAK_FP32_MFMA_TFLOPS, 3) for nm, m, a in zip(names, pmacs, avg)},
+            'per_kernel_padding_overhead': {nm: round(p / m, 3) for nm, p, m in zip(names, pmacs, xmacs) if m > 0 and p > m * 1.001},
             'per_kernel_effective_frac_reference_graph': {nm: round(tf(m, a) / PEAK_FP32_MFMA_TFLOPS, 3) for nm, m, a in zip(names, macs, avg)},
         }
 

@@ -235,6 +235,9 @@ double ukbb_fcn_kernel_macs(const ukbb_fcn_handle *h, int i);
  * layers (16/36 of the direct count), the head (level-0 slice of the 160->64 conv only; the other
  * slices run at low resolution inside the sqg kernels), the first layer (vector ALU, reported as 0). */
 double ukbb_fcn_kernel_mfma_macs(const ukbb_fcn_handle *h, int i);
+/* The same INCLUDING what the kernel issues for partly filled tiles / Winograd regions (every Winograd region runs its 32 tile slots
+ * whatever part of them the map fills): = SQ_INSTS_MFMA x MACs per instruction of a rocprofv3 counter pass. */
+double ukbb_fcn_kernel_mfma_macs_issued(const ukbb_fcn_handle *h, int i);
 
 /* Tiling id the plan chose for kernel i (conv kernels; -1 for the others) and
  * its descriptive name; used by tools/tune_convs.py.  The environment variable

@@ -25,7 +25,7 @@ EXPORTS = [
     'ukbb_fcn_select_kth', 'ukbb_fcn_rescale_pack', 'ukbb_fcn_unpack_labels',
     'ukbb_fcn_roi_compact', 'ukbb_fcn_pairwise_sum', 'ukbb_fcn_zscore_pack',
     'ukbb_fcn_gzip_labels_bound', 'ukbb_fcn_gzip_labels', 'ukbb_fcn_gzip_labels_mode',
-    'ukbb_fcn_forward_seq', 'ukbb_fcn_forward_cine', 'ukbb_fcn_clock_probe',
+    'ukbb_fcn_forward_seq', 'ukbb_fcn_forward_cine', 'ukbb_fcn_clock_probe', 'ukbb_fcn_kernel_mfma_macs_issued',
 ]
 
 
@@ -78,6 +78,8 @@ def _load():
     lib.ukbb_fcn_kernel_macs.argtypes = [vp, C.c_int]
     lib.ukbb_fcn_kernel_mfma_macs.restype = C.c_double
     lib.ukbb_fcn_kernel_mfma_macs.argtypes = [vp, C.c_int]
+    lib.ukbb_fcn_kernel_mfma_macs_issued.restype = C.c_double
+    lib.ukbb_fcn_kernel_mfma_macs_issued.argtypes = [vp, C.c_int]
     lib.ukbb_fcn_kernel_config.argtypes = [vp, C.c_int]
     lib.ukbb_fcn_conv_config_name.restype = C.c_char_p
     lib.ukbb_fcn_conv_config_name.argtypes = [C.c_int]

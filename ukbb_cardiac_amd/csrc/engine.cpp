@@ -99,6 +99,7 @@ struct Op {                    // one kernel launch of the plan
     int H = 0, W = 0, Ho = 0, Wo = 0, stride = 1, pad_y = 0, pad_x = 0;
     double macs_per_image = 0; // algorithmic
     double mfma_macs_per_image = -1; // issued to the matrix pipe; -1 = same as algorithmic
+    double padded_macs_per_image = -1;   // ... including the slots of partly filled tiles / Winograd regions; -1 = same as mfma_macs_per_image
     const float *wpk = nullptr, *bias = nullptr;
 };
 
@@ -560,7 +561,20 @@ int add_conv(ukbb_fcn_handle *h, const std::string &lname, int in0, int in1, int
     op.bias = ((c.pc == 5 || c.pc == 6) && L.cout % 32) ? dev_ptr(h, lname + "/bias_pad") : dev_ptr(h, lname + "/bias");
     op.out = new_act(h, lname, (size_t)op.Ho * op.Wo * L.cout, L.cout);
     op.macs_per_image = (double)op.Ho * op.Wo * L.ks * L.ks * L.cin * L.cout;
-    if (c.pc == 4) op.mfma_macs_per_image = op.macs_per_image * (16.0 / 36.0);   // F(2x2,3x3): 16 products per 4 outputs
+    if (c.pc == 4) {
+        op.mfma_macs_per_image = op.macs_per_image * (16.0 / 36.0);   // F(2x2,3x3): 16 products per 4 outputs
+        // what the kernel ISSUES: every region runs two MFMA column blocks of 16 tile slots (one for a region whose lower half lies below
+        // the map in the 64-channel form, kernels_wino.hip `half`), whatever part of its 4 x 8 (8 x 4) tiles the map fills
+        const int trY = c.th / 2, trX = 32 / trY;        // tiles per region along y / x
+        const int regs_y = (op.Ho + 2 * trY - 1) / (2 * trY), regs_x = (op.Wo + 2 * trX - 1) / (2 * trX);
+        double slots = 0;
+        for (int ry = 0; ry < regs_y; ++ry) slots += (double)regs_x * ((c.wm == 4 && ry * 2 * trY + trY >= op.Ho) ? 16 : 32);
+        op.padded_macs_per_image = slots * 16.0 * L.cin * L.cout;
+    } else if (c.pc <= 2) {                            // direct tilings: tiles x pixel blocks of the MFMA's N width
+        const int npb = (c.th * c.tw + c.mb - 1) / c.mb;
+        const double tiles = (double)((op.Ho + c.th - 1) / c.th) * ((op.Wo + c.tw - 1) / c.tw);
+        op.padded_macs_per_image = tiles * npb * c.mb * L.ks * L.ks * (double)L.cin * L.cout;
+    }
     else if (fused_first) op.mfma_macs_per_image = op.macs_per_image;              // conv0_0 itself runs on the vector ALU
     h->ops.push_back(op);
     *out_buf = op.out;
@@ -1384,6 +1398,13 @@ double ukbb_fcn_kernel_mfma_macs(const ukbb_fcn_handle *h, int i) {
     if (!h || i < 0 || i >= (int)h->ops.size()) return 0.0;
     const Op &op = h->ops[i];
     return (op.mfma_macs_per_image >= 0 ? op.mfma_macs_per_image : op.macs_per_image) * h->last_n;
+}
+
+double ukbb_fcn_kernel_mfma_macs_issued(const ukbb_fcn_handle *h, int i) {
+    if (!h || i < 0 || i >= (int)h->ops.size()) return 0.0;
+    const Op &op = h->ops[i];
+    if (op.padded_macs_per_image >= 0) return op.padded_macs_per_image * h->last_n;
+    return ukbb_fcn_kernel_mfma_macs(h, i);
 }
 
 int ukbb_fcn_set_precision(ukbb_fcn_handle *h, int precision) {

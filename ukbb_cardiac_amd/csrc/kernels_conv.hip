@@ -1347,10 +1347,10 @@ __host__ __device__ constexpr int conv_bf_lds_bytes(int ks, int s, int th, int t
 static const ConvConfig g_cfgs[] = {UKBB_CONV_CONFIGS(UKBB_CFG_ENTRY) UKBB_PC_CONFIGS(UKBB_PC_ENTRY)
                                     UKBB_PCF_CONFIGS(UKBB_PCF_ENTRY) UKBB_BF_CONFIGS(UKBB_BF_ENTRY) UKBB_BFIO_CONFIGS(UKBB_BFIO_ENTRY) UKBB_BFIOF_CONFIGS(UKBB_BFIOF_ENTRY)
                                     // Winograd F(2x2,3x3): region 4x8 tiles (8x16 px), 64 Cout per item, KC 16
-                                    {300, 3, 1, 16, 8, 16, 16, 4, 1, 1, 112640, 4, "winogradF2x2_3x3_t8x16_kc16_cout64"},
-                                    {301, 3, 1, 16, 8, 16, 16, 2, 1, 1, 112640, 4, "winogradF2x2_3x3_t8x16_kc16_cout32"},
-                                    {302, 3, 1, 16, 16, 8, 16, 4, 1, 1, 112640, 4, "winogradF2x2_3x3_t16x8_kc16_cout64"},
-                                    {303, 3, 1, 16, 16, 8, 16, 2, 1, 1, 112640, 4, "winogradF2x2_3x3_t16x8_kc16_cout32"}};
+                                    {300, 3, 1, 16, 8, 16, 16, 4, 1, 1, 125184, 4, "winogradF2x2_3x3_t8x16_kc16_cout64"},
+                                    {301, 3, 1, 16, 8, 16, 16, 2, 1, 1, 125184, 4, "winogradF2x2_3x3_t8x16_kc16_cout32"},
+                                    {302, 3, 1, 16, 16, 8, 16, 4, 1, 1, 125184, 4, "winogradF2x2_3x3_t16x8_kc16_cout64"},
+                                    {303, 3, 1, 16, 16, 8, 16, 2, 1, 1, 125184, 4, "winogradF2x2_3x3_t16x8_kc16_cout32"}};
 
 static constexpr int N_BASE_CFGS = (int)(sizeof(g_cfgs) / sizeof(g_cfgs[0]));
 int num_conv_configs() { return N_BASE_CFGS + num_pk16_configs() + num_ws_configs(); }

@@ -38,7 +38,13 @@ constexpr int NT = 32;                                // Winograd tiles per regi
 constexpr int WKC = 16, WXS = WKC + 4;                // channels per stage, LDS pixel stride (floats)
 constexpr int WHP = 180;                              // raw halo tile: 10 x 18 or 18 x 10 pixels
 constexpr int NITX = (WHP * (WKC / 4) + 255) / 256;   // staging passes of the 256 producer threads (3)
-constexpr int XSZ = NITX * (256 / (WKC / 4)) * WXS;   // floats per XS buffer: padded to 192 pixels, no tail guard
+// Raw halo tile XS: pixel stride WXSX = 24 floats and row pitch RS pixels (18 for the 18-wide halo of 4 x 8-tile regions, 12 for the
+// 10-wide halo of 8 x 4-tile regions).  The input transform reads the 4 x 4 patch of every tile, i.e. pixels TWO apart from lane to
+// lane; at the consumer-friendly stride of 20 floats the 16-lane groups of those ds_read_b128 collided 2-way (8 x 16 regions) and
+// 3-way (16 x 8): this was the SQ_LDS_BANK_CONFLICT = 0.50-0.55 x SQ_LDS_IDX_ACTIVE of r03's counter passes.  With (24, 18) / (24, 12)
+// every group is conflict-free (searched exhaustively, r04_notes.md).  The transformed tiles VS keep the stride of 20.
+constexpr int WXSX = 24;
+constexpr int XSZ = 5376 + 32;                        // floats per XS buffer: 18 rows x 12 x 24 (the larger of the two shapes) + a slot for idle lanes
 constexpr int L_XS = 0;                               // [2][XSZ]
 constexpr int L_VS = L_XS + 2 * XSZ;            // [2][16][NT][WXS]
 constexpr int WINO_LDS_FLOATS = L_VS + 2 * 16 * NT * WXS;
@@ -171,19 +177,27 @@ __global__ __launch_bounds__(512, 2) void wino_pc_kernel(const ConvArgs a) {
             }
             if (++l_ch == nchunk) { l_ch = 0; l_item += gridDim.x; ++l_round; if (l_item < nitems) locate(); }
         };
-        float *const xs_w = lds + L_XS + pix0 * WXS + 4 * c4;
+        constexpr int RS = TRY == 4 ? 18 : 12;          // row pitch of the raw tile in pixels
+        static_assert(WIH * RS * WXSX <= XSZ - 32, "raw tile fits its buffer");
+        unsigned xoff[NITX];                            // this thread's LDS float offsets inside an XS buffer (idle lanes of the last pass: the spare slot)
+#pragma unroll
+        for (int it = 0; it < NITX; ++it) {
+            const int pix = pix0 + it * PSTEP;
+            const int iy = pix / WIW, ix = pix - iy * WIW;
+            xoff[it] = pix < WHP ? (unsigned)((iy * RS + ix) * WXSX + 4 * c4) : (unsigned)(XSZ - 32 + 4 * c4);
+        }
         auto storex = [&](auto par) {
             constexpr int B = decltype(par)::value;
 #pragma unroll
             for (int it = 0; it < NITX; ++it)
-                *reinterpret_cast<u32x4 *>(xs_w + B * XSZ + it * PSTEP * WXS) = xr[it];
+                *reinterpret_cast<u32x4 *>(lds + L_XS + B * XSZ + xoff[it]) = xr[it];
         };
         // V = B^T d B per (tile, channel quad).  The two producer wave pairs split the row pass: waves
         // 4-5 produce rows 0-1 of B^T d (from patch rows 0-2), waves 6-7 rows 2-3 (from patch rows 1-3),
         // so each thread issues 12 reads, 32 packed adds and 8 writes.
         const int half = __builtin_amdgcn_readfirstlane(tid) >> 7;
         const int xt = tid & 127, x_tile = xt / C4, x_q = xt - x_tile * C4;
-        const float *const xs_r = lds + L_XS + ((2 * (x_tile / TRX) + half) * WIW + 2 * (x_tile % TRX)) * WXS + 4 * x_q;
+        const float *const xs_r = lds + L_XS + ((2 * (x_tile / TRX) + half) * RS + 2 * (x_tile % TRX)) * WXSX + 4 * x_q;
         float *const vs_w = lds + L_VS + half * 8 * NT * WXS + x_tile * WXS + 4 * x_q;
         f32x2 e[3][4][2];
         auto xform_read = [&](auto par) {               // issue the 12 patch reads of this thread
@@ -193,7 +207,7 @@ __global__ __launch_bounds__(512, 2) void wino_pc_kernel(const ConvArgs a) {
             for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const f32x4 v = ld4(xs + (i * WIW + j) * WXS);
+                    const f32x4 v = ld4(xs + (i * RS + j) * WXSX);
                     e[i][j][0] = f32x2{v[0], v[1]}; e[i][j][1] = f32x2{v[2], v[3]};
                 }
         };

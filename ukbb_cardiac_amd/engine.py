@@ -170,6 +170,11 @@ class Engine:
         n = _lib.lib.ukbb_fcn_num_kernels(self._h)
         return [_lib.lib.ukbb_fcn_kernel_mfma_macs(self._h, i) for i in range(n)]
 
+    def kernel_mfma_macs_issued(self):
+        """MACs each launch issues to the matrix pipe INCLUDING tile / Winograd-region padding (= SQ_INSTS_MFMA x MACs per instruction)."""
+        n = _lib.lib.ukbb_fcn_num_kernels(self._h)
+        return [_lib.lib.ukbb_fcn_kernel_mfma_macs_issued(self._h, i) for i in range(n)]
+
     def kernel_configs(self):
         n = _lib.lib.ukbb_fcn_num_kernels(self._h)
         return [_lib.lib.ukbb_fcn_kernel_config(self._h, i) for i in range(n)]
