@@ -283,18 +283,22 @@ __device__ __forceinline__ void ws_main(const ConvArgs &a, const int grp, const 
     const int cst = KIND == 1 ? a.up2 : a.cout_store > 0 ? a.cout_store : a.Cout;
     const int OW = KIND == 1 ? 2 * a.Wo : a.Wo, OH = KIND == 1 ? 2 * a.Ho : a.Ho;
     const int out_plane_bytes = OH * OW * 32, out_img_bytes = (cst / 16) * out_plane_bytes;     // channel-blocked like the inputs
-    unsigned svoff[CB][4];
+    // Stores are 16 bytes per lane: the accumulator gives lane half g channels 8 j + 4 g .. + 3 of its pixel (8 bytes as bf16); for a pair
+    // of groups (jb, jb + 1) the halves exchange their packed values with v_permlane32_swap (lower lanes keep group jb and receive the
+    // partner's 8 bytes of it, upper lanes group jb + 1), so every lane then holds 8 consecutive channels = one 16-byte half of a pixel
+    // of the channel-blocked map.  Half as many store instructions, each 1 KB of whole 16-byte pieces.
+    unsigned svoff[CB][2];
     unroll_steps<CB>([&](auto cbc) {
         constexpr int cb = decltype(cbc)::value;
-        unroll_steps<4>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
+        unroll_steps<2>([&](auto pc) {
+            constexpr int jb = 2 * decltype(pc)::value;
             if constexpr (KIND == 0) {
-                const int chn = (grp * CB + cb) * 32 + 8 * j + 4 * g;
-                svoff[cb][j] = chn < cst ? (unsigned)((chn >> 4) * out_plane_bytes + pl * 32 + (chn & 15) * 2) : OOB;
+                const int chn = (grp * CB + cb) * 32 + 8 * (jb + g);
+                svoff[cb][jb / 2] = chn < cst ? (unsigned)((chn >> 4) * out_plane_bytes + pl * 32 + (chn & 15) * 2) : OOB;
             } else {
-                constexpr int ph = TM == 0 ? (cb == 0 ? 0 : 3) : TM == 1 ? (cb == 0 ? 1 : 2) : 2 * cb + (j >> 1);
-                const int co = TM == 2 ? 8 * (j & 1) + 4 * g : (grp >> 1) * 32 + 8 * j + 4 * g;
-                svoff[cb][j] = (unsigned)((co >> 4) * out_plane_bytes + (2 * pl + (ph & 1)) * 32 + (co & 15) * 2);
+                constexpr int ph = TM == 0 ? (cb == 0 ? 0 : 3) : TM == 1 ? (cb == 0 ? 1 : 2) : 2 * cb + (jb >> 1);
+                const int co = TM == 2 ? 8 * g : (grp >> 1) * 32 + 8 * (jb + g);
+                svoff[cb][jb / 2] = (unsigned)((co >> 4) * out_plane_bytes + (2 * pl + (ph & 1)) * 32 + (co & 15) * 2);
             }
         });
     });
@@ -385,36 +389,44 @@ __device__ __forceinline__ void ws_main(const ConvArgs &a, const int grp, const 
         }
         unsigned char *const obase = outb + (size_t)n * out_img_bytes;
         const bool colok = ox0 + pl < a.Wo;
-        unsigned vo[CB][4];
+        unsigned vo[CB][2];
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) vo[cb][j] = colok ? svoff[cb][j] : OOB;
+            for (int q = 0; q < 2; ++q) vo[cb][q] = colok ? svoff[cb][q] : OOB;
         unroll_steps<R>([&](auto rc) {
             constexpr int r = decltype(rc)::value;
             const int oy = oy0 + r;
             const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)obase, 0, (valid && oy < a.Ho) ? out_img_bytes : 0, 0x00020000);
             unroll_steps<CB>([&](auto cbc) {
                 constexpr int cb = decltype(cbc)::value;
-                unroll_steps<4>([&](auto jc) {
-                    constexpr int j = decltype(jc)::value;
+                unroll_steps<2>([&](auto pc) {
+                    constexpr int jb = 2 * decltype(pc)::value;
                     int srow;
                     if constexpr (KIND == 0) srow = (oy * a.Wo + ox0) * 32;
                     else {
-                        constexpr int ph = TM == 0 ? (cb == 0 ? 0 : 3) : TM == 1 ? (cb == 0 ? 1 : 2) : 2 * cb + (j >> 1);
+                        constexpr int ph = TM == 0 ? (cb == 0 ? 0 : 3) : TM == 1 ? (cb == 0 ? 1 : 2) : 2 * cb + (jb >> 1);
                         srow = ((2 * oy + (ph >> 1)) * OW + 2 * ox0) * 32;
                     }
-                    // (elements copied to scalars first: __builtin_bit_cast applied to an ext_vector element expression reads element 0, hipcc 7.2)
-                    const float e0 = acc[cb][r][4 * j + 0], e1 = acc[cb][r][4 * j + 1], e2 = acc[cb][r][4 * j + 2], e3 = acc[cb][r][4 * j + 3];
-                    f32x2 lo2, hi2;
-                    lo2.x = __builtin_bit_cast(float, max(__builtin_bit_cast(int, e0), relu_lo));
-                    lo2.y = __builtin_bit_cast(float, max(__builtin_bit_cast(int, e1), relu_lo));
-                    hi2.x = __builtin_bit_cast(float, max(__builtin_bit_cast(int, e2), relu_lo));
-                    hi2.y = __builtin_bit_cast(float, max(__builtin_bit_cast(int, e3), relu_lo));
-                    u32x2 pk;
-                    pk.x = __builtin_bit_cast(unsigned, __builtin_convertvector(lo2, bf16x2));
-                    pk.y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi2, bf16x2));
-                    __builtin_amdgcn_raw_buffer_store_b64(pk, ro, vo[cb][j], srow, 0);
+                    u32x2 pk[2];
+                    unroll_steps<2>([&](auto dc) {
+                        constexpr int j = jb + decltype(dc)::value;
+                        // (elements copied to scalars first: __builtin_bit_cast applied to an ext_vector element expression reads element 0, hipcc 7.2)
+                        const float e0 = acc[cb][r][4 * j + 0], e1 = acc[cb][r][4 * j + 1], e2 = acc[cb][r][4 * j + 2], e3 = acc[cb][r][4 * j + 3];
+                        f32x2 lo2, hi2;
+                        lo2.x = __builtin_bit_cast(float, max(__builtin_bit_cast(int, e0), relu_lo));
+                        lo2.y = __builtin_bit_cast(float, max(__builtin_bit_cast(int, e1), relu_lo));
+                        hi2.x = __builtin_bit_cast(float, max(__builtin_bit_cast(int, e2), relu_lo));
+                        hi2.y = __builtin_bit_cast(float, max(__builtin_bit_cast(int, e3), relu_lo));
+                        pk[j - jb].x = __builtin_bit_cast(unsigned, __builtin_convertvector(lo2, bf16x2));
+                        pk[j - jb].y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi2, bf16x2));
+                    });
+                    // v_permlane32_swap a, b: a's upper 32 lanes <-> b's lower 32 lanes.  Afterwards (a, b) of a lower lane = (own group jb,
+                    // partner's part of group jb), of an upper lane = (partner's part of group jb + 1, own): ascending channels either way.
+                    const auto sx = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+                    const auto sy = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+                    const u32x4 v = {sx[0], sy[0], sx[1], sy[1]};
+                    __builtin_amdgcn_raw_buffer_store_b128(v, ro, vo[cb][jb / 2], srow, 0);
                 });
             });
         });
