@@ -25,6 +25,8 @@
 // lanes 32-63, and the weights are packed on the host in that k order.
 #include "kernels.h"
 
+#include <cstdio>
+
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -484,6 +486,9 @@ __global__ __launch_bounds__(256, OCC) void fcn_head_kernel(const HeadArgs a) {
     }
 }
 
+#ifdef UKBB_DIAG
+__device__ unsigned long long g_hstamps[8];
+#endif
 // ---------------------------------------------------------------------------
 // Producer/consumer head (768 threads, persistent over 16x16 tiles, one workgroup per CU):
 //   waves 4-11 "producers": stage the G windows of upcoming tiles (global -> registers -> LDS,
@@ -761,11 +766,23 @@ __global__ __launch_bounds__(768) void fcn_head_pc_kernel(const HeadArgs a) {
             xv1 = ldg4(a.conv0 + q0 * 16 + 8 + 4 * g);
         }
         __syncthreads();                                // barrier X
+#ifdef UKBB_DIAG
+        // diagnostic build, UKBB_HEAD_STAMPS=1: where an MFMA wave's stage goes -- wait at barrier A (the producers' hand-off), the LDS
+        // read of the handed tile, wait at barrier B, everything else (MFMA chain + own vector work)
+        unsigned long long hs_a = 0, hs_r = 0, hs_b = 0, hs_t0 = __builtin_amdgcn_s_memtime();
+#define UKBB_HS(var, prev) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); var += t_ - prev; prev = t_; }
+#else
+#define UKBB_HS(var, prev)
+#endif
 #pragma unroll 1
         for (int s = 0; s < nstages; ++s) {
             const size_t q = pixel_of(s);
             const f32x4 x0 = xv0, x1 = xv1;
+#ifdef UKBB_DIAG
+            unsigned long long hs_p = __builtin_amdgcn_s_memtime();
+#endif
             __syncthreads();                            // barrier A_s: px[wave] ready
+            UKBB_HS(hs_a, hs_p)
             f32x16 P0, P1;
             {
                 const float *src = px + wave * PX_WAVE + lane * 4;
@@ -777,7 +794,9 @@ __global__ __launch_bounds__(768) void fcn_head_pc_kernel(const HeadArgs a) {
                     for (int i = 0; i < 4; ++i) { P0[4 * j + i] = v0[i]; P1[4 * j + i] = v1[i]; }
                 }
             }
+            UKBB_HS(hs_r, hs_p)
             __syncthreads();                            // barrier B_s: px may be overwritten
+            UKBB_HS(hs_b, hs_p)
             if (s + 1 < nstages) {                      // features of the next block: a whole stage to arrive
                 const size_t qn = pixel_of(s + 1);
                 xv0 = ldg4(a.conv0 + qn * 16 + 4 * g);
@@ -910,6 +929,12 @@ __global__ __launch_bounds__(768) void fcn_head_pc_kernel(const HeadArgs a) {
                 }
             }
         }
+#ifdef UKBB_DIAG
+        if (lane == 0 && (a.diag & 64)) {
+            atomicAdd(g_hstamps + 0, hs_a); atomicAdd(g_hstamps + 1, hs_r); atomicAdd(g_hstamps + 2, hs_b);
+            atomicAdd(g_hstamps + 3, __builtin_amdgcn_s_memtime() - hs_t0); atomicAdd(g_hstamps + 4, (unsigned long long)nstages);
+        }
+#endif
     }
 }
 
@@ -978,6 +1003,24 @@ hipError_t launch_head(const HeadArgs &a_in, hipStream_t s) {
 #endif
     if ((a.H % HT) || (a.W % HT)) return hipErrorInvalidValue;
     static const int use_pc = [] { const char *e = getenv("UKBB_HEAD_PC"); return e ? atoi(e) : 1; }();   // A/B knob
+#ifdef UKBB_DIAG
+    if (use_pc && getenv("UKBB_HEAD_STAMPS")) {        // the 6th stamped launch reports the MFMA waves' stage budget
+        static int shots = 0;
+        unsigned long long z[8] = {0};
+        a.diag |= 64;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_hstamps), z, 64);
+        const hipError_t e = launch_head_pc(a, s);
+        (void)hipStreamSynchronize(s);
+        if (++shots == 6) {
+            unsigned long long h[8];
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_hstamps), 64);
+            const double st = (double)h[4];
+            if (st > 0) fprintf(stderr, "[head stamps] per MFMA wave and stage (32-pixel block): wait at barrier A (hand-off) %.0f, read of the handed tile %.0f, wait at barrier B %.0f, "
+                                        "MFMA chain + own vector work %.0f; total %.0f cycles\n", h[0] / st, h[1] / st, h[2] / st, (h[3] - h[0] - h[1] - h[2]) / st, h[3] / st);
+        }
+        return e;
+    }
+#endif
     if (use_pc) return launch_head_pc(a, s);
     const HeadArgs &b = a;
     static const int occ = [] { const char *e = getenv("UKBB_HEAD_OCC"); return e ? atoi(e) : 3; }();   // tuning knob
