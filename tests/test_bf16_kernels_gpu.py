@@ -30,6 +30,11 @@ def test_weight_stationary_tilings_match_the_tile_per_workgroup_kernels():
                 'up0_0:400,401', 'up0_t:410,411,412', 'up1_t:410,411,412', 'up2_t:410,411,412', 'up0_1+logits:404,405,406')
     assert 'NOT TAKEN' not in out
     _tool('check_ws.py', 3, 256, 256, 'conv1_1:401', 'conv2_1:402', 'conv3_1:400', 'up1_0:401', 'up2_0:400', 'up0_t:410', 'up1_t:411', 'up2_t:411')
+    # the ring-streamed form (weights of one chunk at a time through a shared two-stage ring, one barrier per chunk): K = 2304 layers and,
+    # for the comparison with the resident-filter form, layers both can run (there the two must agree bit for bit: same summation order)
+    out = _tool('check_ws.py', 2, 64, 96, 'up3_0:420,421,422,423', 'conv4_1:421,423', 'conv3_1:421', 'up2_0:420,422', 'conv2_1:420')
+    assert 'NOT TAKEN' not in out
+    _tool('check_ws.py', 3, 256, 256, 'up3_0:420,422', 'conv4_1:422')
 
 
 def test_fused_tail_matches_the_unfused_plan():

@@ -319,6 +319,8 @@ bool cfg_valid(const ConvConfig &c, int ks, int stride, int c0, int c1, int cout
         if (ks == 2) {                                // transposed conv as 2x2 sub-pixel conv: cout = 4 x real channels (16, or multiples of 32)
             const int real = cout / 4;
             if (c1 || cout % 64 || (real != 16 && real % 32) || (real == 16 ? nch != 2 : (nch != 4 && nch != 8))) return false;
+        } else if (c.kc == 32) {                      // weights through a ring: any even number of chunks, source switch at an even chunk
+            if (ks != 3 || nch < 2 || (nch & 1) || (c1 && (c0 / 16) % 2)) return false;
         } else if (ks != 3 || (c1 && c1 != c0) || (nch != 1 && nch != 2 && nch != 4 && nch != 8) || (c1 && nch < 2)) return false;
         if (cout % (32 * c.cb)) return false;
         return ws_lds_bytes_for(c, c0 + c1) <= 160 * 1024;
@@ -378,10 +380,11 @@ int choose_cfg(const std::string &layer, int ks, int stride, int c0, int c1, int
 // PREC=bf16, profiles/r03_sweep_bf16.txt): {ks, stride, cin (both sources), cout (4 x cout for the 2x2 form of a transposed conv), cfg}.
 // Levels 2-4 sit on a 35-50 us floor per launch whatever the tiling (launch + first-load latency + tail at 100-400 tiles);
 // the table mostly avoids the bad cases (conv3_0 108 -> 47 us, up2_0 104 -> 80, conv2_0 61 -> 45).
-// r04: the weight-stationary persistent tilings (400-403, kernels_ws.hip) where a Cout group's whole filter fits LDS (K <= 1152)
+// r04: the weight-stationary persistent tilings (400-403, kernels_ws.hip) where a Cout group's whole filter fits LDS (K <= 1152); up3_0
+// (K = 2304) on the ring-streamed form 422 (72 vs 78 us; one barrier per chunk keeps it from the ws rate, r04_notes.md)
 const Tuned g_tuned_bfio[] = {
     {3, 1, 16, 16, 236, 232, -1},   {3, 1, 32, 32, 401, 232, -1},   {3, 1, 64, 64, 402, 235, 232},    {3, 1, 128, 128, 400, 235, 232},
-    {3, 1, 256, 256, 239, 232, -1}, {3, 1, 256, 128, 239, 232, -1}, {3, 1, 128, 64, 400, 239, 232},  {3, 1, 64, 32, 401, 232, -1},
+    {3, 1, 256, 256, 239, 232, -1}, {3, 1, 256, 128, 422, 239, 232}, {3, 1, 128, 64, 400, 239, 232},  {3, 1, 64, 32, 401, 232, -1},
     {3, 1, 32, 16, 401, 236, 232},
     {3, 2, 16, 32, 241, -1, -1},    {3, 2, 32, 64, 242, 241, -1},   {3, 2, 64, 128, 244, 241, -1},  {3, 2, 128, 256, 244, 241, -1},
     {2, 1, 256, 512, 253, 251, -1}, {2, 1, 128, 256, 411, 253, 251}, {2, 1, 64, 128, 411, 253, 251},  {2, 1, 32, 64, 410, 258, 253},

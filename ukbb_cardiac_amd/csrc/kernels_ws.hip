@@ -484,6 +484,231 @@ __device__ __forceinline__ void ws_main(const ConvArgs &a, const int grp, const 
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Weights THROUGH A RING (tilings 420-): the same machine for layers whose Cout group's filter does not fit LDS (K = 9 x 256: 147 KB
+// for 32 output channels -- up3_0, conv4_1 of network_ao.py).  The activations keep their private per-wave rings and tiles; the packed
+// weights of ONE 16-channel chunk (9 KB per Cout block) stream through a two-stage ring shared by the workgroup: every thread fetches
+// its share of chunk c + 2 while chunk c is multiplied, and ONE barrier per chunk hands stage (c + 1) & 1 over (written after the
+// barrier that follows the last read of its previous content, read after the next one).  The waves of a workgroup therefore run their
+// tiles in lockstep per chunk (a wave without a tile left runs a ghost tile: out-of-range loads, dropped stores), and the chunk loop is a
+// run-time loop unrolled by two (register-set / stage parity) -- the weights of any number of chunks stream through the same code.
+template <int R, int CB, int NW>
+__device__ __forceinline__ void wr_main(const ConvArgs &a, const int grp, const int walker, const int nwalk) {
+    constexpr int KIND = 0, WS_IW = ws_iw(KIND), HR = ws_hr(KIND, R);
+    constexpr int HP = HR * WS_IW, NLD = ws_nld(KIND, R), STAGE = ws_stage_bytes(KIND, R), PLANE = ws_plane_bytes(KIND, R);
+    constexpr int WCH = CB * 9 * 1024;                  // bytes of one chunk of this group's packed weights: [cb][tap][lane][16]
+    constexpr int NWL = (WCH / 16 + NW * 64 - 1) / (NW * 64);      // 16-byte pieces per thread and chunk
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char *const wring = lds;                   // [2][WCH]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
+    const int g = lane >> 5, pl = lane & 31;
+    unsigned char *const ring = lds + 2 * WCH + wave * (2 * STAGE);
+    const int nch = (a.C0 + a.C1) / 16, nch0 = a.C0 / 16;
+
+    const int tiles = a.tiles_x * a.tiles_y, ntiles = a.N * tiles;
+    const int worker = wave * nwalk + walker, nworkers = nwalk * NW;
+    const int my = worker < ntiles ? (ntiles - worker + nworkers - 1) / nworkers : 0;
+    // rounds of the whole workgroup = the largest tile count among its waves (wave 0 has it: worker ids grow with the wave index)
+    const int rounds = walker < ntiles ? (ntiles - walker + nworkers - 1) / nworkers : 0;
+    if (rounds == 0) return;                            // uniform over the workgroup
+
+    // ---- staging geometry of the activations (as ws_main) ----
+    unsigned geo[NLD], pbase[NLD], lofs[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int p = lane + 64 * i, gg = p & 1, px = p >> 1;
+        const int hy = px / WS_IW, hx = px - hy * WS_IW;
+        geo[i] = (unsigned)hy | ((unsigned)hx << 8) | (px < HP ? 0u : OOB);
+        pbase[i] = (unsigned)((hy * a.W + hx) * 32 + 16 * gg);
+        lofs[i] = (unsigned)((px < HP ? gg * PLANE + px * 16 : 2 * PLANE + (lane & 1) * 16));
+    }
+    const unsigned char *const in0 = reinterpret_cast<const unsigned char *>(a.in0);
+    const unsigned char *const in1 = reinterpret_cast<const unsigned char *>(a.in1);
+    const int plane_bytes = a.H * a.W * 32;
+    const int nb0 = a.C0 / 16, nb1 = a.C1 / 16;
+    auto tile_coords = [&](int k, int &n, int &oy0, int &ox0) -> bool {
+        const bool valid = k < my;
+        const int t = valid ? worker + k * nworkers : 0;
+        n = t / tiles;
+        const int r = t - n * tiles, ty = r / a.tiles_x;
+        oy0 = ty * R; ox0 = (r - ty * a.tiles_x) * WS_TW;
+        return valid;
+    };
+    unsigned voff[NLD];
+    __amdgpu_buffer_rsrc_t rs0, rs1;
+    auto load_setup = [&](int k) {
+        int n, oy0, ox0;
+        const bool valid = tile_coords(k, n, oy0, ox0);
+        rs0 = __builtin_amdgcn_make_buffer_rsrc((void *)(in0 + (size_t)n * nb0 * plane_bytes), 0, nb0 * plane_bytes, 0x00020000);
+        rs1 = __builtin_amdgcn_make_buffer_rsrc((void *)((nb1 ? in1 : in0) + (size_t)n * (nb1 ? nb1 : nb0) * plane_bytes), 0, (nb1 ? nb1 : nb0) * plane_bytes, 0x00020000);
+        const int toff = ((oy0 - 1) * a.W + (ox0 - 1)) * 32;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int hy = (int)(geo[i] & 0xffu), hx = (int)((geo[i] >> 8) & 0xffu);
+            const bool ok = valid && !(geo[i] & OOB) && (unsigned)(oy0 - 1 + hy) < (unsigned)a.H && (unsigned)(ox0 - 1 + hx) < (unsigned)a.W;
+            voff[i] = ok ? pbase[i] + (unsigned)toff : OOB;
+        }
+    };
+    // weights of this group: [chunk][cb][tap][lane][16] contiguous per chunk
+    const unsigned char *const wsrc = reinterpret_cast<const unsigned char *>(a.wpk) + (size_t)grp * nch * WCH;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void *)wsrc, 0, nch * WCH, 0x00020000);
+    unsigned wvo[NWL];
+#pragma unroll
+    for (int i = 0; i < NWL; ++i) wvo[i] = (tid + i * (NW * 64)) * 16 < WCH ? (unsigned)((tid + i * (NW * 64)) * 16) : OOB;
+
+    u32x4 xq[2][NLD], wq[2][NWL];
+    int lk = 0, lch = 0;                                // load cursor: tile (among this wave's), chunk
+    auto request = [&](auto setc) {                     // activations of (tile lk, chunk lch) and this thread's share of the weights of chunk lch
+        constexpr int SET = decltype(setc)::value;
+        const bool second = lch >= nch0;
+        const int soff = (second ? lch - nch0 : lch) * plane_bytes;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) xq[SET][i] = __builtin_amdgcn_raw_buffer_load_b128(second ? rs1 : rs0, voff[i], soff, 0);
+#pragma unroll
+        for (int i = 0; i < NWL; ++i) wq[SET][i] = __builtin_amdgcn_raw_buffer_load_b128(rw, wvo[i], lch * WCH, 0);
+        if (++lch == nch) { lch = 0; ++lk; load_setup(lk); }
+    };
+    auto park = [&](auto setc) {                        // register set SET -> activation stage SET and weight stage SET
+        constexpr int SET = decltype(setc)::value;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) *reinterpret_cast<u32x4 *>(ring + SET * STAGE + lofs[i]) = xq[SET][i];
+#pragma unroll
+        for (int i = 0; i < NWL; ++i)
+            if ((tid + i * (NW * 64)) * 16 < WCH) *reinterpret_cast<u32x4 *>(wring + SET * WCH + (tid + i * (NW * 64)) * 16) = wq[SET][i];
+    };
+
+    // ---- compute (fragment reads pipelined by hand as in ws_main; a chunk = S steps, two chunks per unrolled body) ----
+    constexpr int NGRP = 3, NAF = 3, S = NGRP * HR, PD = 3, NB = 4, U = 2;
+    static_assert((U * S) % NB == 0, "fragment buffers rotate consistently across loop iterations");
+    f32x16 acc[CB][R], biasv[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(a.bias + (grp * CB + cb) * 32 + 8 * j + 4 * g);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) biasv[cb][4 * j + i] = b4[i];
+        }
+    const unsigned char *const xs_lane = ring + g * PLANE + pl * 16;
+    const unsigned char *const ws_lane = wring + lane * 16;
+    u32x4 Bq[NB], Aq[2][CB][NAF];
+    auto readB = [&](auto tc) {
+        constexpr int TT = decltype(tc)::value, T = TT % (U * S), Qn = T / S, s = T % S, kw = s / HR, rp = s % HR;
+        Bq[TT % NB] = *reinterpret_cast<const u32x4 *>(xs_lane + (Qn & 1) * STAGE + (rp * WS_IW + kw) * 16);
+    };
+    auto readA = [&](auto gc) {                         // (chunk parity, kw) group
+        constexpr int GG = decltype(gc)::value, G = GG % (U * NGRP), Qn = G / NGRP, kw = G % NGRP;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+                Aq[GG & 1][cb][kh] = *reinterpret_cast<const u32x4 *>(ws_lane + (Qn & 1) * WCH + (cb * 9 + kh * 3 + kw) * 1024);
+    };
+    auto compute = [&](auto qc) {                       // chunk of parity Q: activation stage Q, weight stage Q
+        constexpr int Q = decltype(qc)::value;
+        unroll_steps<S>([&](auto sc) {
+            constexpr int s = decltype(sc)::value, T = Q * S + s, kw = s / HR, rp = s % HR, G = Q * NGRP + kw;
+            // the reads of the NEXT chunk's first steps / first A group may only go out once its stages are visible: they are issued by
+            // the caller behind the barrier (T + PD >= S of the last chunk before a barrier is handled by splitting the prefetch there)
+            if constexpr (s + PD < S) readB(std::integral_constant<int, T + PD>{});
+            if constexpr (rp == 0 && kw + 1 < NGRP) readA(std::integral_constant<int, G + 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            unroll_steps<NAF>([&](auto khc) {
+                constexpr int kh = decltype(khc)::value, r = rp - kh;
+                if constexpr (r >= 0 && r < R) {
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb) acc[cb][r] = mfma_bf16(Aq[G & 1][cb][kh], Bq[T % NB], acc[cb][r]);
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    auto prime = [&](auto qc) {                         // first reads of chunk parity Q (behind the barrier that made its stages visible)
+        constexpr int Q = decltype(qc)::value;
+        readA(std::integral_constant<int, Q * NGRP>{});
+        unroll_steps<PD>([&](auto tc) { readB(std::integral_constant<int, Q * S + decltype(tc)::value>{}); });
+    };
+
+    // ---- epilogue (as ws_main KIND 0: 16-byte stores through v_permlane32_swap) ----
+    unsigned char *const outb = reinterpret_cast<unsigned char *>(a.out);
+    const int cst = a.cout_store > 0 ? a.cout_store : a.Cout;
+    const int out_plane_bytes = a.Ho * a.Wo * 32, out_img_bytes = (cst / 16) * out_plane_bytes;
+    unsigned svoff[CB][2];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int chn = (grp * CB + cb) * 32 + 8 * (2 * q + g);
+            svoff[cb][q] = chn < cst ? (unsigned)((chn >> 4) * out_plane_bytes + pl * 32 + (chn & 15) * 2) : OOB;
+        }
+    const int relu_lo = a.relu ? 0 : (int)0x80000000;
+    auto epilogue = [&](int k) {
+        int n, oy0, ox0;
+        const bool valid = tile_coords(k, n, oy0, ox0);
+        unsigned char *const obase = outb + (size_t)n * out_img_bytes;
+        const bool colok = ox0 + pl < a.Wo;
+        unroll_steps<R>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            const int oy = oy0 + r;
+            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)obase, 0, (valid && oy < a.Ho) ? out_img_bytes : 0, 0x00020000);
+            const int srow = (oy * a.Wo + ox0) * 32;
+            unroll_steps<CB>([&](auto cbc) {
+                constexpr int cb = decltype(cbc)::value;
+                unroll_steps<2>([&](auto pc) {
+                    constexpr int jb = 2 * decltype(pc)::value;
+                    u32x2 pk[2];
+                    unroll_steps<2>([&](auto dc) {
+                        constexpr int j = jb + decltype(dc)::value;
+                        const float e0 = acc[cb][r][4 * j + 0], e1 = acc[cb][r][4 * j + 1], e2 = acc[cb][r][4 * j + 2], e3 = acc[cb][r][4 * j + 3];
+                        f32x2 lo2, hi2;
+                        lo2.x = __builtin_bit_cast(float, max(__builtin_bit_cast(int, e0), relu_lo));
+                        lo2.y = __builtin_bit_cast(float, max(__builtin_bit_cast(int, e1), relu_lo));
+                        hi2.x = __builtin_bit_cast(float, max(__builtin_bit_cast(int, e2), relu_lo));
+                        hi2.y = __builtin_bit_cast(float, max(__builtin_bit_cast(int, e3), relu_lo));
+                        pk[j - jb].x = __builtin_bit_cast(unsigned, __builtin_convertvector(lo2, bf16x2));
+                        pk[j - jb].y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi2, bf16x2));
+                    });
+                    const auto sx = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+                    const auto sy = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+                    const u32x4 v = {sx[0], sy[0], sx[1], sy[1]};
+                    __builtin_amdgcn_raw_buffer_store_b128(v, ro, colok ? svoff[cb][jb / 2] : OOB, srow, 0);
+                });
+            });
+        });
+    };
+
+    constexpr std::integral_constant<int, 0> S0{};
+    constexpr std::integral_constant<int, 1> S1{};
+    // ---- flattened (round, chunk) sequence, position q: stage / register set q & 1.  Iteration q: barrier; park q + 1; request q + 3;
+    //      compute q.  nch is even for every layer this kernel serves (checked by the launcher), so a tile starts at an even position.
+    load_setup(0);
+    request(S0);                                        // q = 0
+    request(S1);                                        // q = 1
+    park(S0);
+    request(S0);                                        // q = 2
+    const int total = rounds * nch;
+    int ck = 0, cch = 0;                                // compute cursor
+    auto step = [&](auto qc) {
+        constexpr int Q = decltype(qc)::value;          // parity of the position being computed
+        __syncthreads();                                // stage Q (parked an iteration ago) visible; stage Q ^ 1 free (its chunk was multiplied an iteration ago)
+        if constexpr (Q == 0) { park(S1); request(S1); } else { park(S0); request(S0); }
+        prime(qc);
+        if (cch == 0) {
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[cb][r] = biasv[cb];
+        }
+        compute(qc);
+        if (++cch == nch) { cch = 0; epilogue(ck); ++ck; }
+    };
+#pragma unroll 1
+    for (int q = 0; q < total; q += 2) { step(S0); step(S1); }
+}
+
 // ---- workgroup -> (Cout group, walker).  Workgroups b and b + 8 share an XCD (observed round-robin placement, speed only):
 //      the nG workgroups that walk the same tiles with different Cout groups are given equal b % 8 so that a tile is fetched
 //      into ONE per-XCD L2.
@@ -504,6 +729,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_ws_kernel(const ConvArgs
     int grp, walker, nwalk;
     ws_place(a.Cout / (32 * CB), grp, walker, nwalk);
     ws_main<0, R, CB, NW, NCH, TWO, 0, LG>(a, grp, walker, nwalk);
+}
+
+template <int R, int CB, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void conv_wr_kernel(const ConvArgs a) {
+    int grp, walker, nwalk;
+    ws_place(a.Cout / (32 * CB), grp, walker, nwalk);
+    wr_main<R, CB, NW>(a, grp, walker, nwalk);
 }
 
 // transposed conv: R input rows per tile; C16: Cout = 16 (a block holds two phases), else the block pairing alternates with the group
@@ -529,6 +761,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void tconv_ws_kernel(const ConvArg
     L(404, 4, 4)                    \
     L(405, 2, 8)                    \
     L(406, 4, 8)
+// S(id, R, CB, NW): weights through a ring (any even number of chunks): ConvConfig::kc = 32 marks them (two chunks per loop body)
+#define UKBB_WR_CONFIGS(S)          \
+    S(420, 4, 2, 4)                 \
+    S(421, 4, 1, 4)                 \
+    S(422, 2, 2, 8)                 \
+    S(423, 2, 1, 8)
 // T(id, R, NW): the transposed conv as 2x2 sub-pixel conv (ks 2), th = R input rows, two paired 32-row blocks per workgroup (cb 2)
 #define UKBB_WST_CONFIGS(T)         \
     T(410, 4, 4)                    \
@@ -541,7 +779,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void tconv_ws_kernel(const ConvArg
     {ID, 2, 1, 32, R, WS_TW, 16, 1, NW, 2, 0, 6, "tconvBF16ws_2x2_r" #R "x32_cb2_w" #NW, 0},
 #define UKBB_WSL_ENTRY(ID, R, NW) \
     {ID, 3, 1, 32, R, WS_TW, 16, 1, NW, 1, 0, 6, "convBF16ws_3x3s1+logits_r" #R "x32_cb1_w" #NW, 2},
-static const ConvConfig g_ws_cfgs[] = {UKBB_WS_CONFIGS(UKBB_WS_ENTRY) UKBB_WSL_CONFIGS(UKBB_WSL_ENTRY) UKBB_WST_CONFIGS(UKBB_WST_ENTRY)};
+#define UKBB_WR_ENTRY(ID, R, CB, NW) \
+    {ID, 3, 1, 32, R, WS_TW, 32, 1, NW, CB, 0, 6, "convBF16wr_3x3s1_r" #R "x32_cb" #CB "_w" #NW, 0},
+static const ConvConfig g_ws_cfgs[] = {UKBB_WS_CONFIGS(UKBB_WS_ENTRY) UKBB_WSL_CONFIGS(UKBB_WSL_ENTRY) UKBB_WST_CONFIGS(UKBB_WST_ENTRY) UKBB_WR_CONFIGS(UKBB_WR_ENTRY)};
 
 // Order of the 4 x cout phase-major virtual channels (phase = 2 py + px, then channel) in the packed filter / bias of the transposed
 // conv tilings: dst column v takes source column wst_pack_order(cout, v).  cout = 16: unchanged (blocks {00 + 01}, {10 + 11}).
@@ -555,7 +795,10 @@ int wst_pack_order(int cout, int v) {
 
 int num_ws_configs() { return (int)(sizeof(g_ws_cfgs) / sizeof(g_ws_cfgs[0])); }
 const ConvConfig &ws_config(int i) { return g_ws_cfgs[i]; }
-int ws_lds_bytes_for(const ConvConfig &c, int cin) { return ws_lds_bytes(c.ks == 2 ? 1 : 0, c.th, c.cb, c.wn, cin / 16); }
+int ws_lds_bytes_for(const ConvConfig &c, int cin) {
+    if (c.kc == 32) return 2 * c.cb * 9 * 1024 + c.wn * 2 * ws_stage_bytes(0, c.th);      // ring tilings: two weight stages, whatever the K
+    return ws_lds_bytes(c.ks == 2 ? 1 : 0, c.th, c.cb, c.wn, cin / 16);
+}
 
 namespace {
 template <class K>
@@ -585,6 +828,15 @@ hipError_t launch_ws_cfg(const ConvArgs &a, int grid, hipStream_t s) {
         case 8: return two ? launch_ws_one<R, CB, NW, 8, true>(a, grid, s) : launch_ws_one<R, CB, NW, 8, false>(a, grid, s);
         default: return hipErrorInvalidValue;
     }
+}
+template <int R, int CB, int NW>
+hipError_t launch_wr_cfg(const ConvArgs &a, int grid, hipStream_t s) {
+    const int nch = (a.C0 + a.C1) / 16;
+    if (nch < 2 || (nch & 1) || (a.C1 && (a.C0 / 16) % 2)) return hipErrorInvalidValue;   // two chunks per loop body; a source switch at an even chunk
+    constexpr int bytes = 2 * CB * 9 * 1024 + NW * 2 * ws_stage_bytes(0, R);
+    static_assert(bytes <= 160 * 1024, "LDS");
+    static OncePerDevice lds_ok;
+    return launch_ws_kernel(conv_wr_kernel<R, CB, NW>, bytes, NW * 64, a, grid, s, lds_ok);
 }
 template <int R, int NW>
 hipError_t launch_wsl_cfg(const ConvArgs &a, int grid, hipStream_t s) {
@@ -621,12 +873,13 @@ hipError_t launch_conv_ws(int cfg_id, const ConvArgs &a_in, hipStream_t s) {
     ConvArgs a = a_in;
     const bool tconv = c->ks == 2;
     if (a.in0_map || a.first_w || (a.lg_w != nullptr) != (c->fuse == 2)) return hipErrorInvalidValue;
+    const bool ring = c->kc == 32;
     if (tconv) {
         // virtual channels = 4 phases x up2 real ones, packed in the paired block order of wst_pack_order(); one source
         if (a.up2 < 16 || a.up2 % 16 || (a.up2 > 16 && a.up2 % 32) || a.Cout != 4 * a.up2 || a.C1 || a.in1) return hipErrorInvalidValue;
     } else {
         if (a.up2) return hipErrorInvalidValue;
-        if (a.C1 && a.C1 != a.C0) return hipErrorInvalidValue;     // the K loop switches source at the half
+        if (a.C1 && a.C1 != a.C0 && !ring) return hipErrorInvalidValue;     // the K loop switches source at the half
     }
     if (a.C0 % 16 || a.Cout % (32 * c->cb) || a.pad_y != 1 || a.pad_x != 1 || a.Ho != a.H || a.Wo != a.W) return hipErrorInvalidValue;
     const long long out_ch = tconv ? 4ll * a.up2 : a.Cout;         // bytes of the largest map of one image must fit a buffer range
@@ -683,6 +936,8 @@ hipError_t launch_conv_ws(int cfg_id, const ConvArgs &a_in, hipStream_t s) {
     switch (cfg_id) {
 #define UKBB_WS_CASE(ID, R, CB, NW) case ID: return launch_ws_cfg<R, CB, NW>(a, grid, s);
         UKBB_WS_CONFIGS(UKBB_WS_CASE)
+#define UKBB_WR_CASE(ID, R, CB, NW) case ID: return launch_wr_cfg<R, CB, NW>(a, grid, s);
+        UKBB_WR_CONFIGS(UKBB_WR_CASE)
 #define UKBB_WSL_CASE(ID, R, NW) case ID: return launch_wsl_cfg<R, NW>(a, grid, s);
         UKBB_WSL_CONFIGS(UKBB_WSL_CASE)
 #define UKBB_WST_CASE(ID, R, NW) case ID: return launch_wst_cfg<R, NW>(a, grid, s);
