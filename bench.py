@@ -102,9 +102,19 @@ def cpu_quota():
 def smi_sclk_mhz():
     """Best effort: the shader clock rocm-smi reports right now (None when the tool or the permission is missing)."""
     import re
+    import shutil
     import subprocess
+    # Under a profiler (rocprofv3 preloads a library that initialises the GPU in every child) a `#!/usr/bin/env python3` tool is an exec
+    # from a GPU-initialised process, which this pool refuses: no probe there, and everywhere else the tool is started with this
+    # interpreter directly, in an environment without the preload.
+    if any('rocprof' in os.environ.get(k, '').lower() for k in ('LD_PRELOAD', 'HSA_TOOLS_LIB', 'ROCP_TOOL_LIBRARIES')):
+        return None
+    tool = shutil.which('rocm-smi')
+    if tool is None:
+        return None
+    env = {k: v for k, v in os.environ.items() if k not in ('LD_PRELOAD', 'HSA_TOOLS_LIB')}
     try:
-        r = subprocess.run(['rocm-smi', '--showclocks'], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=10)
+        r = subprocess.run([sys.executable, tool, '--showclocks'], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=10, env=env)
         m = re.search(r'sclk clock level:?\s*\d*:?\s*\(?(\d+)\s*Mhz', r.stdout, flags=re.I)
         return int(m.group(1)) if m else None
     except Exception:

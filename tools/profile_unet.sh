@@ -3,7 +3,7 @@
 # stats and hardware-counter passes of the bf16 path (counters in runs of their own, never with --kernel-trace).
 # usage: tools/profile_unet.sh r03   -> gpurun_out/r03_unet/{unet.txt,kernels_bf16.txt,kernel_stats.csv,pmc/summary.csv,roofline.txt}
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/${TAG}_unet
 mkdir -p "$OUT/pmc"

@@ -26,8 +26,10 @@ for _ in range(5): eng.run_device(x.data_ptr(), n, H, W, pred_ptr=pred.data_ptr(
 ms, cnt = eng.kernel_times()
 macs = eng.kernel_macs()
 tot = 0
+bf = len(sys.argv) > 2 and sys.argv[2] == 'bf16'
+peak = 2500e12 if bf else 157.3e12                                 # dense bf16 / fp32 MFMA peak (MI355X_MICROARCH.md)
 for nm, cfg, m, c, mac in zip(eng.kernel_names(), eng.kernel_configs(), ms, cnt, macs):
     t = m / c
     tot += t
-    print('%-10s cfg %4d %-48s %7.1f us  %.2f of peak (reference-graph FLOPs)' % (nm, cfg, _lib.lib.ukbb_fcn_conv_config_name(cfg).decode() if cfg >= 0 else '', t * 1e3, 2 * mac / (t * 1e-3) / 157.3e12))
+    print('%-10s cfg %4d %-48s %7.1f us  %.3f of the %s MFMA peak (reference-graph FLOPs)' % (nm, cfg, _lib.lib.ukbb_fcn_conv_config_name(cfg).decode() if cfg >= 0 else '', t * 1e3, 2 * mac / (t * 1e-3) / peak, 'bf16' if bf else 'fp32'))
 print('sum %.1f us -> %.0f slices/s ; untimed stream: %.1f us per forward -> %.0f slices/s' % (tot * 1e3, n / (tot * 1e-3), wall * 1e6, n / wall))

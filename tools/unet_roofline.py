@@ -54,7 +54,8 @@ def main(out):
         alg += lv[l] * 2 * 2                                    # conv{l}_0 written + read
         alg += lv[l] * 2 * (3 if l < 4 else 2)                  # conv{l}_1 written, read by the next level and (l < 4) by the decoder
     for l in range(3, -1, -1):
-        alg += lv[l] * 2 * 2 * (3 if l > 0 else 2)              # up{l}_t, up{l}_0, up{l}_1 written + read (up0_1 is never stored)
+        # up{l}_t, up{l}_0, up{l}_1 written + read; at level 0 (r04: fused tail, kernels_tail.hip) only up0_t exists in HBM
+        alg += lv[l] * 2 * 2 * (3 if l > 0 else 1)
     alg += H * W * 4                                            # pred out
     alg *= n
     print('aortic U-Net, UKBB_PREC_BF16, N = %d x %dx%d, %s ms per forward (un-profiled run), %d kernel launches per forward' % (
