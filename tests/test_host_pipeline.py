@@ -415,6 +415,183 @@ def test_label_gzip_reports_a_short_buffer():
     assert _lib.lib.ukbb_fcn_gzip_labels(lab.ctypes.data, lab.size, 1024, b'', 0, out.ctypes.data, cap) == -1         # int64: not offered
 
 
+# ---- whole-file gzip decoder (csrc/gz_inflate.cpp, ukbb_fcn_gunzip) ------------------------------------------------------------
+
+def _gunzip(blob, cap, verify=1):
+    from ukbb_cardiac_amd import _labelgz
+    src = np.frombuffer(blob, np.uint8) if len(blob) else np.zeros(1, np.uint8)
+    dst = np.empty(cap + 1, np.uint8)
+    dst[cap] = 0xA5                                                           # canary behind the capacity
+    r = int(_labelgz.lib.ukbb_fcn_gunzip(src.ctypes.data, len(blob), dst.ctypes.data, cap, verify))
+    assert dst[cap] == 0xA5
+    return r, dst[:max(r, 0)].tobytes()
+
+
+def _deflate(raw, level=6, strategy=0):
+    import zlib
+    co = zlib.compressobj(level, zlib.DEFLATED, 31, 9, strategy)
+    return co.compress(raw) + co.flush()
+
+
+def test_gunzip_inflates_what_zlib_writes_at_every_level_and_strategy():
+    """Stored, fixed-Huffman (Z_FIXED), dynamic blocks, Huffman-only, RLE; match distances 1..32768 (every copy width of the
+    decoder); output buffers of exactly the content's size (the last 320 bytes go through the careful loop) and larger."""
+    import zlib
+    rng = np.random.default_rng(3)
+    cases = [b'', b'a', b'hello hello hello hello', bytes(200000), rng.integers(0, 256, 70000, dtype=np.uint8).tobytes(),
+             rng.integers(0, 4, 120000, dtype=np.uint8).tobytes(), np.cumsum(rng.normal(0, 3, 150000)).astype(np.int16).tobytes(),
+             np.round(rng.gamma(2.0, 300.0, 60000)).astype(np.float32).tobytes(),
+             b''.join(b'the quick brown fox %d jumps over the lazy dog\n' % i for i in range(6000))]
+    for d in (1, 2, 3, 5, 7, 8, 9, 15, 16, 17, 31, 33, 258, 259, 4097, 32768):
+        cases.append((rng.integers(0, 256, d, dtype=np.uint8).tobytes() * (90000 // d + 2))[:90000])
+    for raw in cases:
+        for level, strategy in ((1, 0), (6, 0), (9, 0), (0, 0), (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE)):
+            g = _deflate(raw, level, strategy)
+            for cap in (len(raw), len(raw) + 777):
+                r, out = _gunzip(g, cap)
+                assert r == len(raw) and out == raw, (len(raw), level, strategy, cap, r)
+            if raw:
+                assert _gunzip(g, len(raw) - 1)[0] == -4                      # UKBB_ENOMEM: does not fit
+
+
+def test_gunzip_members_padding_names_and_what_it_refuses():
+    import gzip
+    import io
+    rng = np.random.default_rng(4)
+    a, b = rng.integers(0, 7, 50000, dtype=np.uint8).tobytes(), np.cumsum(rng.normal(0, 2, 40000)).astype(np.int16).tobytes()
+    g = _deflate(a) + b'\x00' * 5 + _deflate(b, 1) + b'\x00' * 100
+    assert _gunzip(g, len(a) + len(b)) == (len(a) + len(b), a + b)
+    bio = io.BytesIO()
+    with gzip.GzipFile(filename='cine.nii', mode='wb', fileobj=bio, mtime=1234) as f:     # FNAME + MTIME
+        f.write(b)
+    assert _gunzip(bio.getvalue(), len(b)) == (len(b), b)
+    g = _deflate(a)
+    assert _gunzip(g + b'junk', len(a))[0] == -1                              # trailing bytes that are no member
+    assert _gunzip(g[:3] + bytes([g[3] | 2]) + g[4:], len(a))[0] == -1       # FHCRC: left to zlib
+    assert _gunzip(b'\x1f\x8b\x07' + g[3:], len(a))[0] == -1                  # not deflate
+    for cut in list(range(0, 30)) + list(range(len(g) - 30, len(g))):
+        assert _gunzip(g[:cut], len(a))[0] < 0, cut
+    bad = bytearray(g); bad[-6] ^= 0x10                                       # CRC-32
+    assert _gunzip(bytes(bad), len(a))[0] == -1 and _gunzip(bytes(bad), len(a), verify=0) == (len(a), a)
+    bad = bytearray(g); bad[-2] ^= 0x10                                       # ISIZE
+    assert _gunzip(bytes(bad), len(a))[0] == -1
+
+
+def test_gunzip_agrees_with_zlib_on_corrupted_and_random_streams():
+    """Whatever it accepts, zlib accepts with the same bytes (a flipped distance bit that lands on an identical run, padding bits);
+    it never writes behind the capacity, never crashes (run under the address sanitiser by the test below)."""
+    import zlib
+    from ukbb_cardiac_amd import _labelgz
+    rng = np.random.default_rng(5)
+    raw = np.cumsum(rng.normal(0, 3, 60000)).astype(np.int16).tobytes()
+    g = _deflate(raw)
+    accepted = 0
+    for _ in range(4000):
+        bad = bytearray(g)
+        for _ in range(int(rng.integers(1, 3))):
+            bad[int(rng.integers(10, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+        r, out = _gunzip(bytes(bad), len(raw))
+        if r >= 0:
+            accepted += 1
+            z = zlib.decompressobj(31)
+            assert z.decompress(bytes(bad)) == out and z.eof
+    hdr = b'\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\x03'
+    for i in range(20000):
+        body = rng.integers(0, 256, int(rng.integers(0, 300)), dtype=np.uint8).tobytes()
+        if i % 3 == 0:
+            body = bytes([int(rng.integers(0, 8)) | 4]) + body                 # more dynamic-block headers
+        r, out = _gunzip(hdr + body, int(rng.integers(0, 3000)))
+        if r >= 0:
+            z = zlib.decompressobj(31)
+            assert z.decompress(hdr + body) == out and z.eof
+    for n in list(range(0, 200)) + [1000, 4096, 65537, 1 << 20]:              # CRC-32: table path, carry-less path, every tail length
+        d = rng.integers(0, 256, n, dtype=np.uint8)
+        for init in (0, 0x12345678):
+            assert _labelgz.lib.ukbb_fcn_gzip_crc(init, d.ctypes.data, n) == zlib.crc32(d.tobytes(), init)
+
+
+def test_load_takes_the_whole_file_decoder_and_falls_back_to_zlib(tmp_path):
+    """nifti.load of a .nii.gz: same arrays from the whole-file decoder and from the zlib reader (plain, alloc'd, alloc'd with headroom
+    = decoded in place, big-endian, scaled); streams the decoder refuses still load -- or raise -- through zlib as before."""
+    import gzip
+    import zlib
+    from ukbb_cardiac_amd import nifti, _labelgz
+    rng = np.random.default_rng(6)
+    vol = np.round(rng.gamma(2.0, 300.0, (40, 36, 3, 7))).astype(np.float32)
+    p = str(tmp_path / 'v.nii.gz')
+    nifti.save(vol, p, np.eye(4))
+    calls = []
+    real = _labelgz.lib.ukbb_fcn_gunzip
+
+    class Spy:                                                                # counts calls and results of the native decoder
+        def __call__(self, *a):
+            r = real(*a)
+            calls.append(int(r))
+            return r
+    _labelgz.lib.ukbb_fcn_gunzip = Spy()
+    try:
+        assert np.array_equal(nifti.load(p).get_data(), vol) and calls == [352 + vol.nbytes]
+        buf = np.empty(vol.shape, np.float32, order='F')
+        assert nifti.load(p, alloc=lambda sh, dt: buf).get_data() is buf and np.array_equal(buf, vol)
+        # headroom: the header lands in front of the array, the voxels in it, nothing behind it
+        flat = np.full(1024 + vol.size + 16, np.float32(-7.0))
+        view = flat[1024:1024 + vol.size].reshape(vol.shape, order='F')
+        out = nifti.load(p, alloc=lambda sh, dt: (view, 4096)).get_data()
+        assert out is view and np.array_equal(view, vol) and np.all(flat[1024 + vol.size:] == -7.0) and np.all(flat[:1024 - 88] == -7.0)
+        assert bytes(flat[1024 - 88:1024].view(np.uint8)[:4]) == (348).to_bytes(4, 'little')       # the header's sizeof_hdr
+        n_native = len(calls)
+        nifti.NATIVE_GUNZIP = False
+        ref = nifti.load(p)
+        nifti.NATIVE_GUNZIP = True
+        assert len(calls) == n_native and np.array_equal(ref.get_data(), vol) and np.array_equal(ref.affine, nifti.load(p).affine)
+        # int16 with scl_slope / big-endian: the conversions behind the decoder are the old ones
+        raw = gzip.open(p, 'rb').read()
+        hdr = bytearray(raw[:352])
+        i16 = rng.integers(-300, 3000, vol.size).astype('>i2')
+        import struct
+        be = bytearray(hdr)
+        be[0:4] = struct.pack('>i', 348)
+        be[40:56] = struct.pack('>8h', 4, *vol.shape, 1, 1, 1)
+        be[70:74] = struct.pack('>2h', 4, 16)
+        be[76:108] = struct.pack('>8f', 1, 1, 1, 1, 1, 1, 1, 1)
+        be[108:120] = struct.pack('>3f', 352, 2.0, 5.0)
+        be[252:256] = struct.pack('>2h', 0, 0)
+        q = str(tmp_path / 'be.nii.gz')
+        open(q, 'wb').write(gzip.compress(bytes(be) + i16.tobytes()))
+        got = nifti.load(q).get_data()
+        nifti.NATIVE_GUNZIP = False
+        want = nifti.load(q).get_data()
+        nifti.NATIVE_GUNZIP = True
+        assert got.dtype == want.dtype == np.float64 and np.array_equal(got, want) and got.flags.writeable
+        assert np.array_equal(got, i16.astype(np.float64).reshape(vol.shape, order='F') * 2.0 + 5.0)
+        # refused by the decoder, accepted by zlib: members with a tiny first one, junk behind the data
+        whole = open(p, 'rb').read()
+        multi = str(tmp_path / 'm.nii.gz')
+        open(multi, 'wb').write(gzip.compress(raw[:100]) + gzip.compress(raw[100:]))
+        assert np.array_equal(nifti.load(multi).get_data(), vol)
+        junk = str(tmp_path / 'j.nii.gz')
+        open(junk, 'wb').write(whole + b'not a gzip member')
+        calls.clear()
+        staged = []
+
+        def alloc_once(sh, dt):                                               # the fall-back must reuse the array the first reader asked for
+            staged.append(np.empty(sh, dt, order='F'))
+            return staged[-1]
+        assert np.array_equal(nifti.load(junk, alloc=alloc_once).get_data(), vol) and calls == [-1] and len(staged) == 1
+        # refused by both
+        cut = str(tmp_path / 't.nii.gz')
+        open(cut, 'wb').write(whole[:len(whole) // 2])
+        with pytest.raises((EOFError, ValueError)):
+            nifti.load(cut)
+        bad = bytearray(whole); bad[-6] ^= 0xff
+        open(cut, 'wb').write(bytes(bad))
+        with pytest.raises(zlib.error):
+            nifti.load(cut)
+    finally:
+        _labelgz.lib.ukbb_fcn_gunzip = real
+        nifti.NATIVE_GUNZIP = True
+
+
 # ---- .gz reader: zlib fed in large pieces (nifti._GzReader) ---------------------------------------------------------------
 
 def test_gz_reader_members_padding_truncation_and_crc(tmp_path):
@@ -815,10 +992,11 @@ def test_label_gzip_clean_under_address_and_ub_sanitizers(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib = str(tmp_path / 'libukbb_labelgz_asan.so')
     subprocess.check_call(['g++', '-O1', '-g', '-std=c++17', '-fPIC', '-shared', '-fsanitize=address,undefined', '-fno-sanitize-recover=undefined',
-                           '-fno-omit-frame-pointer', '-o', lib, os.path.join(root, 'ukbb_cardiac_amd', 'csrc', 'label_gzip.cpp')])
+                           '-fno-omit-frame-pointer', '-o', lib, os.path.join(root, 'ukbb_cardiac_amd', 'csrc', 'label_gzip.cpp'),
+                           os.path.join(root, 'ukbb_cardiac_amd', 'csrc', 'gz_inflate.cpp')])
     env = dict(os.environ, LD_PRELOAD=asan + ' ' + ubsan, ASAN_OPTIONS='detect_leaks=0', UKBB_LABELGZ_LIB=lib)
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-p', 'no:cacheprovider', '-k',
-                        'degenerate_histograms or run_lengths_and_crc or modes_inflate_identically or never_loses_to_zlib'],
+                        'degenerate_histograms or run_lengths_and_crc or modes_inflate_identically or never_loses_to_zlib or test_gunzip_ or whole_file_decoder'],
                        env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0 and ' passed' in r.stdout and 'ERROR: AddressSanitizer' not in r.stdout and 'runtime error' not in r.stdout, r.stdout[-3000:]
 

@@ -114,19 +114,19 @@ def run_pipelined(FLAGS, engine, data_list, log=print, csv_rows=None):
                 if state['pipe'] is None:                  # sized by the first volume; bigger ones fall back below
                     state['pipe'] = SubjectPipeline(engine, shape, FLAGS.batch_slices, depth=depth, extra_inputs=window)
             try:
-                return state['pipe'].stage(shape, dt).array
+                return state['pipe'].stage(shape, dt).array, SubjectPipeline.HEADROOM
             except ValueError:
                 pass
-        return np.empty(shape, dt, order='F')
+        return np.empty(shape, dt, order='F'), 0
 
     def read(item):
         t0 = time.time()
         handed = []
 
         def alloc_tracked(shape, dt):
-            a = alloc(shape, dt)
+            a, headroom = alloc(shape, dt)
             handed.append(a)
-            return a
+            return a, headroom
         try:
             nim = nifti.load(item[2], alloc=alloc_tracked)
         except BaseException:

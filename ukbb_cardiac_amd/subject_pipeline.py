@@ -38,6 +38,8 @@ class Staged:
 
 
 class SubjectPipeline:
+    HEADROOM = 4096                                         # bytes of writable pinned memory in front of every staged array
+
     def __init__(self, engine, max_shape, batch_slices=128, depth=3, thres=(1, 99), extra_inputs=2):
         """max_shape: largest (X, Y, Z, T) expected (buffers are sized for it; larger volumes re-allocate).
         extra_inputs: pinned input buffers beyond ``depth`` (one per reader thread that may hold one)."""
@@ -57,7 +59,9 @@ class SubjectPipeline:
         self._in_cap = int(np.prod(max_shape))
         self._in_free = queue.Queue()
         for _ in range(self.depth + int(extra_inputs)):
-            self._in_free.put(torch.empty(self._in_cap, dtype=torch.float32, pin_memory=True))
+            # HEADROOM bytes in front of every buffer: nifti.load's whole-file decoder writes the 352-byte NIfTI header there and the
+            # voxels straight behind it, i.e. into the array stage() hands out (the view keeps the whole allocation alive)
+            self._in_free.put(torch.empty(self._in_cap + self.HEADROOM // 4, dtype=torch.float32, pin_memory=True)[self.HEADROOM // 4:])
         import threading
         self._lock = threading.Lock()
         self._staged = {}                                     # id(array) -> Staged, for arrays handed out by stage()
