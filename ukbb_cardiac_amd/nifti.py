@@ -276,7 +276,7 @@ def load_header(path):
     return hdr
 
 
-NATIVE_GUNZIP = True       # tests switch it off to compare with the zlib reader
+NATIVE_GUNZIP = os.environ.get('UKBB_GUNZIP', 'native') != 'zlib'     # A/B knob (tools/shard_rehearsal.py); tests switch it off to compare with the zlib reader
 
 
 def _checked_alloc(alloc, shape, dt):
