@@ -31,8 +31,9 @@ constexpr int LL_BITS = UKBB_GZ_LL_BITS, D_BITS = 8;   // first-level table widt
 constexpr int LL_SIZE = (1 << LL_BITS) + 288 * 16;      // + every possible second-level entry (codes of up to 15 bits)
 constexpr int D_SIZE = (1 << D_BITS) + 32 * 128;
 
-// Table entry: bits 0-7 code bits to drop for this lookup, bits 8-11 extra-bit count (second-level pointer: index bits of that
-// table), bits 12-15 kind, bits 16-31 base value (literal byte, length base, distance base, or second-level table start).
+// Table entry: bits 0-7 bits to drop for this lookup (code bits; for length / distance symbols code + extra bits), bits 8-11
+// extra-bit count (literal entries: number of literals, 1 or 2; second-level pointer: index bits of that table), bits 12-15 kind,
+// bits 16-31 base value (literal byte(s), length base, distance base, or second-level table start).
 constexpr uint32_t K_LIT = 0x1000, K_SUB = 0x2000, K_EOB = 0x4000, K_BAD = 0x8000;
 inline uint32_t mk(uint32_t base, uint32_t extra, uint32_t len, uint32_t kind) { return (base << 16) | kind | (extra << 8) | len; }
 
@@ -64,10 +65,11 @@ int build_table(const uint8_t *lens, int n, int kind, uint32_t *tab, int root) {
     uint32_t next[16]; next[0] = 0; next[1] = 0;
     for (int l = 1; l < 15; ++l) next[l + 1] = (next[l] + count[l]) << 1;
     auto entry = [&](int sym, int drop) -> uint32_t {
-        if (kind == 1) return sym < 30 ? mk(DIST_BASE[sym], DIST_EXTRA[sym], drop, 0) : mk(0, 0, drop, K_BAD);
+        // length / distance symbols: bits 0-5 = code bits + extra bits (dropped in one shift), bits 8-11 = the extra-bit count
+        if (kind == 1) return sym < 30 ? mk(DIST_BASE[sym], DIST_EXTRA[sym], drop + DIST_EXTRA[sym], 0) : mk(0, 0, drop, K_BAD);
         if (sym < 256) return mk(sym, 1, drop, K_LIT);
         if (sym == 256) return mk(0, 0, drop, K_EOB);
-        return sym < 286 ? mk(LEN_BASE[sym - 257], LEN_EXTRA[sym - 257], drop, 0) : mk(0, 0, drop, K_BAD);
+        return sym < 286 ? mk(LEN_BASE[sym - 257], LEN_EXTRA[sym - 257], drop + LEN_EXTRA[sym - 257], 0) : mk(0, 0, drop, K_BAD);
     };
     // second-level tables: one per root-bit prefix that long codes share, sized by the longest code under that prefix
     uint8_t sub_bits[1 << LL_BITS];
@@ -264,52 +266,68 @@ int64_t inflate_stream(Bits &b, uint8_t *const out, uint64_t pos, const uint64_t
             bool done = false; int64_t err = 0;
 #define REFILL() { buf |= load64(in) << cnt; in += (63 - cnt) >> 3; cnt |= 56; }
 #define PUT_LIT(e) { const uint16_t v2 = (uint16_t)((e) >> 16); memcpy(o, &v2, 2); o += ((e) >> 8) & 3; }      /* one or two bytes; the second is scratch when one */
-            while (end - in > 24 && o < o_fast) {
+#define LOOKUP_LL(e) { e = ll[buf & ((1u << LL_BITS) - 1)]; if (__builtin_expect(e & K_SUB, 0)) { buf >>= LL_BITS; cnt -= LL_BITS; e = ll[(e >> 16) + (buf & ((1u << ((e >> 8) & 15)) - 1))]; } }
+            // Entries of length / distance symbols drop code + extra bits in ONE shift (bits 0-5 hold the sum, see mk_x): the value's
+            // extra bits are cut from a copy of the bit buffer off the critical path, which is lookup -> shift -> lookup.
+            if (end - in > 24 && o < o_fast) {
                 REFILL();
-                uint32_t e = ll[buf & ((1u << LL_BITS) - 1)];
-                if (e & K_SUB) { buf >>= LL_BITS; cnt -= LL_BITS; e = ll[(e >> 16) + (buf & ((1u << ((e >> 8) & 15)) - 1))]; }
-                buf >>= (e & 63); cnt -= (e & 63);
-                if (e & K_LIT) {
-                    PUT_LIT(e);
-                    e = ll[buf & ((1u << LL_BITS) - 1)];              // second symbol on the same refill (>= 41 bits left)
-                    if (e & K_SUB) { buf >>= LL_BITS; cnt -= LL_BITS; e = ll[(e >> 16) + (buf & ((1u << ((e >> 8) & 15)) - 1))]; }
+                uint32_t e;
+                LOOKUP_LL(e);
+                for (;;) {
+                    // invariant here: e = entry of the next symbol, looked up in a buffer of >= 56 - 11 bits (second-level hit) else >= 56
+                    uint64_t saved = buf;
                     buf >>= (e & 63); cnt -= (e & 63);
                     if (e & K_LIT) {
                         PUT_LIT(e);
-                        e = ll[buf & ((1u << LL_BITS) - 1)];          // third (>= 26 bits left)
-                        if (e & K_SUB) { buf >>= LL_BITS; cnt -= LL_BITS; e = ll[(e >> 16) + (buf & ((1u << ((e >> 8) & 15)) - 1))]; }
+                        LOOKUP_LL(e);                                 // >= 41 - 11 bits left: enough for any single code
+                        saved = buf;
                         buf >>= (e & 63); cnt -= (e & 63);
-                        if (e & K_LIT) { PUT_LIT(e); continue; }
+                        if (e & K_LIT) {
+                            PUT_LIT(e);
+                            if (!(end - in > 24 && o < o_fast)) break;
+                            REFILL();
+                            LOOKUP_LL(e);
+                            continue;
+                        }
                     }
+                    if (__builtin_expect(e & (K_EOB | K_BAD), 0)) { if (e & K_BAD) err = E_DATA; done = true; break; }
+                    const uint32_t xl = (e >> 8) & 15;
+                    const uint32_t len = (e >> 16) + (uint32_t)((saved >> ((e & 63) - xl)) & ((1u << xl) - 1));
+                    if (cnt < 28) REFILL();                           // distance code + extra: <= 15 + 13 bits
+                    uint32_t d = dt[buf & ((1u << D_BITS) - 1)];
+                    if (__builtin_expect(d & K_SUB, 0)) { buf >>= D_BITS; cnt -= D_BITS; d = dt[(d >> 16) + (buf & ((1u << ((d >> 8) & 15)) - 1))]; }
+                    saved = buf;
+                    buf >>= (d & 63); cnt -= (d & 63);
+                    if (__builtin_expect(d & K_BAD, 0)) { err = E_DATA; done = true; break; }
+                    const uint32_t xd = (d >> 8) & 15;
+                    const uint32_t dist = (d >> 16) + (uint32_t)((saved >> ((d & 63) - xd)) & ((1u << xd) - 1));
+                    if (__builtin_expect(dist > (uint64_t)(o - out), 0)) { err = E_DATA; done = true; break; }
+                    // next symbol's entry on its way while the bytes are copied
+                    const bool more = end - in > 24 && o < o_fast;
+                    uint32_t e_next = 0;
+                    if (more) { REFILL(); LOOKUP_LL(e_next); }
+                    const uint8_t *s = o - dist;
+                    uint8_t *const oe = o + len;
+                    if (dist >= 16 || dist >= len) {                  // no overlap inside one 16-byte step (bytes read at / behind o are scratch)
+                        copy16(o, s);
+                        if (__builtin_expect(len > 16, 0)) { do { o += 16; s += 16; copy16(o, s); } while (o + 16 < oe); }
+                    } else if (dist >= 8) {
+                        do { copy8(o, s); o += 8; s += 8; } while (o < oe);
+                    } else if (dist == 1 || dist == 2 || dist == 4) { // runs of one byte / int16 / float32 value: the period divides 8
+                        uint64_t v;
+                        if (dist == 1) v = 0x0101010101010101ull * s[0];
+                        else if (dist == 2) { uint16_t t; memcpy(&t, s, 2); v = 0x0001000100010001ull * t; }
+                        else { uint32_t t; memcpy(&t, s, 4); v = 0x0000000100000001ull * t; }
+                        do { memcpy(o, &v, 8); o += 8; } while (o < oe);
+                    } else {
+                        do { *o++ = *s++; } while (o < oe);
+                    }
+                    o = oe;
+                    if (!more) break;
+                    e = e_next;
                 }
-                if (e & (K_EOB | K_BAD)) { if (e & K_BAD) err = E_DATA; done = true; break; }
-                // length (>= 11 bits left, extra <= 5), then a fresh refill for the distance (<= 15 + 13 bits)
-                const uint32_t xl = (e >> 8) & 15;
-                uint32_t len = (e >> 16) + (uint32_t)(buf & ((1u << xl) - 1));
-                buf >>= xl; cnt -= xl;
-                REFILL();
-                uint32_t d = dt[buf & ((1u << D_BITS) - 1)];
-                if (d & K_SUB) { buf >>= D_BITS; cnt -= D_BITS; d = dt[(d >> 16) + (buf & ((1u << ((d >> 8) & 15)) - 1))]; }
-                buf >>= (d & 63); cnt -= (d & 63);
-                if (d & K_BAD) { err = E_DATA; done = true; break; }
-                const uint32_t xd = (d >> 8) & 15;
-                const uint32_t dist = (d >> 16) + (uint32_t)(buf & ((1u << xd) - 1));
-                buf >>= xd; cnt -= xd;
-                if (dist > (uint64_t)(o - out)) { err = E_DATA; done = true; break; }
-                const uint8_t *s = o - dist;
-                uint8_t *const oe = o + len;
-                if (dist >= 16) {
-                    do { copy16(o, s); o += 16; s += 16; } while (o < oe);
-                } else if (dist >= 8) {
-                    do { copy8(o, s); o += 8; s += 8; } while (o < oe);
-                } else if (dist == 1) {
-                    const uint64_t v = 0x0101010101010101ull * *s;
-                    do { memcpy(o, &v, 8); o += 8; } while (o < oe);
-                } else {
-                    do { *o++ = *s++; } while (o < oe);
-                }
-                o = oe;
             }
+#undef LOOKUP_LL
 #undef REFILL
 #undef PUT_LIT
             // give the whole unread bytes back so that the careful loop starts from a consistent state
@@ -324,9 +342,9 @@ int64_t inflate_stream(Bits &b, uint8_t *const out, uint64_t pos, const uint64_t
             b.fill_safe();
             uint32_t e = ll[b.buf & ((1u << LL_BITS) - 1)];
             if (e & K_SUB) { b.take(LL_BITS); e = ll[(e >> 16) + (b.buf & ((1u << ((e >> 8) & 15)) - 1))]; }
-            b.take(e & 0xff);
-            if (b.overrun()) return E_INPUT;
             if (e & K_LIT) {
+                b.take(e & 63);
+                if (b.overrun()) return E_INPUT;
                 const int k = (e >> 8) & 3;
                 if (o_end - o < k) return E_OUTPUT;
                 *o++ = (uint8_t)(e >> 16);
@@ -334,14 +352,18 @@ int64_t inflate_stream(Bits &b, uint8_t *const out, uint64_t pos, const uint64_t
                 continue;
             }
             if (e & K_BAD) return E_DATA;
+            const uint32_t xl = (e >> 8) & 15;
+            b.take((e & 63) - xl);
+            if (b.overrun()) return E_INPUT;
             if (e & K_EOB) break;
-            uint32_t len = (e >> 16) + b.take((e >> 8) & 15);
+            uint32_t len = (e >> 16) + b.take(xl);
             b.fill_safe();
             uint32_t d = dt[b.buf & ((1u << D_BITS) - 1)];
             if (d & K_SUB) { b.take(D_BITS); d = dt[(d >> 16) + (b.buf & ((1u << ((d >> 8) & 15)) - 1))]; }
-            b.take(d & 0xff);
             if (d & K_BAD) return E_DATA;
-            const uint32_t dist = (d >> 16) + b.take((d >> 8) & 15);
+            const uint32_t xd = (d >> 8) & 15;
+            b.take((d & 63) - xd);
+            const uint32_t dist = (d >> 16) + b.take(xd);
             if (b.overrun()) return E_INPUT;
             if (dist > (uint64_t)(o - out)) return E_DATA;
             if ((uint64_t)(o_end - o) < len) return E_OUTPUT;
