@@ -10,8 +10,8 @@ from collections import defaultdict
 
 def short(name):
     name = re.sub(r'^void\s+', '', name)
-    name = re.sub(r'\(.*\)$', '', name)
-    return name.replace('ukbb::', '')
+    name = re.sub(r'\([^()]*\)$', '', name)                      # the trailing argument list only: '(anonymous namespace)' has parentheses too
+    return name.replace('(anonymous namespace)::', '').replace('ukbb::', '')
 
 
 def main(dirs):

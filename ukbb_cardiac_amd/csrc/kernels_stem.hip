@@ -60,7 +60,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void unet_stem_kernel(const StemAr
 
     const int tiles_x = (a.W + ST_TW - 1) / ST_TW, tiles_y = (a.H + R - 1) / R, tiles = tiles_x * tiles_y, ntiles = a.N * tiles;
     const int nwalk = (int)gridDim.x, walker = (int)blockIdx.x;
+#ifdef UKBB_TILE_ORDER_WAVE_MAJOR
     const int worker = wave * nwalk + walker, nworkers = nwalk * NW;
+#else
+    // Tiles that share halo columns / rows run at the same time on the same XCD: the NW waves of a workgroup take NW consecutive
+    // tiles of a tile row, and the workgroups of one XCD (blockIdx % 8 on this chip's round-robin dispatch) take consecutive runs
+    // of such groups, so a halo pixel is fetched from HBM once and re-read from that XCD's L2 (r04: the narrow tiles re-read 1.9x).
+    const int per_xcd = nwalk / 8, xcd = walker & 7, slot = walker >> 3;
+    const int chunk = (nwalk % 8 == 0) ? xcd * per_xcd + slot : walker;
+    const int worker = chunk * NW + wave, nworkers = nwalk * NW;
+#endif
     const int my = worker < ntiles ? (ntiles - worker + nworkers - 1) / nworkers : 0;
     if (my == 0) return;
 
@@ -278,7 +287,10 @@ hipError_t launch_unet_stem(const StemArgs &a, hipStream_t s) {
     const long long ntiles = (long long)a.N * ((a.H + R - 1) / R) * ((a.W + ST_TW - 1) / ST_TW);
     const int cus = device_cu_count();
     const long long want = (ntiles + NW - 1) / NW;
-    const int grid = (int)(want < cus ? want : cus);
+    // two workgroups per CU (240 registers, 57 KB of LDS each): two waves per SIMD cover each other's non-MFMA phases (101 -> 78 us at N = 100; r04)
+    static const int per_cu = getenv("UKBB_STEM_WGS_PER_CU") ? atoi(getenv("UKBB_STEM_WGS_PER_CU")) : 2;   // A/B knob
+    const long long cap = (long long)cus * (per_cu > 0 ? per_cu : 1);
+    const int grid = (int)(want < cap ? want : cap);
     constexpr int bytes = NW * st_wave_bytes(R);
     static_assert(bytes <= 160 * 1024, "LDS");
     auto k = unet_stem_kernel<R, NW>;

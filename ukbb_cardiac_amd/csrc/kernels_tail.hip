@@ -48,40 +48,54 @@ __device__ __forceinline__ void unroll_steps(F &&f) {
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); unroll_steps<N, I + 1>(f); }
 }
 
-constexpr int TL_TW = 30;                               // label columns per tile
-constexpr int TL_MW = 32;                               // stage-1 columns (two 16-pixel MFMA blocks)
-constexpr int TL_IW = 34;                               // input halo columns
+// NB = 16-pixel MFMA blocks per tile row: label columns per tile 16 NB - 2, stage-1 columns 16 NB, input halo columns 16 NB + 2.
+// NB = 2 (30-column tiles) needs 37 KB of LDS and 415 registers per wave: ONE wave per SIMD, and its non-MFMA phases (park, request,
+// mid, epilogue: 5-6 k of 10.4 k cycles per tile, r04 stamps) leave the matrix pipe idle.  NB = 1 (14-column tiles) fits 19.7 KB and
+// 256 registers: TWO waves per SIMD cover each other's phases, for 7 % more MFMAs and 14 % more halo reads per label pixel.
+__host__ __device__ constexpr int tl_tw(int nb) { return 16 * nb - 2; }
+__host__ __device__ constexpr int tl_mw(int nb) { return 16 * nb; }
+__host__ __device__ constexpr int tl_iw(int nb) { return 16 * nb + 2; }
 
-__host__ __device__ constexpr int tl_hp(int r) { return (r + 4) * TL_IW; }                       // input halo pixels
-__host__ __device__ constexpr int tl_nld(int r) { return (2 * tl_hp(r) + 63) / 64; }             // 16-byte pieces per lane and source
+__host__ __device__ constexpr int tl_hp(int r, int nb) { return (r + 4) * tl_iw(nb); }            // input halo pixels
+__host__ __device__ constexpr int tl_nld(int r, int nb) { return (2 * tl_hp(r, nb) + 63) / 64; }  // 16-byte pieces per lane and source
 // input stage of one source: [halo pixel][k half] x 16 B = the pixel's 32 bytes as they lie in HBM, LINEAR in the order the load
 // instructions deliver them (conflict-free ds_write_b128 at immediate offsets, no per-lane offsets); rounded up to whole load
 // instructions so that the idle lanes of the last one write padding of the same stage.  Fragment reads (lane: pixel n16, k-quarter kq)
 // at 32-byte pixel stride stay conflict-free because a ds_read_b128's 16-lane group holds pixels {0-3, 12-15} of one quarter and {4-11}
 // of the next: even and odd 16-byte slots, all different.
-__host__ __device__ constexpr int tl_stage(int r) { return tl_nld(r) * 1024; }
+__host__ __device__ constexpr int tl_stage(int r, int nb) { return tl_nld(r, nb) * 1024; }
 // mid tile: [k half][pixel] planes a multiple of 256 bytes apart (16-byte pixel stride; the same group argument with whole planes)
-__host__ __device__ constexpr int tl_mplane(int r) { return ((r + 2) * TL_MW * 16 + 255) / 256 * 256; }
-__host__ __device__ constexpr int tl_wave_bytes(int r) { return 2 * tl_stage(r) + 2 * tl_mplane(r) + 256; }   // + pad the last row's column overhang reads into
-__host__ __device__ constexpr int tl_lds_bytes(int r, int nw) { return nw * tl_wave_bytes(r); }
+__host__ __device__ constexpr int tl_mplane(int r, int nb) { return ((r + 2) * tl_mw(nb) * 16 + 255) / 256 * 256; }
+__host__ __device__ constexpr int tl_wave_bytes(int r, int nb) { return 2 * tl_stage(r, nb) + 2 * tl_mplane(r, nb) + 256; }   // + pad the last row's column overhang reads into
+__host__ __device__ constexpr int tl_lds_bytes(int r, int nw, int nb) { return nw * tl_wave_bytes(r, nb); }
 
 // NC: classes (compile time: the epilogue is straight-line code for exactly this count); FULL: also store logits / probabilities
 // (the hot path of the deploy loop asks for the label map only)
-template <int R, int NW, int NC, bool FULL>
+template <int R, int NW, int NB, int NC, bool FULL>
 __global__ __launch_bounds__(NW * 64, NW / 4) void unet_tail_kernel(const TailArgs a) {
-    constexpr int R1 = R + 2, HR0 = R + 4, HP0 = tl_hp(R), NLD = tl_nld(R), STAGE = tl_stage(R), MPLANE = tl_mplane(R);
+    constexpr int TL_TW = tl_tw(NB), TL_MW = tl_mw(NB), TL_IW = tl_iw(NB);
+    constexpr int R1 = R + 2, HR0 = R + 4, HP0 = tl_hp(R, NB), NLD = tl_nld(R, NB), STAGE = tl_stage(R, NB), MPLANE = tl_mplane(R, NB);
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
     const int n16 = lane & 15, kq = lane >> 4;          // MFMA column (pixel) and k-quarter / row group of this lane
-    unsigned char *const wl = lds + wave * tl_wave_bytes(R);      // [2 sources][2 halves][HP0] | mid [2 halves][R1 x 32] | pad
+    unsigned char *const wl = lds + wave * tl_wave_bytes(R, NB);      // [2 sources][2 halves][HP0] | mid [2 halves][R1 x 32] | pad
     unsigned char *const mid = wl + 2 * STAGE;
 
     const int tiles_x = (a.W + TL_TW - 1) / TL_TW, tiles_y = (a.H + R - 1) / R, tiles = tiles_x * tiles_y, ntiles = a.N * tiles;
     const int nwalk = (int)gridDim.x, walker = (int)blockIdx.x;
+#ifdef UKBB_TILE_ORDER_WAVE_MAJOR
     const int worker = wave * nwalk + walker, nworkers = nwalk * NW;
+#else
+    // Tiles that share halo columns / rows run at the same time on the same XCD: the NW waves of a workgroup take NW consecutive
+    // tiles of a tile row, and the workgroups of one XCD (blockIdx % 8 on this chip's round-robin dispatch) take consecutive runs
+    // of such groups, so a halo pixel is fetched from HBM once and re-read from that XCD's L2 (r04: the narrow tiles re-read 1.9x).
+    const int per_xcd = nwalk / 8, xcd = walker & 7, slot = walker >> 3;
+    const int chunk = (nwalk % 8 == 0) ? xcd * per_xcd + slot : walker;
+    const int worker = chunk * NW + wave, nworkers = nwalk * NW;
+#endif
     const int my = worker < ntiles ? (ntiles - worker + nworkers - 1) / nworkers : 0;
     if (my == 0) return;                                // no barrier anywhere: a wave may simply leave
 
@@ -204,9 +218,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void unet_tail_kernel(const TailAr
         // LDS fragment reads software-pipelined by hand (kernels_ws.hip: left to hipcc every read is waited for with lgkmcnt(0) right
         // behind it, and with one wave per SIMD nothing covers the ~120 cycles): step s = (block, kw, halo row) reads its B fragment
         // PD1 steps ahead into a rotating buffer; sched_barrier pins the order.
-        f32x4 acc1[R1][2];
+        f32x4 acc1[R1][NB];
         {
-            constexpr int S1 = 2 * 3 * HR0, PD1 = 4, NB1 = 5;
+            constexpr int S1 = NB * 3 * HR0, PD1 = 4, NB1 = 5;
             u32x4 Bq[NB1];
             auto readB = [&](auto sc) {
                 constexpr int s = decltype(sc)::value, blk = s / (3 * HR0), kw = (s / HR0) % 3, rp = s % HR0;
@@ -234,7 +248,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void unet_tail_kernel(const TailAr
             unroll_steps<R1>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
                 const bool rowok = (unsigned)(oy0 - 1 + r) < (unsigned)a.H;
-                unroll_steps<2>([&](auto bc) {
+                unroll_steps<NB>([&](auto bc) {
                     constexpr int blk = decltype(bc)::value;
                     const float e0 = acc1[r][blk][0], e1 = acc1[r][blk][1], e2 = acc1[r][blk][2], e3 = acc1[r][blk][3];
                     f32x2 lo2, hi2;
@@ -256,17 +270,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void unet_tail_kernel(const TailAr
         else mid_store(std::true_type{});
         UKBB_TL_STAMP(3)
         // ---- stage 2: up0_1 on R rows x 2 blocks, two taps per MFMA; one read per 16-cycle MFMA: reads PD2 steps ahead ----
-        f32x4 acc2[R][2];
+        f32x4 acc2[R][NB];
         {
-            constexpr int S2 = R * 2 * 5, PD2 = 8, NB2 = 9;
+            constexpr int S2 = R * NB * 5, PD2 = 8, NB2 = 9;
             u32x4 Bq[NB2];
             auto readB = [&](auto sc) {
-                constexpr int s = decltype(sc)::value, r = s / 10, blk = (s / 5) % 2, p = s % 5;
+                constexpr int s = decltype(sc)::value, r = s / (5 * NB), blk = (s / 5) % NB, p = s % 5;
                 Bq[s % NB2] = *reinterpret_cast<const u32x4 *>(s2_lane[p] + (r * TL_MW + 16 * blk) * 16);
             };
             unroll_steps<PD2>([&](auto sc) { readB(sc); });
             unroll_steps<S2>([&](auto sc) {
-                constexpr int s = decltype(sc)::value, r = s / 10, blk = (s / 5) % 2, p = s % 5;
+                constexpr int s = decltype(sc)::value, r = s / (5 * NB), blk = (s / 5) % NB, p = s % 5;
                 if constexpr (s + PD2 < S2) readB(std::integral_constant<int, s + PD2>{});
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (p == 0) acc2[r][blk] = mfma16(A1[p], Bq[s % NB2], bias1);
@@ -279,15 +293,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void unet_tail_kernel(const TailAr
         const __amdgpu_buffer_rsrc_t ro_pred = __builtin_amdgcn_make_buffer_rsrc((void *)(a.pred + (size_t)n * npx), 0, a.pred ? npx * 4 : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t ro_lg = __builtin_amdgcn_make_buffer_rsrc((void *)(a.logits + (size_t)n * npx * NC), 0, (FULL && a.logits) ? npx * NC * 4 : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t ro_pr = __builtin_amdgcn_make_buffer_rsrc((void *)(a.prob + (size_t)n * npx * NC), 0, (FULL && a.prob) ? npx * NC * 4 : 0, 0x00020000);
-        // units (row r, block blk) in groups of four: unit u = (row 2 q + (u >> 1), block u & 1) lands in lane quarter u
-        static_assert(R % 2 == 0, "rows pair up in the logits groups");
-        const int c0 = 16 * (kq & 1) + n16;             // this lane's column in the tile and ...
+        // units (row r, block blk) in groups of four: unit u lands in lane quarter u.  NB = 2: unit u = (row 2 q + (u >> 1), block u & 1);
+        // NB = 1: unit u = row 4 q + u
+        static_assert(R % (4 / NB) == 0, "rows pair up in the logits groups");
+        constexpr int GR = 4 / NB;                       // rows per group
+        const int c0 = NB == 2 ? 16 * (kq & 1) + n16 : n16;     // this lane's column in the tile and ...
         const bool colok = c0 < TL_TW && ox0 + c0 < a.W;
-        unroll_steps<R / 2>([&](auto qc) {
+        unroll_steps<R / GR>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
             f32x4 lg = lgC;
             unroll_steps<4>([&](auto uc) {
-                constexpr int u = decltype(uc)::value, r = 2 * q + (u >> 1), blk = u & 1;
+                constexpr int u = decltype(uc)::value, r = NB == 2 ? 2 * q + (u >> 1) : 4 * q + u, blk = NB == 2 ? (u & 1) : 0;
                 const float e0 = acc2[r][blk][0], e1 = acc2[r][blk][1], e2 = acc2[r][blk][2], e3 = acc2[r][blk][3];
                 f32x2 lo2, hi2;
                 lo2.x = __builtin_bit_cast(float, max(__builtin_bit_cast(int, e0), 0)); lo2.y = __builtin_bit_cast(float, max(__builtin_bit_cast(int, e1), 0));
@@ -296,7 +312,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void unet_tail_kernel(const TailAr
                 lg = mfma16(Alg[u][1], bq, lg);         // smaller term first
                 lg = mfma16(Alg[u][0], bq, lg);
             });
-            const int oy = oy0 + 2 * q + (kq >> 1);     // ... its row in this group
+            const int oy = oy0 + GR * q + (NB == 2 ? (kq >> 1) : kq);     // ... its row in this group
             const bool own = valid && colok && oy < a.H;
             const unsigned px = (unsigned)(oy * a.W + ox0 + c0);
             float l[NC];
@@ -375,15 +391,16 @@ hipError_t launch_unet_tail(const TailArgs &a_in, hipStream_t s) {
     if (!a.in0 || !a.in1 || !a.wA0 || !a.wA1 || !a.b0 || !a.b1 || !a.lg_w || !a.lg_b || a.ncls < 2 || a.ncls > 4 || a.N < 1) return hipErrorInvalidValue;
     if ((long long)a.H * a.W * 32 >= 0x7fffffffll) return hipErrorInvalidValue;
 #if defined(UKBB_TAIL_R)
-    constexpr int R = UKBB_TAIL_R, NW = UKBB_TAIL_NW;   // A/B builds
+    constexpr int R = UKBB_TAIL_R, NW = UKBB_TAIL_NW, NB = UKBB_TAIL_NB;   // A/B builds
 #else
-    constexpr int R = 8, NW = 4;
+    constexpr int R = 8, NW = 8, NB = 1;
 #endif
+    constexpr int TL_TW = tl_tw(NB);
     const long long ntiles = (long long)a.N * ((a.H + R - 1) / R) * ((a.W + TL_TW - 1) / TL_TW);
     const int cus = device_cu_count();
     const long long want = (ntiles + NW - 1) / NW;
     const int grid = (int)(want < cus ? want : cus);
-    constexpr int bytes = tl_lds_bytes(R, NW);
+    constexpr int bytes = tl_lds_bytes(R, NW, NB);
     static_assert(bytes <= 160 * 1024, "LDS");
     const bool full = a.logits || a.prob;
 #ifdef UKBB_DIAG
@@ -420,7 +437,7 @@ hipError_t launch_unet_tail(const TailArgs &a_in, hipStream_t s) {
 #define UKBB_TAIL_CASE(NC)                                                                         \
     case NC: {                                                                                     \
         static OncePerDevice ok_full, ok_pred;                                                     \
-        return full ? go(unet_tail_kernel<R, NW, NC, true>, ok_full) : go(unet_tail_kernel<R, NW, NC, false>, ok_pred); \
+        return full ? go(unet_tail_kernel<R, NW, NB, NC, true>, ok_full) : go(unet_tail_kernel<R, NW, NB, NC, false>, ok_pred); \
     }
     switch (a.ncls) {
         UKBB_TAIL_CASE(2)

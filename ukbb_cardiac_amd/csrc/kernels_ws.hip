@@ -889,6 +889,7 @@ hipError_t launch_conv_ws(int cfg_id, const ConvArgs &a_in, hipStream_t s) {
     const long long ntiles = (long long)a.N * a.tiles_y * a.tiles_x;
     // one workgroup per CU; a multiple of 8 nG where the chip allows it (XCD-aware walker mapping), never more walkers than tiles need
     int cus = device_cu_count();
+    { static const int per_cu = getenv("UKBB_WS_WGS_PER_CU") ? atoi(getenv("UKBB_WS_WGS_PER_CU")) : 1; if (per_cu > 1) cus *= per_cu; }   // A/B knob
     long long want = ((ntiles + c->wn - 1) / c->wn) * nG;           // workgroups that would give every wave one tile
     int grid = cus >= 8 * nG ? cus / (8 * nG) * (8 * nG) : cus / nG * nG;
     if (grid < nG) grid = nG;
