@@ -1028,3 +1028,16 @@ def test_stale_tmp_files_of_dead_writers_are_swept_and_noise_fallback_keeps_the_
     assert raws['small'][:10] == raws['zlib'][:10] == bytes([0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 4, 0xff])
     assert gzip.decompress(raws['small']) == gzip.decompress(raws['zlib'])
     assert raws['small'] == raws['zlib']                                  # noise: 'small' kept zlib's stream, byte for byte the zlib-mode file
+
+
+def test_pmc_summary_keeps_kernels_of_anonymous_namespaces():
+    """tools/pmc_summary.py shortens rocprofv3 kernel names; the '(anonymous namespace)' of kernels_ws / tail / stem has parentheses of
+    its own and the r04 mid-round summaries lost those kernels to a greedy regular expression."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('pmc_summary', os.path.join(root, 'tools', 'pmc_summary.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert m.short('void ukbb::(anonymous namespace)::unet_tail_kernel<8, 8, 1, 3, false>(ukbb::TailArgs)') == 'unet_tail_kernel<8, 8, 1, 3, false>'
+    assert m.short('void ukbb::wino_pc_kernel<4, 4>(ukbb::ConvArgs)') == 'wino_pc_kernel<4, 4>'
+    assert m.short('clock_probe_kernel(unsigned long long*, unsigned long long)') == 'clock_probe_kernel'
