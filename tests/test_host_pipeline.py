@@ -1041,3 +1041,30 @@ def test_pmc_summary_keeps_kernels_of_anonymous_namespaces():
     assert m.short('void ukbb::(anonymous namespace)::unet_tail_kernel<8, 8, 1, 3, false>(ukbb::TailArgs)') == 'unet_tail_kernel<8, 8, 1, 3, false>'
     assert m.short('void ukbb::wino_pc_kernel<4, 4>(ukbb::ConvArgs)') == 'wino_pc_kernel<4, 4>'
     assert m.short('clock_probe_kernel(unsigned long long*, unsigned long long)') == 'clock_probe_kernel'
+
+
+def test_threshold_params_give_the_label_map_they_promise():
+    """weights.threshold_params (the 'realistic label statistics' model of tools/shard_rehearsal.py): through the fp64 oracle the label is
+    the number of thresholds below the twice 3x3-averaged image, for every FCN model."""
+    from oracle import fcn_oracle as O
+    from ukbb_cardiac_amd.arch import MODELS
+    from ukbb_cardiac_amd.phantom import cine_phantom
+    from ukbb_cardiac_amd.weights import pack_flat, threshold_params
+    img = cine_phantom(2, 48, 64, seed=5).astype(np.float64)
+
+    def mean3(a):
+        pad = np.pad(a, ((0, 0), (1, 1), (1, 1)))
+        return sum(pad[:, i:i + a.shape[1], j:j + a.shape[2]] for i in range(3) for j in range(3)) / 9.0
+    m = mean3(mean3(img[..., 0]))
+    for name in ('FCN_sa', 'FCN_la_2ch', 'FCN_la_4ch_seg4'):
+        arch = MODELS[name]
+        P = threshold_params(arch)
+        assert pack_flat(arch, P).size == arch.n_weight_floats()
+        lg = O.build_FCN(img, P, arch.n_class, arch.n_level, arch.n_filter, arch.n_block, arch.same_dim, arch.fc)
+        th = [0.3 + 0.5 * c / max(1, arch.n_class - 2) for c in range(arch.n_class - 1)]
+        want = sum((m > t).astype(int) for t in th)
+        lab = np.argmax(lg, -1)
+        clear = np.min([np.abs(m - t) for t in th], axis=0) > 1e-9            # not exactly on a threshold
+        assert np.array_equal(lab[clear], want[clear]) and len(np.unique(lab)) == arch.n_class
+    with pytest.raises(ValueError):
+        threshold_params(MODELS['UNet_ao'])

@@ -60,6 +60,49 @@ def synthetic_params(arch: ModelArch, seed: int = 1234) -> Params:
     return params
 
 
+def threshold_params(arch: ModelArch, thresholds=None, slope: float = 40.0) -> Params:
+    """A parameter set whose label map is a smooth function of the image: label = number of `thresholds` below the intensity after
+    two 3x3 means.  Random weights (synthetic_params) give noise-like label maps -- millions of runs per subject, which makes the label
+    writer, not the network or the reader, the longest host stage of a cohort run; a trained model segments a few compact regions.
+    This set reproduces THAT output statistic at the same arithmetic cost (every kernel does the same work whatever the weights):
+    channel 0 carries the image through conv0_0 and conv0_1 (3x3 means), same_dim0, out0 and out1 with identity batch
+    norm, every other weight is zero, and the logits are the upper envelope of lines that cross at the thresholds.
+    FCN models only (tools/shard_rehearsal.py, tools/bench_subject.py)."""
+    from .arch import KIND_FCN
+    if arch.kind != KIND_FCN:
+        raise ValueError('threshold_params: FCN models only')
+    nc = arch.n_class
+    if thresholds is None:
+        thresholds = [0.3 + 0.5 * c / max(1, nc - 2) for c in range(nc - 1)]     # 0.3 .. 0.8 of the [0, 1] range rescale_intensity produces
+    thresholds = [float(t) for t in thresholds]
+    if len(thresholds) != nc - 1 or sorted(thresholds) != thresholds:
+        raise ValueError('need n_class - 1 increasing thresholds')
+    params: Params = {}
+    for s in arch.layer_specs():
+        kh, kw, a, b = s.kernel_shape
+        k = np.zeros(s.kernel_shape, np.float32)
+        p = {'kernel': k}
+        if s.has_bn:                                                          # scale 1, shift 0 after folding (epsilon 1e-3)
+            p['gamma'] = np.full(b, np.sqrt(1.0 + 1e-3), np.float32)
+            p['beta'] = np.zeros(b, np.float32)
+            p['mean'] = np.zeros(b, np.float32)
+            p['var'] = np.ones(b, np.float32)
+        if s.name in ('conv0_0', 'conv0_1'):
+            k[:, :, 0, 0] = 1.0 / 9.0                                         # two 3x3 means (zero padding at the border)
+        elif s.name in ('same_dim0', 'out0', 'out1'):
+            k[0, 0, 0, 0] = 1.0                                               # out0: channel 0 of the level-0 block of the concat
+        elif s.name == 'logits':
+            bias = np.zeros(nc, np.float32)
+            for c in range(1, nc):                                            # line c = line c-1 + slope (x - t_c): the upper envelope switches at t_c
+                k[0, 0, 0, c] = k[0, 0, 0, c - 1] + slope
+                bias[c] = bias[c - 1] - slope * thresholds[c - 1]
+            p['bias'] = bias
+        elif s.has_bias:
+            p['bias'] = np.zeros(b, np.float32)
+        params[s.name] = p
+    return params
+
+
 def pack_flat(arch: ModelArch, params: Params) -> np.ndarray:
     """Flatten to the canonical order ``ukbb_fcn_create`` expects: per layer of
     ``arch.layer_specs()``: kernel (C order), then gamma, beta, mean, var -- or
