@@ -94,6 +94,7 @@ struct ConvArgs {
     float *lg_logits, *lg_prob;   // optional [N,Ho,Wo,lg_ncls]
     int32_t *lg_pred;             // optional [N,Ho,Wo]
     int lg_ncls;
+    int xcd_local;      // kernels_ws.hip only: tile order (set by launch_conv_ws)
     int cout_store;     // bf16-storage tilings (ConvConfig::pc == 5) only: real channel count of `out` when Cout is the zero-padded
                         // count the weights were packed for (a 16-channel layer on the 32-row MFMA); 0 = Cout
 };

@@ -131,7 +131,14 @@ __device__ __forceinline__ void ws_main(const ConvArgs &a, const int grp, const 
     const int tiles = a.tiles_x * a.tiles_y, ntiles = a.N * tiles;
     // wave-major numbering: when the tiles do not divide evenly the workers with one tile more are spread one wave per workgroup
     // (one SIMD of a CU carries 7 tiles, the others 6) instead of filling whole workgroups (8 against 6)
-    const int worker = wave * nwalk + walker, nworkers = nwalk * NW;
+    // Tile t of a round goes to worker t.  Default: wave-major numbering, consecutive tiles on consecutive walkers (= different XCDs).
+    // xcd_local (large maps, set by the launcher): the walkers of one XCD (walker & 7 after ws_place) take a contiguous run of tiles and
+    // the waves of a workgroup consecutive ones, so vertically adjacent row bands -- which share two halo rows -- are read through ONE
+    // XCD's L2 at about the same time.  Measured at N = 100 (r04): 128x128 maps conv1_1 50.5 -> 46.8 us, up1_0 75.4 -> 66.4, up1_1
+    // 51.1 -> 49.0; 64x64 and 32x32 maps 1-4 us SLOWER per layer (few tiles per image: the eight waves of a workgroup then sit on
+    // one image's rows and queue on the same channels), hence the switch.
+    const int per_xcd_ = nwalk / 8, chunk_ = (nwalk % 8 == 0) ? (walker & 7) * per_xcd_ + (walker >> 3) : walker;
+    const int worker = a.xcd_local ? chunk_ * NW + wave : wave * nwalk + walker, nworkers = nwalk * NW;
     const int my = worker < ntiles ? (ntiles - worker + nworkers - 1) / nworkers : 0;
 
     // ---- once per workgroup: this group's packed weights and bias -> LDS.  All of a thread's pieces are requested before the first is
@@ -509,7 +516,14 @@ __device__ __forceinline__ void wr_main(const ConvArgs &a, const int grp, const 
     const int nch = (a.C0 + a.C1) / 16, nch0 = a.C0 / 16;
 
     const int tiles = a.tiles_x * a.tiles_y, ntiles = a.N * tiles;
-    const int worker = wave * nwalk + walker, nworkers = nwalk * NW;
+    // Tile t of a round goes to worker t.  Default: wave-major numbering, consecutive tiles on consecutive walkers (= different XCDs).
+    // xcd_local (large maps, set by the launcher): the walkers of one XCD (walker & 7 after ws_place) take a contiguous run of tiles and
+    // the waves of a workgroup consecutive ones, so vertically adjacent row bands -- which share two halo rows -- are read through ONE
+    // XCD's L2 at about the same time.  Measured at N = 100 (r04): 128x128 maps conv1_1 50.5 -> 46.8 us, up1_0 75.4 -> 66.4, up1_1
+    // 51.1 -> 49.0; 64x64 and 32x32 maps 1-4 us SLOWER per layer (few tiles per image: the eight waves of a workgroup then sit on
+    // one image's rows and queue on the same channels), hence the switch.
+    const int per_xcd_ = nwalk / 8, chunk_ = (nwalk % 8 == 0) ? (walker & 7) * per_xcd_ + (walker >> 3) : walker;
+    const int worker = a.xcd_local ? chunk_ * NW + wave : wave * nwalk + walker, nworkers = nwalk * NW;
     const int my = worker < ntiles ? (ntiles - worker + nworkers - 1) / nworkers : 0;
     // rounds of the whole workgroup = the largest tile count among its waves (wave 0 has it: worker ids grow with the wave index)
     const int rounds = walker < ntiles ? (ntiles - walker + nworkers - 1) / nworkers : 0;
@@ -885,6 +899,10 @@ hipError_t launch_conv_ws(int cfg_id, const ConvArgs &a_in, hipStream_t s) {
     const long long out_ch = tconv ? 4ll * a.up2 : a.Cout;         // bytes of the largest map of one image must fit a buffer range
     if ((long long)a.H * a.W * (a.C0 > out_ch ? a.C0 : out_ch) * 2 >= 0x7fffffffll) return hipErrorInvalidValue;
     a.tiles_y = (a.Ho + c->th - 1) / c->th; a.tiles_x = (a.Wo + WS_TW - 1) / WS_TW;
+    {   // tile order, see ws_main; UKBB_WS_XCD_LOCAL=0 / 1 forces it (A/B)
+        static const char *const force = getenv("UKBB_WS_XCD_LOCAL");
+        a.xcd_local = force ? atoi(force) : ((long long)a.H * a.W >= 128ll * 128);
+    }
     const int nG = a.Cout / (32 * c->cb);
     const long long ntiles = (long long)a.N * a.tiles_y * a.tiles_x;
     // one workgroup per CU; a multiple of 8 nG where the chip allows it (XCD-aware walker mapping), never more walkers than tiles need
