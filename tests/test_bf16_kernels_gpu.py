@@ -47,3 +47,11 @@ def test_fused_stem_matches_the_r03_form():
     """conv0_0 + conv0_1 in one launch (image rounded to bf16) against conv0_0 in fp32 inside conv0_1's staging: the level-0 map's error
     against the fp32 path stays at the bf16 level, Dice against fp32 unchanged."""
     _tool('check_stem.py', 2, 64, 96, 3, 256, 256, 1, 48, 80, 2, 16, 16)
+
+
+def test_winograd_f2x4_matches_f2x2_and_its_two_region_shapes_agree_bit_for_bit():
+    """r04: kernels_wino24.hip (tilings 304 / 305) on the fp32 FCN and U-Net layers it serves, layer by layer against the F(2x2,3x3) kernel
+    (<= 2e-6 of the map's scale: the level of a direct fp32 sum) and 304 against 305 (identical bits: the small-batch plan takes 305
+    where the large one takes 304, and test_small_batch_plan_is_arithmetic_neutral relies on that)."""
+    out = _tool('check_wino24.py')
+    assert 'NOT TAKEN' not in out and 'not available' not in out

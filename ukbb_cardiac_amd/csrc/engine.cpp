@@ -275,8 +275,8 @@ int override_cfg(const std::string &layer) {
 struct Tuned { int ks, stride, cin, cout, cfg, alt, alt2, alt3 = -1; };   // alt.. (or -1): the first of the four whose tiles divide the map wins
 const Tuned g_tuned_large[] = {
     {3, 1, 16, 16, 11, -1, -1}, {3, 2, 16, 32, 120, 123, -1},  {3, 1, 32, 32, 301, -1, -1},
-    {3, 2, 32, 64, 124, 123, 142, 145},  {3, 1, 64, 64, 300, -1, -1},  {3, 2, 64, 128, 124, 123, 142, 145},
-    {3, 1, 128, 128, 300, -1, -1},  {3, 2, 128, 256, 124, 123, 142, 145}, {3, 1, 256, 256, 300, -1, -1},
+    {3, 2, 32, 64, 124, 123, 142, 145},  {3, 1, 64, 64, 304, 300, -1},  {3, 2, 64, 128, 124, 123, 142, 145},
+    {3, 1, 128, 128, 304, 300, -1},  {3, 2, 128, 256, 124, 123, 142, 145}, {3, 1, 256, 256, 300, -1, -1},
 };      // r03: 13x16 tiles (145) divide the 208x256 pyramid (52x64, 26x32, 13x16: conv2_0 112 -> 86 us, conv3_0 / conv4_0 -6 / -7 at N = 64);
         // r02: the stride-2 layers moved to the producer/consumer kernel once its loads ran two stages ahead (profiles/r02_notes.md);
         // its straight-line producer needs tiles that divide the map: 12x13 tiles for the 192x208 pyramid, 8x16 (123) for the
@@ -327,6 +327,10 @@ bool cfg_valid(const ConvConfig &c, int ks, int stride, int c0, int c1, int cout
     }
     if (c.pc == 4) {                                  // Winograd: 3x3 s1, 64-channel output groups, single source ok
         static const bool off = getenv("UKBB_NO_WINOGRAD") != nullptr;
+        if (is_wino24(c)) {                           // F(2x4,3x3), kernels_wino24.hip: 64-channel groups, K >= 64 (the MFMA-bound layers; no frame map)
+            static const bool off24 = getenv("UKBB_NO_WINOGRAD24") != nullptr;
+            if (off24 || cout % 64 || c0 + c1 < 64) return false;
+        }
         return !off && !fused_first && ks == 3 && stride == 1 && cout % (16 * c.wm) == 0 && c0 % 16 == 0 && c1 % 16 == 0;
     }
     if (c.pc == 2 && cout != c.mb * c.cb * c.wm) return false;   // fused kernel stages its weights once: one Cout group
@@ -369,11 +373,30 @@ int finer_sibling(int id, int ks, int stride, int c0, int c1, int cout, int Ho, 
     return id;
 }
 
+// Winograd F(2x4,3x3) comes with 8 x 32-pixel regions (304) and 8 x 16 (305); both compute every tile with the same arithmetic (same tile
+// grid, same transforms, same K order), so the choice is a matter of filling the CUs: the region shape whose item count wastes less of
+// the last round wins, 304 on a tie (fewer, longer items: FCN level 2 60 us against 65); small batches take the finer one.
+int pick_wino24(int id, int ks, int stride, int c0, int c1, int cout, int Ho, int Wo, int N) {
+    if (id != 304 && id != 305) return id;
+    const int cus = device_cu_count();
+    int best = id; double best_eff = -1.0;
+    for (int cand : {304, 305}) {
+        ConvConfig c;
+        if (find_cfg(cand, c) || !cfg_valid(c, ks, stride, c0, c1, cout) || !tile_fit_ok(c, Ho, Wo)) continue;
+        const long long items = (long long)N * ((Ho + c.th - 1) / c.th) * ((Wo + c.tw - 1) / c.tw) * (cout / 64);
+        const long long rounds = (items + cus - 1) / cus;
+        double eff = (double)items / (double)(rounds * cus);
+        if (N <= SMALL_BATCH) eff = cand == 305 ? 2.0 : 1.0;          // fewer items than CUs either way: more of them
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = cand; }
+    }
+    return best;
+}
+
 int choose_cfg(const std::string &layer, int ks, int stride, int c0, int c1, int cout, int Ho, int Wo, int N,
                bool fused_first = false, int want_bf16 = 0) {
     const int id = choose_cfg_raw(layer, ks, stride, c0, c1, cout, Ho, Wo, N, fused_first, want_bf16);
     if (override_cfg(layer) >= 0) return id;
-    return finer_sibling(wino_orient(id, Ho, Wo), ks, stride, c0, c1, cout, Ho, Wo, N);
+    return finer_sibling(wino_orient(pick_wino24(id, ks, stride, c0, c1, cout, Ho, Wo, N), Ho, Wo), ks, stride, c0, c1, cout, Ho, Wo, N);
 }
 
 // bf16-storage tilings measured best per layer type of the aortic U-Net at N = 100 x 256 x 256 (tools/sweep_convs.py with
@@ -465,7 +488,7 @@ int choose_cfg_raw(const std::string &layer, int ks, int stride, int c0, int c1,
         // Winograd: one stage (16 input channels of one 8x16 region, 64 output channels) costs ~5.2k cycles
         // per CU measured; 5800 puts it on the scale of the direct estimate above (which ignores the direct
         // kernels' ~70 % matrix-pipe efficiency), calibrated on the three tuned shapes.
-        if (c.pc == 4) cost = (double)tiles * (cout / (16 * c.wm)) * ((c0 + c1) / 16) * (c.wm == 4 ? 5800.0 : 3500.0);
+        if (c.pc == 4) cost = (double)tiles * (cout / (16 * c.wm)) * ((c0 + c1) / 16) * (is_wino24(c) ? (c.tw == 32 ? 9300.0 : 4700.0) : c.wm == 4 ? 5800.0 : 3500.0);   // F(2x4): 256 / 128 pixels per stage
         int rank = 12;
         for (int r = 0; r < (int)(sizeof(g_pref) / sizeof(g_pref[0])); ++r)
             if (g_pref[r] == c.id) { rank = r % 6; break; }
@@ -495,10 +518,12 @@ int ensure_packed(ukbb_fcn_handle *h, int layer, const ConvConfig &c, const floa
     char key[128];
     const bool bfpk = c.pc == 3 || c.pc == 5 || c.pc == 6;
     const int coutp = (c.pc == 5 || c.pc == 6) ? round_up(L.cout, 32) : L.cout;
-    snprintf(key, sizeof key, "%s/pk%s_mb%d_kc%d_g%d", L.name.c_str(), bfpk ? "bf16" : c.pc == 4 ? "wino" : "", c.mb, c.kc, c.wm * c.cb);
+    const bool w24 = is_wino24(c);
+    snprintf(key, sizeof key, "%s/pk%s_mb%d_kc%d_g%d", L.name.c_str(), bfpk ? "bf16" : w24 ? "wino24" : c.pc == 4 ? "wino" : "", c.mb, c.kc, c.wm * c.cb);
     if (!dev_ptr(h, key)) {
-        std::vector<float> pk(c.pc == 4 ? (size_t)16 * L.cin * L.cout : (size_t)L.ks * L.ks * L.cin * coutp);
-        if (c.pc == 4) pack_wino_weights(L.w.data(), L.cin, L.cout, c.wm, pk.data());
+        std::vector<float> pk(w24 ? (size_t)24 * L.cin * L.cout : c.pc == 4 ? (size_t)16 * L.cin * L.cout : (size_t)L.ks * L.ks * L.cin * coutp);
+        if (w24) pack_wino24_weights(L.w.data(), L.cin, L.cout, pk.data());
+        else if (c.pc == 4) pack_wino_weights(L.w.data(), L.cin, L.cout, c.wm, pk.data());
         else if (bfpk && coutp != L.cout) {           // zero rows up to the MFMA's 32
             std::vector<float> wp((size_t)L.ks * L.ks * L.cin * coutp, 0.f);
             for (size_t r = 0; r < (size_t)L.ks * L.ks * L.cin; ++r)
@@ -564,7 +589,11 @@ int add_conv(ukbb_fcn_handle *h, const std::string &lname, int in0, int in1, int
     op.bias = ((c.pc == 5 || c.pc == 6) && L.cout % 32) ? dev_ptr(h, lname + "/bias_pad") : dev_ptr(h, lname + "/bias");
     op.out = new_act(h, lname, (size_t)op.Ho * op.Wo * L.cout, L.cout);
     op.macs_per_image = (double)op.Ho * op.Wo * L.ks * L.ks * L.cin * L.cout;
-    if (c.pc == 4) {
+    if (is_wino24(c)) {
+        op.mfma_macs_per_image = op.macs_per_image * (24.0 / 72.0);   // F(2x4,3x3): 24 products per 8 outputs
+        const double regs = (double)((op.Ho + 7) / 8) * ((op.Wo + c.tw - 1) / c.tw);      // every region issues all its tile slots (c.tw / 4 x 4)
+        op.padded_macs_per_image = regs * c.tw * 24.0 * L.cin * L.cout;
+    } else if (c.pc == 4) {
         op.mfma_macs_per_image = op.macs_per_image * (16.0 / 36.0);   // F(2x2,3x3): 16 products per 4 outputs
         // what the kernel ISSUES: every region runs two MFMA column blocks of 16 tile slots (one for a region whose lower half lies below
         // the map in the 64-channel form, kernels_wino.hip `half`), whatever part of its 4 x 8 (8 x 4) tiles the map fills

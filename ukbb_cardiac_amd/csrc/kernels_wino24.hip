@@ -1,0 +1,402 @@
+// Winograd F(2x4, 3x3) convolution (+ folded BN bias, ReLU): the 64-channel-group stride-1 3x3 layers of levels 2-3 of build_FCN
+// (reference common/network.py:19-25, 186-188) on maps of at least 8 x 32 pixels.
+//
+//   Y = A_y^T [ sum_ci (G_y g G_x^T) .* (B_y^T d B_x) ] A_x       per 2 x 4 output tile, 4 x 6 input patch d
+//
+// rows through F(2,3) (entries 0, +-1, 1/2: exactly the transform of kernels_wino.hip), columns through F(4,3) (points 0, +-1, +-2, inf).
+// 24 multiplies per 8 outputs instead of the 32 of F(2x2,3x3) and the 72 of the direct sum: the levels this runs on are bound by
+// the MFMA stream of the consumer waves (r04 stamps: 4.1 k cycles of MFMA against 3.5-3.8 k of producer work per stage), so the
+// quarter fewer MFMAs is time.  Why not F(4x4): its rounding error is 6-13x that of F(2x2) (numpy model, r04_notes.md); with the
+// large factors of F(4,3) along ONE axis only the error stays at the level of a direct fp32 sum (rms 9e-8 of the activation scale
+// against 3.6e-8 for F(2x2) and 3.1e-8 direct; max 6e-7 against 1.6e-7 direct at C = 64, 7e-7 / 4e-7 at C = 256).
+//
+// Structure as kernels_wino.hip (persistent producer / consumer workgroup of 512 threads, one barrier per stage):
+//   item  = (group of 64 output channels, image, region of 4 x 8 tiles = 8 x 32 pixels)
+//   stage = one chunk of 16 input channels of one item
+//   producers (waves 4-7): global -> registers -> raw 10 x 34 halo tile XS (LDS) -> input transform -> VS[24][32 tiles][16] (LDS);
+//   consumers (waves 0-3, one 16-channel block each): 24 GEMM positions x 2 tile blocks x 4 k-steps = 192 v_mfma_f32_16x16x4_f32 per
+//       stage, A fragments straight from L2 through a rolling register queue, then the output transform, ReLU and NHWC stores.
+// LDS: two raw tiles (pixel stride 20 floats: the 4-pixel tile step makes the patch reads conflict-free) and two transformed
+// stages WITHOUT padding -- the 16-byte quad q of tile t sits at slot q ^ (3 * ((t >> 3) & 1)), which keeps the consumers' ds_read_b128
+// conflict-free at a pixel stride of 16 floats (slot = q ^ 3 for tiles 8-15 of each 16-tile block): 153 KB of the 160.
+#include "kernels.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+namespace ukbb {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int TRY = 4;                                // tile rows per region (8 pixel rows)
+constexpr int NK = 24;                                // GEMM positions: k = 6 i + j, i = row position 0..3, j = column position 0..5
+constexpr int WKC = 16;                               // input channels per stage
+constexpr int XS_S = 20;                              // raw tile: floats per pixel
+// TBW = 16-tile MFMA column blocks per region: 2 -> 4 x 8 tiles = 8 x 32 pixels, 1 -> 4 x 4 tiles = 8 x 16 pixels (twice the items:
+// maps whose 8 x 32 regions do not fill the CUs evenly, e.g. 24 x 26 at N = 64: 384 items on 256 CUs)
+template <int TBW> struct W24 {
+    static constexpr int NT = 16 * TBW, TRX = 4 * TBW;
+    static constexpr int WIH = 2 * TRY + 2, WIW = 4 * TRX + 2;        // raw halo tile: 10 x 34 / 10 x 18 pixels
+    static constexpr int WHP = WIH * WIW;
+    static constexpr int NITX = (WHP * (WKC / 4) + 255) / 256;        // staging passes of the 256 producer threads (6 / 3)
+    // row pitch of the raw tile in pixels: the patch reads of a 16-lane ds_read_b128 group touch tiles of two tile rows when a tile row has
+    // only 4 tiles; with a pitch of 24 pixels (two rows = a multiple of 256 bytes) their 64-byte pieces stay on different banks
+    static constexpr int RS = TBW == 2 ? WIW : 24;
+    static constexpr int XSZ = WIH * RS * XS_S + 32;                  // + a slot for the idle lanes of the last pass
+    static constexpr int VSZ = NK * NT * WKC;                         // one transformed stage
+    static constexpr int L_XS = 0;                                    // [2][XSZ]
+    static constexpr int L_VS = L_XS + 2 * XSZ;                       // [2][24][NT][16]
+    static constexpr int LDS_FLOATS = L_VS + 2 * VSZ;
+    static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS");
+};
+
+__device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+__device__ __forceinline__ void st4(float *p, const f32x4 &v) { *reinterpret_cast<f32x4 *>(p) = v; }
+
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// a * s + b with a scalar factor in both halves (v_pk_fma_f32; the factor is splat into a register pair by the caller)
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 s, f32x2 b) { f32x2 r; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(s), "v"(b)); return r; }
+
+struct V4 { f32x2 lo, hi; };                           // four channels as two packed pairs
+__device__ __forceinline__ V4 operator+(const V4 &a, const V4 &b) { return V4{pk_add(a.lo, b.lo), pk_add(a.hi, b.hi)}; }
+__device__ __forceinline__ V4 operator-(const V4 &a, const V4 &b) { return V4{pk_sub(a.lo, b.lo), pk_sub(a.hi, b.hi)}; }
+__device__ __forceinline__ V4 fma4(const V4 &a, const f32x2 &s, const V4 &b) { return V4{pk_fma(a.lo, s, b.lo), pk_fma(a.hi, s, b.hi)}; }
+__device__ __forceinline__ V4 to4(const f32x4 &v) { return V4{f32x2{v[0], v[1]}, f32x2{v[2], v[3]}}; }
+__device__ __forceinline__ f32x4 from4(const V4 &v) { return f32x4{v.lo[0], v.lo[1], v.hi[0], v.hi[1]}; }
+
+__device__ __forceinline__ float relu1(float x) { const int b = __builtin_bit_cast(int, x); return __builtin_bit_cast(float, b > 0 ? b : 0); }
+
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void unroll_k(F &&f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); unroll_k<N, I + 1>(f); }
+}
+
+// F(4,3) input transform of six values along a row (B_x^T d): 12 operations
+//   r0 = 4 d0 - 5 d2 + d4      r1 = (d4 - 4 d2) + (d3 - 4 d1)     r2 = (d4 - 4 d2) - (d3 - 4 d1)
+//   r5 = 4 d1 - 5 d3 + d5      r3 = (d4 - d2) + 2 (d3 - d1)       r4 = (d4 - d2) - 2 (d3 - d1)
+__device__ __forceinline__ void bx_transform(const V4 (&d)[6], V4 (&r)[6]) {
+    const f32x2 c4 = {4.f, 4.f}, cm4 = {-4.f, -4.f}, cm5 = {-5.f, -5.f}, c2 = {2.f, 2.f}, cm2 = {-2.f, -2.f};
+    r[0] = fma4(d[2], cm5, fma4(d[0], c4, d[4]));
+    r[5] = fma4(d[3], cm5, fma4(d[1], c4, d[5]));
+    const V4 a = fma4(d[2], cm4, d[4]), b = fma4(d[1], cm4, d[3]);
+    r[1] = a + b; r[2] = a - b;
+    const V4 c = d[4] - d[2], e = d[3] - d[1];
+    r[3] = fma4(e, c2, c); r[4] = fma4(e, cm2, c);
+}
+
+}  // namespace
+
+template <int TBW>
+__global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
+    using G = W24<TBW>;
+    constexpr int NT = G::NT, TRX = G::TRX, WIH = G::WIH, WIW = G::WIW, WHP = G::WHP, NITX = G::NITX, RS = G::RS, XSZ = G::XSZ, VSZ = G::VSZ, L_XS = G::L_XS, L_VS = G::L_VS;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int cin = a.C0 + a.C1;
+    const int nchunk = cin / WKC;
+    const int regs_x = (a.Wo + 4 * TRX - 1) / (4 * TRX), regs_y = (a.Ho + 2 * TRY - 1) / (2 * TRY);
+    const int regions = regs_x * regs_y;
+    const int per_group = a.N * regions;
+    const int nitems = per_group * (a.Cout / 64);
+    const int my_items = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nstages = my_items * nchunk;
+    const bool producer = __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256;
+
+    if (producer) {
+        const int tid = threadIdx.x - 256;
+        constexpr int C4 = WKC / 4, PSTEP = 256 / C4;                 // 64 halo pixels per pass, 6 passes
+        const int c4 = tid % C4, pix0 = tid / C4;
+        // In-image test of a halo pixel: its row bit and column bit (10 + 34 bits) against the region's 64-bit mask
+        unsigned tb_lo[NITX], tb_hi[NITX], pixoff[NITX], pre[NITX], xoff[NITX];
+#pragma unroll
+        for (int it = 0; it < NITX; ++it) {
+            const int pix = pix0 + it * PSTEP;
+            const int iy = pix / WIW, ix = pix - iy * WIW;
+            const unsigned long long m = pix < WHP ? (1ull << iy) | (1ull << (WIH + ix)) : (1ull << 63);      // bit 63 is never set in a region mask
+            tb_lo[it] = (unsigned)m; tb_hi[it] = (unsigned)(m >> 32);
+            pixoff[it] = (unsigned)(iy * a.W + ix);
+            pre[it] = 0;
+            xoff[it] = pix < WHP ? (unsigned)((iy * RS + ix) * XS_S + 4 * c4) : (unsigned)(XSZ - 32 + 4 * c4);
+        }
+        int cur_cs = 0;
+        u32x4 xr[NITX];
+        int l_ch = 0, l_item = blockIdx.x, l_n = 0, l_iy0 = 0, l_ix0 = 0;
+        auto locate = [&]() {
+            const int rest = l_item % per_group;
+            l_n = rest / regions;
+            const int r = rest - l_n * regions;
+            const int ry = r / regs_x, rx = r - ry * regs_x;
+            l_iy0 = ry * 2 * TRY - 1; l_ix0 = rx * 4 * TRX - 1;
+        };
+        locate();
+        auto loadx = [&]() {                            // raw halo of the cursor stage -> registers; advances the cursor
+            const float *src; int cs;
+            const bool from0 = l_ch * WKC < a.C0;
+            if (from0) { src = a.in0 + l_ch * WKC; cs = a.C0; }
+            else       { src = a.in1 + (l_ch * WKC - a.C0); cs = a.C1; }
+            if (cs != cur_cs) {
+                cur_cs = cs;
+#pragma unroll
+                for (int it = 0; it < NITX; ++it) pre[it] = pixoff[it] * (unsigned)(cs * 4) + 16u * c4;
+            }
+            src += ((long long)(l_n * a.H + l_iy0) * a.W + l_ix0) * cs;   // may point before the tensor; masked lanes never use it
+            const int ylo = l_iy0 < 0 ? -l_iy0 : 0, yhi = a.H - l_iy0 < WIH ? a.H - l_iy0 : WIH;
+            const int xlo = l_ix0 < 0 ? -l_ix0 : 0, xhi = a.W - l_ix0 < WIW ? a.W - l_ix0 : WIW;
+            const unsigned long long cm = (((1ull << yhi) - 1ull) & ~((1ull << ylo) - 1ull)) | ((((1ull << xhi) - 1ull) & ~((1ull << xlo) - 1ull)) << WIH);
+            const unsigned cm_lo = (unsigned)cm, cm_hi = (unsigned)(cm >> 32);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+            for (int it = 0; it < NITX; ++it) {
+                const bool ok = (cm_lo & tb_lo[it]) == tb_lo[it] && (cm_hi & tb_hi[it]) == tb_hi[it];
+                xr[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? pre[it] : 0x80000000u, 0, 0);    // out of range -> zeros
+            }
+            if (++l_ch == nchunk) { l_ch = 0; l_item += gridDim.x; if (l_item < nitems) locate(); }
+        };
+        auto storex = [&](auto par) {
+            constexpr int B = decltype(par)::value;
+#pragma unroll
+            for (int it = 0; it < NITX; ++it) *reinterpret_cast<u32x4 *>(lds + L_XS + B * XSZ + xoff[it]) = xr[it];
+        };
+        // V = B_y^T d B_x per (tile, channel quad).  The producer waves split the row positions i = 0..3 of B_y^T d
+        //   (d0 - d2, d1 + d2, d2 - d1, d1 - d3):
+        // TBW = 2: wave pairs -- waves 4-5 produce i = 0, 1 (from patch rows 0-2), waves 6-7 i = 2, 3 (rows 1-3): 18 reads, two F(4,3)
+        //          column transforms and 12 writes per thread;
+        // TBW = 1: one position per wave (rows {0,2}, {1,2}, {1,2}, {1,3}): 12 reads, one column transform, 6 writes.
+        constexpr int PARTS = 4 / TBW, PP = TBW;        // parts of the producer half of the workgroup, row positions per part
+        const int part = __builtin_amdgcn_readfirstlane(tid) / (256 / PARTS);
+        const int xt = tid % (256 / PARTS), x_tile = xt / C4, x_q = xt - x_tile * C4;
+        // first patch row this thread reads and the distance to its second one (TBW = 1)
+        const int row0 = TBW == 2 ? part : (part == 0 ? 0 : 1), rstep = TBW == 2 ? 1 : (part == 0 ? 2 : part == 3 ? 2 : 1);
+        const float *const xs_r = lds + L_XS + ((2 * (x_tile / TRX) + row0) * RS + 4 * (x_tile % TRX)) * XS_S + 4 * x_q;
+        // transformed stage: [k][tile][16] floats, quad q of tile t in slot q ^ (3 * ((t >> 3) & 1)): a consumer ds_read_b128's 16-lane
+        // group holds tiles {0-3, 12-15} of one k-quarter g and {4-11} of g + 1 -- with the flip all sixteen 16-byte slots differ
+        float *const vs_w = lds + L_VS + part * (6 * PP) * NT * WKC + x_tile * WKC + 4 * (x_q ^ (3 * ((x_tile >> 3) & 1)));
+        constexpr int NR = TBW == 2 ? 3 : 2;            // patch rows a thread reads
+        V4 e[NR][6];
+        auto xform_read = [&](auto par) {
+            constexpr int B = decltype(par)::value;
+            const float *xs = xs_r + B * XSZ;
+#pragma unroll
+            for (int i = 0; i < NR; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) e[i][j] = to4(ld4(xs + (i * rstep * RS + j) * XS_S));
+        };
+        auto xform_finish = [&](auto par) {
+            constexpr int B = decltype(par)::value;
+            float *vs = vs_w + B * VSZ;
+            if constexpr (TBW == 2) {
+                auto rows = [&](auto hc) {              // a real (uniform) branch per wave pair
+                    constexpr int HALF = decltype(hc)::value;
+                    V4 wa[6], wb[6], ra[6], rb[6];
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        if constexpr (HALF == 0) { wa[j] = e[0][j] - e[2][j]; wb[j] = e[1][j] + e[2][j]; }   // i = 0: d0 - d2, i = 1: d1 + d2
+                        else                     { wa[j] = e[1][j] - e[0][j]; wb[j] = e[0][j] - e[2][j]; }   // i = 2: d2 - d1, i = 3: d1 - d3 (rows 1..3 are e[0..2])
+                    }
+                    bx_transform(wa, ra);
+                    bx_transform(wb, rb);
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        st4(vs + j * NT * WKC, from4(ra[j]));
+                        st4(vs + (6 + j) * NT * WKC, from4(rb[j]));
+                    }
+                };
+                if (part == 0) rows(std::integral_constant<int, 0>{});
+                else           rows(std::integral_constant<int, 1>{});
+            } else {
+                // e[0], e[1] = rows {0,2}, {1,2}, {1,2}, {1,3} for i = 0..3
+                V4 w[6], r[6];
+                if (part == 1) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) w[j] = e[0][j] + e[1][j];        // d1 + d2
+                } else if (part == 2) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) w[j] = e[1][j] - e[0][j];        // d2 - d1
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) w[j] = e[0][j] - e[1][j];        // d0 - d2 / d1 - d3
+                }
+                bx_transform(w, r);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) st4(vs + j * NT * WKC, from4(r[j]));
+            }
+        };
+        constexpr std::integral_constant<int, 0> P0{};
+        constexpr std::integral_constant<int, 1> P1{};
+        // prologue: XS[0] <- stage 0, XS[1] <- stage 1, registers <- stage 2
+        if (nstages > 0) { loadx(); storex(P0); }
+        if (nstages > 1) { loadx(); storex(P1); }
+        if (nstages > 2) loadx();
+        __syncthreads();                                // barrier X: XS[0], XS[1] visible to every producer
+        if (nstages > 0) { xform_read(P0); xform_finish(P0); }
+        auto stage = [&](auto par, auto npar, int s) {
+            __syncthreads();                            // barrier #s: VS[s&1] ready / VS[(s+1)&1], XS[s&1] free
+            const bool xf = s + 1 < nstages;
+            if (xf) xform_read(npar);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 2 < nstages) storex(par);           // stage s+2 (requested an iteration ago) replaces stage s
+            if (s + 3 < nstages) loadx();
+            __builtin_amdgcn_sched_barrier(0);
+            if (xf) xform_finish(npar);
+        };
+#pragma unroll 1
+        for (int s = 0; s < nstages; s += 2) {
+            stage(P0, P1, s);
+            if (s + 1 < nstages) stage(P1, P0, s + 1);
+        }
+    } else {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;      // consumer wave = Cout block within the item
+        const int t16 = lane & 15, g = lane >> 4;
+        __syncthreads();                                // barrier X
+        int s = 0;
+        constexpr int AD = TBW == 2 ? 4 : 8;            // A-fragment queue depth (k positions; 256 / 128 MFMA cycles each)
+        f32x4 aq[AD];
+        // this lane's B operand of tile block tb: tile t = 16 tb + t16, quad g -> slot g ^ (3 * ((t >> 3) & 1))
+        const int vofs0 = t16 * WKC + 4 * (g ^ (3 * ((t16 >> 3) & 1)));
+        const int vofs1 = (TBW == 2 ? 16 + t16 : t16) * WKC + 4 * (g ^ (3 * ((t16 >> 3) & 1)));
+        for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+            const int grp = item / per_group, rest = item - grp * per_group;
+            const int n = rest / regions;
+            const int r = rest - n * regions;
+            const int ry = r / regs_x, rx = r - ry * regs_x;
+            const int co = (grp * 4 + wave) * 16 + 4 * g;
+            const f32x4 bias = ld4(a.bias + co);
+            // the folded-BN bias rides through the output transform as M[1][1] (k = 7): A_y^T column 1 and A_x^T column 1 are all ones
+            f32x4 acc[NK][TBW];
+            const float *wbase = a.wpk + ((size_t)grp * nchunk * 4 + wave) * (NK * 64 * 4) + lane * 4;
+            const int item_n = item + (int)gridDim.x < nitems ? item + (int)gridDim.x : item;
+            const float *wnext = a.wpk + ((size_t)(item_n / per_group) * nchunk * 4 + wave) * (NK * 64 * 4) + lane * 4;
+            if (item == (int)blockIdx.x) {
+#pragma unroll
+                for (int i = 0; i < AD; ++i) aq[i] = ld4(wbase + i * 64 * 4);
+            }
+            auto chunk = [&](auto firstc, int ch) {
+                constexpr bool FIRST = decltype(firstc)::value;
+                __syncthreads();                        // barrier #s
+                const float *vs = lds + L_VS + (s & 1) * VSZ;
+                const float *wp = wbase + (size_t)ch * 4 * (NK * 64 * 4);
+                const float *wn = ch + 1 < nchunk ? wp + 4 * (NK * 64 * 4) : wnext;
+                f32x4 b0[2], b1[2];
+                b0[0] = ld4(vs + vofs0);
+                if constexpr (TBW == 2) b1[0] = ld4(vs + vofs1);
+                unroll_k<NK>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    const f32x4 av = aq[k % AD];
+                    if constexpr (k + AD < NK) aq[k % AD] = ld4(wp + (k + AD) * 64 * 4);
+                    else                       aq[k % AD] = ld4(wn + (k + AD - NK) * 64 * 4);
+                    if constexpr (k + 1 < NK) {         // B operands of k+1 in flight during the MFMAs of k
+                        b0[(k + 1) & 1] = ld4(vs + (k + 1) * NT * WKC + vofs0);
+                        if constexpr (TBW == 2) b1[(k + 1) & 1] = ld4(vs + (k + 1) * NT * WKC + vofs1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (FIRST) {
+                        const f32x4 c0v = k == 7 ? bias : f32x4{0.f, 0.f, 0.f, 0.f};
+                        acc[k][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], b0[k & 1][0], c0v, 0, 0, 0);
+                        if constexpr (TBW == 2) acc[k][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], b1[k & 1][0], c0v, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int i = FIRST ? 1 : 0; i < 4; ++i) {
+                        acc[k][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], b0[k & 1][i], acc[k][0], 0, 0, 0);
+                        if constexpr (TBW == 2) acc[k][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], b1[k & 1][i], acc[k][1], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                ++s;
+            };
+            chunk(std::true_type{}, 0);
+#pragma unroll 1
+            for (int ch = 1; ch < nchunk; ++ch) chunk(std::false_type{}, ch);
+            // ---- output transform Y = A_y^T M A_x, ReLU, NHWC stores ----
+            asm volatile("s_nop 15" ::: "memory");        // MFMA -> VALU wait states before the inline-asm packed adds (kernels_wino.hip)
+            const f32x2 c2 = {2.f, 2.f}, c4 = {4.f, 4.f}, c8 = {8.f, 8.f};
+#pragma unroll
+            for (int tb = 0; tb < TBW; ++tb) {
+                const int q = tb * 16 + t16;
+                const int oy = (ry * TRY + q / TRX) * 2, ox = (rx * TRX + q % TRX) * 4;
+                V4 t0[6], t1[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {           // rows: t = A_y^T M  (y0 = m0 + m1 + m2, y1 = m1 - m2 - m3)
+                    const V4 m0 = to4(acc[j][tb]), m1 = to4(acc[6 + j][tb]), m2 = to4(acc[12 + j][tb]), m3 = to4(acc[18 + j][tb]);
+                    t0[j] = (m0 + m1) + m2;
+                    t1[j] = (m1 - m2) - m3;
+                }
+                float *const o00 = a.out + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.Cout + co;
+                const size_t dx = (size_t)a.Cout, dy = (size_t)a.Wo * a.Cout;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const V4 (&t)[6] = i == 0 ? t0 : t1;
+                    // columns: y = t A_x   (A_x^T rows: [1 1 1 1 1 0], [0 1 -1 2 -2 0], [0 1 1 4 4 0], [0 1 -1 8 -8 1])
+                    const V4 s1 = t[1] + t[2], d1 = t[1] - t[2], s2 = t[3] + t[4], d2 = t[3] - t[4];
+                    V4 y[4];
+                    y[0] = (t[0] + s1) + s2;
+                    y[1] = fma4(d2, c2, d1);
+                    y[2] = fma4(s2, c4, s1);
+                    y[3] = fma4(d2, c8, d1) + t[5];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        f32x4 v = from4(y[j]);
+                        if (a.relu) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) v[c] = relu1(v[c]);
+                        }
+                        if (oy + i < a.Ho && ox + j < a.Wo) st4(o00 + i * dy + j * dx, v);
+                    }
+                }
+            }
+        }
+    }
+}
+
+int wino24_lds_bytes(int tbw) { return (tbw == 2 ? W24<2>::LDS_FLOATS : W24<1>::LDS_FLOATS) * 4; }
+
+template <int TBW>
+static hipError_t launch_wino24_t(const ConvArgs &a, hipStream_t s) {
+    using G = W24<TBW>;
+    const int n_cu = device_cu_count();
+    static OncePerDevice lds_ok;
+    hipError_t e = allow_dynamic_lds(lds_ok, reinterpret_cast<const void *>(wino24_pc_kernel<TBW>), G::LDS_FLOATS * 4);
+    if (e != hipSuccess) return e;
+    const int regs_x = (a.Wo + 4 * G::TRX - 1) / (4 * G::TRX), regs_y = (a.Ho + 2 * TRY - 1) / (2 * TRY);
+    const long long nitems = (long long)a.N * regs_x * regs_y * (a.Cout / 64);
+    dim3 grid((unsigned)(nitems < n_cu ? nitems : n_cu));
+    hipLaunchKernelGGL(wino24_pc_kernel<TBW>, grid, dim3(512), G::LDS_FLOATS * 4, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_wino24(const ConvArgs &a, int tile_cols, hipStream_t s) {
+    if (a.Cout % 64 || (a.C0 + a.C1) % WKC || a.C0 % WKC || a.up2 || a.in0_map) return hipErrorInvalidValue;
+    return tile_cols == 32 ? launch_wino24_t<2>(a, s) : tile_cols == 16 ? launch_wino24_t<1>(a, s) : hipErrorInvalidValue;
+}
+
+size_t pack_wino24_weights(const float *w, int cin, int cout, float *dst) {
+    // w: folded [3][3][cin][cout].  U = G_y g G_x^T per (ci, co); G_y = F(2,3) rows, G_x = F(4,3) columns.
+    // dst[group of 64][chunk][cbl 0..3][k = 6 i + j][lane][s]:  lane = (g << 4) | m, ci = chunk*16 + 4*g + s, co = (group*4 + cbl)*16 + m
+    static const double GY[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
+    static const double GX[6][3] = {{1.0 / 4, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                    {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    const int nchunk = cin / WKC;
+    size_t o = 0;
+    for (int grp = 0; grp < cout / 64; ++grp)
+        for (int ch = 0; ch < nchunk; ++ch)
+            for (int cbl = 0; cbl < 4; ++cbl)
+                for (int k = 0; k < NK; ++k)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int s = 0; s < 4; ++s) {
+                            const int m = lane & 15, g = lane >> 4;
+                            const int ci = ch * WKC + 4 * g + s, co = (grp * 4 + cbl) * 16 + m;
+                            const int i = k / 6, j = k % 6;
+                            double u = 0.0;
+                            for (int p = 0; p < 3; ++p)
+                                for (int q = 0; q < 3; ++q)
+                                    u += GY[i][p] * (double)w[((size_t)(p * 3 + q) * cin + ci) * cout + co] * GX[j][q];
+                            dst[o++] = (float)u;
+                        }
+    return o;
+}
+
+}  // namespace ukbb
