@@ -92,6 +92,15 @@ __device__ __forceinline__ void bx_transform(const V4 (&d)[6], V4 (&r)[6]) {
 
 }  // namespace
 
+// Diagnostic only (-DUKBB_WINO_STAMPS + UKBB_STAMPS=1): s_memtime stamps around the phases of a stage (perturbs the MFMA stream)
+#ifdef UKBB_WINO_STAMPS
+#define STAMP(v) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); }
+#define STAMP_DO(...) __VA_ARGS__
+__device__ unsigned long long g_w24stamps[8];
+#else
+#define STAMP(v)
+#define STAMP_DO(...)
+#endif
 template <int TBW>
 __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
     using G = W24<TBW>;
@@ -134,27 +143,35 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
             l_iy0 = ry * 2 * TRY - 1; l_ix0 = rx * 4 * TRX - 1;
         };
         locate();
+        // The in-image test and the byte offsets of a thread's pieces depend on the region and on the source's channel count only: they are
+        // recomputed when the cursor enters a new item or switches source, not per stage -- every vector instruction of a producer waits
+        // for a gap in the co-resident consumer's MFMA stream (r02: ~28-60 cycles each), and the transform below already needs ~75.
+        unsigned vo[NITX];
         auto loadx = [&]() {                            // raw halo of the cursor stage -> registers; advances the cursor
             const float *src; int cs;
             const bool from0 = l_ch * WKC < a.C0;
             if (from0) { src = a.in0 + l_ch * WKC; cs = a.C0; }
             else       { src = a.in1 + (l_ch * WKC - a.C0); cs = a.C1; }
-            if (cs != cur_cs) {
-                cur_cs = cs;
+            if (l_ch == 0 || cs != cur_cs) {            // uniform
+                if (cs != cur_cs) {
+                    cur_cs = cs;
 #pragma unroll
-                for (int it = 0; it < NITX; ++it) pre[it] = pixoff[it] * (unsigned)(cs * 4) + 16u * c4;
+                    for (int it = 0; it < NITX; ++it) pre[it] = pixoff[it] * (unsigned)(cs * 4) + 16u * c4;
+                }
+                const int ylo = l_iy0 < 0 ? -l_iy0 : 0, yhi = a.H - l_iy0 < WIH ? a.H - l_iy0 : WIH;
+                const int xlo = l_ix0 < 0 ? -l_ix0 : 0, xhi = a.W - l_ix0 < WIW ? a.W - l_ix0 : WIW;
+                const unsigned long long cm = (((1ull << yhi) - 1ull) & ~((1ull << ylo) - 1ull)) | ((((1ull << xhi) - 1ull) & ~((1ull << xlo) - 1ull)) << WIH);
+                const unsigned cm_lo = (unsigned)cm, cm_hi = (unsigned)(cm >> 32);
+#pragma unroll
+                for (int it = 0; it < NITX; ++it) {
+                    const bool ok = (cm_lo & tb_lo[it]) == tb_lo[it] && (cm_hi & tb_hi[it]) == tb_hi[it];
+                    vo[it] = ok ? pre[it] : 0x80000000u;    // out of range -> zeros
+                }
             }
             src += ((long long)(l_n * a.H + l_iy0) * a.W + l_ix0) * cs;   // may point before the tensor; masked lanes never use it
-            const int ylo = l_iy0 < 0 ? -l_iy0 : 0, yhi = a.H - l_iy0 < WIH ? a.H - l_iy0 : WIH;
-            const int xlo = l_ix0 < 0 ? -l_ix0 : 0, xhi = a.W - l_ix0 < WIW ? a.W - l_ix0 : WIW;
-            const unsigned long long cm = (((1ull << yhi) - 1ull) & ~((1ull << ylo) - 1ull)) | ((((1ull << xhi) - 1ull) & ~((1ull << xlo) - 1ull)) << WIH);
-            const unsigned cm_lo = (unsigned)cm, cm_hi = (unsigned)(cm >> 32);
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-            for (int it = 0; it < NITX; ++it) {
-                const bool ok = (cm_lo & tb_lo[it]) == tb_lo[it] && (cm_hi & tb_hi[it]) == tb_hi[it];
-                xr[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? pre[it] : 0x80000000u, 0, 0);    // out of range -> zeros
-            }
+            for (int it = 0; it < NITX; ++it) xr[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo[it], 0, 0);
             if (++l_ch == nchunk) { l_ch = 0; l_item += gridDim.x; if (l_item < nitems) locate(); }
         };
         auto storex = [&](auto par) {
@@ -234,21 +251,28 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
         if (nstages > 2) loadx();
         __syncthreads();                                // barrier X: XS[0], XS[1] visible to every producer
         if (nstages > 0) { xform_read(P0); xform_finish(P0); }
+        STAMP_DO(unsigned long long pw = 0, px_ = 0, pl = 0, t0, t1, t2, t3;)
         auto stage = [&](auto par, auto npar, int s) {
+            STAMP(t0)
             __syncthreads();                            // barrier #s: VS[s&1] ready / VS[(s+1)&1], XS[s&1] free
+            STAMP(t1)
             const bool xf = s + 1 < nstages;
             if (xf) xform_read(npar);
             __builtin_amdgcn_sched_barrier(0);
             if (s + 2 < nstages) storex(par);           // stage s+2 (requested an iteration ago) replaces stage s
             if (s + 3 < nstages) loadx();
             __builtin_amdgcn_sched_barrier(0);
+            STAMP(t2)
             if (xf) xform_finish(npar);
+            STAMP(t3)
+            STAMP_DO(pw += t1 - t0; px_ += t2 - t1; pl += t3 - t2;)
         };
 #pragma unroll 1
         for (int s = 0; s < nstages; s += 2) {
             stage(P0, P1, s);
             if (s + 1 < nstages) stage(P1, P0, s + 1);
         }
+        STAMP_DO(if (threadIdx.x == 256) { atomicAdd(g_w24stamps + 0, pw); atomicAdd(g_w24stamps + 1, px_); atomicAdd(g_w24stamps + 2, pl); atomicAdd(g_w24stamps + 3, (unsigned long long)nstages); })
     } else {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;      // consumer wave = Cout block within the item
         const int t16 = lane & 15, g = lane >> 4;
@@ -256,6 +280,7 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
         int s = 0;
         constexpr int AD = TBW == 2 ? 4 : 8;            // A-fragment queue depth (k positions; 256 / 128 MFMA cycles each)
         f32x4 aq[AD];
+        STAMP_DO(unsigned long long cw = 0, cc = 0, ce = 0, sc0, sc1, sc2, sc3;)
         // this lane's B operand of tile block tb: tile t = 16 tb + t16, quad g -> slot g ^ (3 * ((t >> 3) & 1))
         const int vofs0 = t16 * WKC + 4 * (g ^ (3 * ((t16 >> 3) & 1)));
         const int vofs1 = (TBW == 2 ? 16 + t16 : t16) * WKC + 4 * (g ^ (3 * ((t16 >> 3) & 1)));
@@ -277,14 +302,47 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
             }
             auto chunk = [&](auto firstc, int ch) {
                 constexpr bool FIRST = decltype(firstc)::value;
+                STAMP(sc0)
                 __syncthreads();                        // barrier #s
+                STAMP(sc1)
                 const float *vs = lds + L_VS + (s & 1) * VSZ;
                 const float *wp = wbase + (size_t)ch * 4 * (NK * 64 * 4);
                 const float *wn = ch + 1 < nchunk ? wp + 4 * (NK * 64 * 4) : wnext;
+                if constexpr (TBW == 1) {
+                    // one tile block per wave: the four MFMAs of a position form a dependent chain, so two positions run interleaved
+                    // (stamps of the first build: 4.7 k cycles per stage for 96 MFMAs = 3.1 k)
+                    constexpr int BD = 2, BRG = BD + 1;             // B pairs in flight ahead of the MFMAs, ring size
+                    f32x4 bp[BRG][2];
+#pragma unroll
+                    for (int q = 0; q < BD; ++q) { bp[q][0] = ld4(vs + (2 * q) * NT * WKC + vofs0); bp[q][1] = ld4(vs + (2 * q + 1) * NT * WKC + vofs0); }
+                    unroll_k<NK / 2>([&](auto pc) {
+                        constexpr int p = decltype(pc)::value, k0 = 2 * p, k1 = 2 * p + 1;
+                        const f32x4 av0 = aq[k0 % AD], av1 = aq[k1 % AD];
+                        if constexpr (k0 + AD < NK) aq[k0 % AD] = ld4(wp + (k0 + AD) * 64 * 4);
+                        else                        aq[k0 % AD] = ld4(wn + (k0 + AD - NK) * 64 * 4);
+                        if constexpr (k1 + AD < NK) aq[k1 % AD] = ld4(wp + (k1 + AD) * 64 * 4);
+                        else                        aq[k1 % AD] = ld4(wn + (k1 + AD - NK) * 64 * 4);
+                        if constexpr (p + BD < NK / 2) {
+                            bp[(p + BD) % BRG][0] = ld4(vs + (k0 + 2 * BD) * NT * WKC + vofs0);
+                            bp[(p + BD) % BRG][1] = ld4(vs + (k1 + 2 * BD) * NT * WKC + vofs0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (FIRST) {
+                            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                            acc[k0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[0], bp[p % BRG][0][0], k0 == 7 ? bias : z, 0, 0, 0);
+                            acc[k1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[0], bp[p % BRG][1][0], k1 == 7 ? bias : z, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int i = FIRST ? 1 : 0; i < 4; ++i) {
+                            acc[k0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[i], bp[p % BRG][0][i], acc[k0][0], 0, 0, 0);
+                            acc[k1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[i], bp[p % BRG][1][i], acc[k1][0], 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                }
                 f32x4 b0[2], b1[2];
-                b0[0] = ld4(vs + vofs0);
-                if constexpr (TBW == 2) b1[0] = ld4(vs + vofs1);
-                unroll_k<NK>([&](auto kc) {
+                if constexpr (TBW == 2) { b0[0] = ld4(vs + vofs0); b1[0] = ld4(vs + vofs1); }
+                if constexpr (TBW == 2) unroll_k<NK>([&](auto kc) {
                     constexpr int k = decltype(kc)::value;
                     const f32x4 av = aq[k % AD];
                     if constexpr (k + AD < NK) aq[k % AD] = ld4(wp + (k + AD) * 64 * 4);
@@ -306,11 +364,14 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 });
+                STAMP(sc2)
+                STAMP_DO(cw += sc1 - sc0; cc += sc2 - sc1;)
                 ++s;
             };
             chunk(std::true_type{}, 0);
 #pragma unroll 1
             for (int ch = 1; ch < nchunk; ++ch) chunk(std::false_type{}, ch);
+            STAMP(sc2)
             // ---- output transform Y = A_y^T M A_x, ReLU, NHWC stores ----
             asm volatile("s_nop 15" ::: "memory");        // MFMA -> VALU wait states before the inline-asm packed adds (kernels_wino.hip)
             const f32x2 c2 = {2.f, 2.f}, c4 = {4.f, 4.f}, c8 = {8.f, 8.f};
@@ -348,7 +409,10 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
                     }
                 }
             }
+            STAMP(sc3)
+            STAMP_DO(ce += sc3 - sc2;)
         }
+        STAMP_DO(if (threadIdx.x == 0) { atomicAdd(g_w24stamps + 4, cw); atomicAdd(g_w24stamps + 5, cc); atomicAdd(g_w24stamps + 6, ce); })
     }
 }
 
@@ -364,7 +428,22 @@ static hipError_t launch_wino24_t(const ConvArgs &a, hipStream_t s) {
     const int regs_x = (a.Wo + 4 * G::TRX - 1) / (4 * G::TRX), regs_y = (a.Ho + 2 * TRY - 1) / (2 * TRY);
     const long long nitems = (long long)a.N * regs_x * regs_y * (a.Cout / 64);
     dim3 grid((unsigned)(nitems < n_cu ? nitems : n_cu));
+#ifdef UKBB_WINO_STAMPS
+    const bool on = getenv("UKBB_STAMPS") != nullptr;
+    unsigned long long z[8] = {0};
+    if (on) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_w24stamps), z, 64);
+#endif
     hipLaunchKernelGGL(wino24_pc_kernel<TBW>, grid, dim3(512), G::LDS_FLOATS * 4, s, a);
+#ifdef UKBB_WINO_STAMPS
+    if (on) {
+        unsigned long long h[8];
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_w24stamps), 64);
+        const double st = (double)h[3];
+        fprintf(stderr, "WINO24STAMPS TBW %d Cin %d Cout %d Ho %d: per stage: producer wait %.0f read+store+load %.0f transform %.0f | consumer wait %.0f "
+                        "mfma %.0f epilogue(avg/stage) %.0f (stages/WG %.0f)\n", TBW, a.C0 + a.C1, a.Cout, a.Ho, h[0] / st, h[1] / st, h[2] / st,
+                h[4] / st, h[5] / st, h[6] / st, st / grid.x);
+    }
+#endif
     return hipGetLastError();
 }
 
