@@ -32,7 +32,11 @@ if __name__ == '__main__':
     bad = 0
     cases = [('FCN_sa', (3, 192, 208), [('conv2_1', 'conv2_1'), ('conv2_2', 'conv2'), ('conv3_1', 'conv3_1'), ('conv3_2', 'conv3')]),
              ('FCN_sa', (2, 48, 80), [('conv2_2', 'conv2'), ('conv3_2', 'conv3')]),                # ragged regions: 12 x 20 and 6 x 10 maps
-             ('UNet_ao', (2, 256, 256), [('conv2_1', 'conv2'), ('conv3_1', 'conv3'), ('up2_0', 'up2_0'), ('up2_1', 'up2')])]
+             ('UNet_ao', (2, 256, 256), [('conv2_1', 'conv2'), ('conv3_1', 'conv3'), ('up2_0', 'up2_0'), ('up2_1', 'up2')]),
+             # image pairs with seam regions (tiling 306, maps with Ho % 8 == 4): 12 x 13 maps, even and odd batches, 20 x 16 and 4 x 8 maps
+             ('FCN_sa', (4, 192, 208), [('conv4_1', 'conv4_1'), ('conv4_2', 'conv4')]),
+             ('FCN_sa', (3, 192, 208), [('conv4_2', 'conv4')]), ('FCN_sa', (1, 192, 208), [('conv4_1', 'conv4_1')]),
+             ('FCN_sa', (5, 160, 256), [('conv3_2', 'conv3')]), ('FCN_sa', (3, 64, 128), [('conv4_2', 'conv4')])]
     for model, (n, H, W), layers in cases:
         arch = MODELS[model]
         params = synthetic_params(arch, 1234)
@@ -47,7 +51,8 @@ if __name__ == '__main__':
                 bad += 1
                 continue
             res = {}
-            for cfg in (304, 305):
+            pair = (H >> int(layer[4])) % 8 == 4                                     # the layer's map height: tiling 306 applies
+            for cfg in ((304, 305, 306) if pair else (304, 305)):
                 out, ocfg, oact = run(arch, params, img, '%s:%d' % (layer, cfg), key)
                 if ocfg.get(layer) != cfg:
                     print('%s %s cfg %d: NOT TAKEN (ran %s)' % (model, layer, cfg, ocfg.get(layer)))
@@ -61,9 +66,10 @@ if __name__ == '__main__':
                 print('%-8s %dx%dx%d %-8s cfg %d vs 300: max |d| %.2e of the scale, labels differ %.5f %%: %s' % (
                     model, n, H, W, layer, cfg, err, 100 * lab, 'ok' if ok else 'FAIL'))
                 bad += 0 if ok else 1
-            if res.get(304) is not None and res.get(305) is not None:
-                same = np.array_equal(res[304], res[305])
-                print('%-8s %dx%dx%d %-8s 304 == 305 bit for bit: %s' % (model, n, H, W, layer, same))
+            got = [c for c in (304, 305, 306) if res.get(c) is not None]
+            if len(got) > 1:
+                same = all(np.array_equal(res[got[0]], res[c]) for c in got[1:])
+                print('%-8s %dx%dx%d %-8s %s agree bit for bit: %s' % (model, n, H, W, layer, ' == '.join(map(str, got)), same))
                 bad += 0 if same else 1
     print('FAIL' if bad else 'OK')
     sys.exit(1 if bad else 0)

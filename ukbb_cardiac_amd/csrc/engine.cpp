@@ -327,6 +327,10 @@ bool cfg_valid(const ConvConfig &c, int ks, int stride, int c0, int c1, int cout
     }
     if (c.pc == 4) {                                  // Winograd: 3x3 s1, 64-channel output groups, single source ok
         static const bool off = getenv("UKBB_NO_WINOGRAD") != nullptr;
+        if (c.id == 306) {                            // image pairs with seam regions (maps with Ho % 8 == 4): only where UKBB_CONV_CFG names it -- at N = 64 its 384
+            const char *e = getenv("UKBB_CONV_CFG");   // items leave half the CUs idle in the second round, and the plan must not depend on the batch (r04_notes.md)
+            if (!e || !strstr(e, ":306")) return false;
+        }
         if (is_wino24(c)) {                           // F(2x4,3x3), kernels_wino24.hip: 64-channel groups, K >= 64 (the MFMA-bound layers; no frame map)
             static const bool off24 = getenv("UKBB_NO_WINOGRAD24") != nullptr;
             if (off24 || cout % 64 || c0 + c1 < 64) return false;
@@ -477,7 +481,7 @@ int choose_cfg_raw(const std::string &layer, int ks, int stride, int c0, int c1,
     int best_id = -1;
     for (int i = 0; i < num_conv_configs(); ++i) {
         const ConvConfig &c = conv_config(i);
-        if (!cfg_valid(c, ks, stride, c0, c1, cout, fused_first)) continue;
+        if (c.id == 306 || !cfg_valid(c, ks, stride, c0, c1, cout, fused_first)) continue;
         const int group = c.mb * c.cb * c.wm;
         const int tiles = ((Ho + c.th - 1) / c.th) * ((Wo + c.tw - 1) / c.tw);
         const int npb = (c.th * c.tw + c.mb - 1) / c.mb;

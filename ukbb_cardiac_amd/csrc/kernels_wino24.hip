@@ -39,11 +39,17 @@ constexpr int WKC = 16;                               // input channels per stag
 constexpr int XS_S = 20;                              // raw tile: floats per pixel
 // TBW = 16-tile MFMA column blocks per region: 2 -> 4 x 8 tiles = 8 x 32 pixels, 1 -> 4 x 4 tiles = 8 x 16 pixels (twice the items:
 // maps whose 8 x 32 regions do not fill the CUs evenly, e.g. 24 x 26 at N = 64: 384 items on 256 CUs)
-template <int TBW> struct W24 {
+// PAIR (TBW = 1 only, maps with Ho = 8 m + 4, e.g. the 12 x 13 maps of level 4): the four left-over rows of an image would fill half a region.
+// Images are processed in pairs instead: m regions of image A, one SEAM region whose tile rows 0-1 are A's last four rows and whose tile
+// rows 2-3 are B's first four, then m regions of image B starting at its row 4 -- 2 m + 1 regions per pair with every tile slot in use
+// along y.  The seam's raw tile has 12 rows: A's rows 8 m - 1 .. 8 m + 4 (the last one is padding, forced to zero although B's row 0 lies
+// there in memory) and B's rows -1 .. 4 (the first one forced to zero although A's last row lies there).
+template <int TBW, bool PAIR = false> struct W24 {
+    static_assert(!PAIR || TBW == 1, "paired regions come in the 8 x 16 form only");
     static constexpr int NT = 16 * TBW, TRX = 4 * TBW;
-    static constexpr int WIH = 2 * TRY + 2, WIW = 4 * TRX + 2;        // raw halo tile: 10 x 34 / 10 x 18 pixels
+    static constexpr int WIH = 2 * TRY + (PAIR ? 4 : 2), WIW = 4 * TRX + 2;   // raw halo tile: 10 x 34 / 10 x 18 / 12 x 18 pixels
     static constexpr int WHP = WIH * WIW;
-    static constexpr int NITX = (WHP * (WKC / 4) + 255) / 256;        // staging passes of the 256 producer threads (6 / 3)
+    static constexpr int NITX = (WHP * (WKC / 4) + 255) / 256;        // staging passes of the 256 producer threads (6 / 3 / 4)
     // row pitch of the raw tile in pixels: the patch reads of a 16-lane ds_read_b128 group touch tiles of two tile rows when a tile row has
     // only 4 tiles; with a pitch of 24 pixels (two rows = a multiple of 256 bytes) their 64-byte pieces stay on different banks
     static constexpr int RS = TBW == 2 ? WIW : 24;
@@ -101,16 +107,19 @@ __device__ unsigned long long g_w24stamps[8];
 #define STAMP(v)
 #define STAMP_DO(...)
 #endif
-template <int TBW>
+template <int TBW, bool PAIR>
 __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
-    using G = W24<TBW>;
+    using G = W24<TBW, PAIR>;
     constexpr int NT = G::NT, TRX = G::TRX, WIH = G::WIH, WIW = G::WIW, WHP = G::WHP, NITX = G::NITX, RS = G::RS, XSZ = G::XSZ, VSZ = G::VSZ, L_XS = G::L_XS, L_VS = G::L_VS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int cin = a.C0 + a.C1;
     const int nchunk = cin / WKC;
-    const int regs_x = (a.Wo + 4 * TRX - 1) / (4 * TRX), regs_y = (a.Ho + 2 * TRY - 1) / (2 * TRY);
+    const int regs_x = (a.Wo + 4 * TRX - 1) / (4 * TRX);
+    // PAIR: `regions` counts the regions of an image PAIR (2 m + 1 rows of them), `a.N` images are (N + 1) / 2 pairs
+    const int pm = a.Ho / 8;                            // PAIR: m
+    const int regs_y = PAIR ? 2 * pm + 1 : (a.Ho + 2 * TRY - 1) / (2 * TRY);
     const int regions = regs_x * regs_y;
-    const int per_group = a.N * regions;
+    const int per_group = (PAIR ? (a.N + 1) / 2 : a.N) * regions;
     const int nitems = per_group * (a.Cout / 64);
     const int my_items = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int nstages = my_items * nchunk;
@@ -122,6 +131,7 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
         const int c4 = tid % C4, pix0 = tid / C4;
         // In-image test of a halo pixel: its row bit and column bit (10 + 34 bits) against the region's 64-bit mask
         unsigned tb_lo[NITX], tb_hi[NITX], pixoff[NITX], pre[NITX], xoff[NITX];
+        unsigned pixoff_s[PAIR ? NITX : 1];
 #pragma unroll
         for (int it = 0; it < NITX; ++it) {
             const int pix = pix0 + it * PSTEP;
@@ -129,18 +139,25 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
             const unsigned long long m = pix < WHP ? (1ull << iy) | (1ull << (WIH + ix)) : (1ull << 63);      // bit 63 is never set in a region mask
             tb_lo[it] = (unsigned)m; tb_hi[it] = (unsigned)(m >> 32);
             pixoff[it] = (unsigned)(iy * a.W + ix);
+            if constexpr (PAIR) pixoff_s[it] = (unsigned)((iy - (iy >= 6 ? 2 : 0)) * a.W + ix);    // seam: B's row -1 is the flat row behind A's row 8 m + 3
             pre[it] = 0;
             xoff[it] = pix < WHP ? (unsigned)((iy * RS + ix) * XS_S + 4 * c4) : (unsigned)(XSZ - 32 + 4 * c4);
         }
         int cur_cs = 0;
         u32x4 xr[NITX];
         int l_ch = 0, l_item = blockIdx.x, l_n = 0, l_iy0 = 0, l_ix0 = 0;
+        bool l_seam = false;                            // PAIR: the cursor's region is a seam region
         auto locate = [&]() {
             const int rest = l_item % per_group;
             l_n = rest / regions;
             const int r = rest - l_n * regions;
             const int ry = r / regs_x, rx = r - ry * regs_x;
             l_iy0 = ry * 2 * TRY - 1; l_ix0 = rx * 4 * TRX - 1;
+            if constexpr (PAIR) {                       // l_n = pair index so far
+                l_seam = ry == pm;
+                if (ry <= pm) l_n = 2 * l_n;                                     // image A (the seam's raw tile starts in A)
+                else { l_n = 2 * l_n + 1; l_iy0 = 4 + (ry - pm - 1) * 8 - 1; }   // image B, regions from its row 4
+            }
         };
         locate();
         // The in-image test and the byte offsets of a thread's pieces depend on the region and on the source's channel count only: they are
@@ -153,14 +170,26 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
             if (from0) { src = a.in0 + l_ch * WKC; cs = a.C0; }
             else       { src = a.in1 + (l_ch * WKC - a.C0); cs = a.C1; }
             if (l_ch == 0 || cs != cur_cs) {            // uniform
-                if (cs != cur_cs) {
+                if (!PAIR && cs != cur_cs) {
                     cur_cs = cs;
 #pragma unroll
                     for (int it = 0; it < NITX; ++it) pre[it] = pixoff[it] * (unsigned)(cs * 4) + 16u * c4;
                 }
-                const int ylo = l_iy0 < 0 ? -l_iy0 : 0, yhi = a.H - l_iy0 < WIH ? a.H - l_iy0 : WIH;
+                if constexpr (PAIR) {                   // the seam's lower six raw rows lie two flat rows earlier: offsets per item
+                    cur_cs = cs;
+#pragma unroll
+                    for (int it = 0; it < NITX; ++it) pre[it] = (l_seam ? pixoff_s[it] : pixoff[it]) * (unsigned)(cs * 4) + 16u * c4;
+                }
+                constexpr int NROW = PAIR ? 10 : WIH;   // rows of an ordinary region's raw tile (the seam uses all 12)
+                const int ylo = l_iy0 < 0 ? -l_iy0 : 0, yhi = a.H - l_iy0 < NROW ? a.H - l_iy0 : NROW;
                 const int xlo = l_ix0 < 0 ? -l_ix0 : 0, xhi = a.W - l_ix0 < WIW ? a.W - l_ix0 : WIW;
-                const unsigned long long cm = (((1ull << yhi) - 1ull) & ~((1ull << ylo) - 1ull)) | ((((1ull << xhi) - 1ull) & ~((1ull << xlo) - 1ull)) << WIH);
+                unsigned long long rowm = ((1ull << yhi) - 1ull) & ~((1ull << ylo) - 1ull);
+                if constexpr (PAIR) {
+                    if (l_seam) {                       // A: rows 8 m - 1 .. 8 m + 3 (raw 0..4; raw 5 = padding), B: rows 0 .. 4 (raw 7..11; raw 6 = padding) if B exists
+                        rowm = (l_iy0 < 0 ? 0x1eull : 0x1full) | (l_n + 1 < a.N ? (a.H > 4 ? 0xf80ull : 0x780ull) : 0ull);   // B's row 4 exists unless H = 4
+                    } else if (l_n >= a.N) rowm = 0;    // the B half of a last, single image: nothing to read (and nothing stored)
+                }
+                const unsigned long long cm = rowm | ((((1ull << xhi) - 1ull) & ~((1ull << xlo) - 1ull)) << WIH);
                 const unsigned cm_lo = (unsigned)cm, cm_hi = (unsigned)(cm >> 32);
 #pragma unroll
                 for (int it = 0; it < NITX; ++it) {
@@ -195,9 +224,16 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
         float *const vs_w = lds + L_VS + part * (6 * PP) * NT * WKC + x_tile * WKC + 4 * (x_q ^ (3 * ((x_tile >> 3) & 1)));
         constexpr int NR = TBW == 2 ? 3 : 2;            // patch rows a thread reads
         V4 e[NR][6];
+        int x_stage = 0;                                // PAIR: stage the next xform_read works on -> is its region a seam?
         auto xform_read = [&](auto par) {
             constexpr int B = decltype(par)::value;
             const float *xs = xs_r + B * XSZ;
+            if constexpr (PAIR) {
+                const int it_ = (int)blockIdx.x + (x_stage / nchunk) * (int)gridDim.x;
+                const int ry_ = ((it_ % per_group) % regions) / regs_x;
+                if (ry_ == pm && x_tile / TRX >= 2) xs += 2 * RS * XS_S;
+                ++x_stage;
+            }
 #pragma unroll
             for (int i = 0; i < NR; ++i)
 #pragma unroll
@@ -286,7 +322,7 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
         const int vofs1 = (TBW == 2 ? 16 + t16 : t16) * WKC + 4 * (g ^ (3 * ((t16 >> 3) & 1)));
         for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
             const int grp = item / per_group, rest = item - grp * per_group;
-            const int n = rest / regions;
+            const int n = rest / regions;               // PAIR: pair index
             const int r = rest - n * regions;
             const int ry = r / regs_x, rx = r - ry * regs_x;
             const int co = (grp * 4 + wave) * 16 + 4 * g;
@@ -378,7 +414,15 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
 #pragma unroll
             for (int tb = 0; tb < TBW; ++tb) {
                 const int q = tb * 16 + t16;
-                const int oy = (ry * TRY + q / TRX) * 2, ox = (rx * TRX + q % TRX) * 4;
+                int oy = (ry * TRY + q / TRX) * 2, on = n;
+                const int ox = (rx * TRX + q % TRX) * 4;
+                if constexpr (PAIR) {
+                    const int tr = q / TRX;
+                    if (ry < pm) on = 2 * n;                                                  // image A
+                    else if (ry == pm) { on = 2 * n + (tr >= 2 ? 1 : 0); oy = tr >= 2 ? 2 * (tr - 2) : 8 * pm + 2 * tr; }   // seam
+                    else { on = 2 * n + 1; oy = 4 + (ry - pm - 1) * 8 + 2 * tr; }             // image B
+                    if (on >= a.N) oy = a.Ho;                                                 // no such image: nothing is stored
+                }
                 V4 t0[6], t1[6];
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {           // rows: t = A_y^T M  (y0 = m0 + m1 + m2, y1 = m1 - m2 - m3)
@@ -386,7 +430,7 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
                     t0[j] = (m0 + m1) + m2;
                     t1[j] = (m1 - m2) - m3;
                 }
-                float *const o00 = a.out + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.Cout + co;
+                float *const o00 = a.out + ((size_t)(on * a.Ho + oy) * a.Wo + ox) * a.Cout + co;
                 const size_t dx = (size_t)a.Cout, dy = (size_t)a.Wo * a.Cout;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -416,40 +460,43 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
     }
 }
 
-int wino24_lds_bytes(int tbw) { return (tbw == 2 ? W24<2>::LDS_FLOATS : W24<1>::LDS_FLOATS) * 4; }
+int wino24_lds_bytes(int tbw, int pair) { return (tbw == 2 ? W24<2>::LDS_FLOATS : pair ? W24<1, true>::LDS_FLOATS : W24<1>::LDS_FLOATS) * 4; }
 
-template <int TBW>
+template <int TBW, bool PAIR>
 static hipError_t launch_wino24_t(const ConvArgs &a, hipStream_t s) {
-    using G = W24<TBW>;
+    using G = W24<TBW, PAIR>;
     const int n_cu = device_cu_count();
     static OncePerDevice lds_ok;
-    hipError_t e = allow_dynamic_lds(lds_ok, reinterpret_cast<const void *>(wino24_pc_kernel<TBW>), G::LDS_FLOATS * 4);
+    hipError_t e = allow_dynamic_lds(lds_ok, reinterpret_cast<const void *>(wino24_pc_kernel<TBW, PAIR>), G::LDS_FLOATS * 4);
     if (e != hipSuccess) return e;
-    const int regs_x = (a.Wo + 4 * G::TRX - 1) / (4 * G::TRX), regs_y = (a.Ho + 2 * TRY - 1) / (2 * TRY);
-    const long long nitems = (long long)a.N * regs_x * regs_y * (a.Cout / 64);
+    const int regs_x = (a.Wo + 4 * G::TRX - 1) / (4 * G::TRX);
+    const long long per_image_or_pair = PAIR ? (long long)(2 * (a.Ho / 8) + 1) * ((a.N + 1) / 2) : (long long)((a.Ho + 2 * TRY - 1) / (2 * TRY)) * a.N;
+    const long long nitems = per_image_or_pair * regs_x * (a.Cout / 64);
     dim3 grid((unsigned)(nitems < n_cu ? nitems : n_cu));
 #ifdef UKBB_WINO_STAMPS
     const bool on = getenv("UKBB_STAMPS") != nullptr;
     unsigned long long z[8] = {0};
     if (on) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_w24stamps), z, 64);
 #endif
-    hipLaunchKernelGGL(wino24_pc_kernel<TBW>, grid, dim3(512), G::LDS_FLOATS * 4, s, a);
+    hipLaunchKernelGGL((wino24_pc_kernel<TBW, PAIR>), grid, dim3(512), G::LDS_FLOATS * 4, s, a);
 #ifdef UKBB_WINO_STAMPS
     if (on) {
         unsigned long long h[8];
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_w24stamps), 64);
         const double st = (double)h[3];
-        fprintf(stderr, "WINO24STAMPS TBW %d Cin %d Cout %d Ho %d: per stage: producer wait %.0f read+store+load %.0f transform %.0f | consumer wait %.0f "
-                        "mfma %.0f epilogue(avg/stage) %.0f (stages/WG %.0f)\n", TBW, a.C0 + a.C1, a.Cout, a.Ho, h[0] / st, h[1] / st, h[2] / st,
+        fprintf(stderr, "WINO24STAMPS TBW %d%s Cin %d Cout %d Ho %d: per stage: producer wait %.0f read+store+load %.0f transform %.0f | consumer wait %.0f "
+                        "mfma %.0f epilogue(avg/stage) %.0f (stages/WG %.0f)\n", TBW, PAIR ? " paired" : "", a.C0 + a.C1, a.Cout, a.Ho, h[0] / st, h[1] / st, h[2] / st,
                 h[4] / st, h[5] / st, h[6] / st, st / grid.x);
     }
 #endif
     return hipGetLastError();
 }
 
-hipError_t launch_wino24(const ConvArgs &a, int tile_cols, hipStream_t s) {
+// tile_cols: 32 | 16 (regions of 8 x 32 / 8 x 16 pixels); pair: images in pairs with seam regions (16 only, Ho % 8 == 4)
+hipError_t launch_wino24(const ConvArgs &a, int tile_cols, int pair, hipStream_t s) {
     if (a.Cout % 64 || (a.C0 + a.C1) % WKC || a.C0 % WKC || a.up2 || a.in0_map) return hipErrorInvalidValue;
-    return tile_cols == 32 ? launch_wino24_t<2>(a, s) : tile_cols == 16 ? launch_wino24_t<1>(a, s) : hipErrorInvalidValue;
+    if (pair) return (tile_cols == 16 && a.Ho % 8 == 4 && a.Ho == a.H) ? launch_wino24_t<1, true>(a, s) : hipErrorInvalidValue;
+    return tile_cols == 32 ? launch_wino24_t<2, false>(a, s) : tile_cols == 16 ? launch_wino24_t<1, false>(a, s) : hipErrorInvalidValue;
 }
 
 size_t pack_wino24_weights(const float *w, int cin, int cout, float *dst) {
