@@ -33,6 +33,8 @@ if __name__ == '__main__':
     cases = [('FCN_sa', (3, 192, 208), [('conv2_1', 'conv2_1'), ('conv2_2', 'conv2'), ('conv3_1', 'conv3_1'), ('conv3_2', 'conv3')]),
              ('FCN_sa', (2, 48, 80), [('conv2_2', 'conv2'), ('conv3_2', 'conv3')]),                # ragged regions: 12 x 20 and 6 x 10 maps
              ('UNet_ao', (2, 256, 256), [('conv2_1', 'conv2'), ('conv3_1', 'conv3'), ('up2_0', 'up2_0'), ('up2_1', 'up2')]),
+             ('FCN_sa', (3, 192, 208), [('conv1_1', 'conv1')]), ('FCN_sa', (2, 48, 80), [('conv1_1', 'conv1')]),
+             ('UNet_ao', (2, 256, 256), [('conv1_1', 'conv1'), ('up1_0', 'up1_0'), ('up1_1', 'up1')]),
              # image pairs with seam regions (tiling 306, maps with Ho % 8 == 4): 12 x 13 maps, even and odd batches, 20 x 16 and 4 x 8 maps
              ('FCN_sa', (4, 192, 208), [('conv4_1', 'conv4_1'), ('conv4_2', 'conv4')]),
              ('FCN_sa', (3, 192, 208), [('conv4_2', 'conv4')]), ('FCN_sa', (1, 192, 208), [('conv4_1', 'conv4_1')]),
@@ -45,14 +47,15 @@ if __name__ == '__main__':
             img = (img - 0.3) / 0.25
         for layer, key in layers:
             try:
-                ref, rcfg, ract = run(arch, params, img, '%s:300' % layer, key)
+                ref, rcfg, ract = run(arch, params, img, '%s:%d' % (layer, 301 if layer in ('conv1_1', 'up1_0', 'up1_1') else 300), key)
             except Exception as e:
                 print('%s %s: activation %s not available (%s)' % (model, layer, key, e))
                 bad += 1
                 continue
             res = {}
             pair = (H >> int(layer[4])) % 8 == 4                                     # the layer's map height: tiling 306 applies
-            for cfg in ((304, 305, 306) if pair else (304, 305)):
+            narrow = layer in ('conv1_1', 'up1_0', 'up1_1')                          # 32 output channels: tiling 307 only
+            for cfg in ((307,) if narrow else (304, 305, 306) if pair else (304, 305)):
                 out, ocfg, oact = run(arch, params, img, '%s:%d' % (layer, cfg), key)
                 if ocfg.get(layer) != cfg:
                     print('%s %s cfg %d: NOT TAKEN (ran %s)' % (model, layer, cfg, ocfg.get(layer)))
@@ -63,7 +66,7 @@ if __name__ == '__main__':
                 err = float(np.abs(oact - ract).max()) / scale
                 lab = float((out['pred'] != ref['pred']).mean())
                 ok = err <= 2e-6 and np.isfinite(oact).all()
-                print('%-8s %dx%dx%d %-8s cfg %d vs 300: max |d| %.2e of the scale, labels differ %.5f %%: %s' % (
+                print('%-8s %dx%dx%d %-8s cfg %d vs F(2x2): max |d| %.2e of the scale, labels differ %.5f %%: %s' % (
                     model, n, H, W, layer, cfg, err, 100 * lab, 'ok' if ok else 'FAIL'))
                 bad += 0 if ok else 1
             got = [c for c in (304, 305, 306) if res.get(c) is not None]

@@ -274,7 +274,7 @@ int override_cfg(const std::string &layer) {
 // type reuse the entry (e.g. the long-axis models at 176x208).
 struct Tuned { int ks, stride, cin, cout, cfg, alt, alt2, alt3 = -1; };   // alt.. (or -1): the first of the four whose tiles divide the map wins
 const Tuned g_tuned_large[] = {
-    {3, 1, 16, 16, 11, -1, -1}, {3, 2, 16, 32, 120, 123, -1},  {3, 1, 32, 32, 301, -1, -1},
+    {3, 1, 16, 16, 11, -1, -1}, {3, 2, 16, 32, 120, 123, -1},  {3, 1, 32, 32, 307, 301, -1},
     {3, 2, 32, 64, 124, 123, 142, 145},  {3, 1, 64, 64, 304, 300, -1},  {3, 2, 64, 128, 124, 123, 142, 145},
     {3, 1, 128, 128, 304, 300, -1},  {3, 2, 128, 256, 124, 123, 142, 145}, {3, 1, 256, 256, 300, -1, -1},
 };      // r03: 13x16 tiles (145) divide the 208x256 pyramid (52x64, 26x32, 13x16: conv2_0 112 -> 86 us, conv3_0 / conv4_0 -6 / -7 at N = 64);
@@ -333,7 +333,9 @@ bool cfg_valid(const ConvConfig &c, int ks, int stride, int c0, int c1, int cout
         }
         if (is_wino24(c)) {                           // F(2x4,3x3), kernels_wino24.hip: 64-channel groups, K >= 64 (the MFMA-bound layers; no frame map)
             static const bool off24 = getenv("UKBB_NO_WINOGRAD24") != nullptr;
-            if (off24 || cout % 64 || c0 + c1 < 64) return false;
+            if (off24) return false;
+            if (c.wm == 2) { if (cout != 32) return false; }   // 32-channel items (307): the layers with exactly 32 output channels (never the ConvLSTM gates: frame map)
+            else if (cout % 64 || c0 + c1 < 64) return false;
         }
         return !off && !fused_first && ks == 3 && stride == 1 && cout % (16 * c.wm) == 0 && c0 % 16 == 0 && c1 % 16 == 0;
     }
@@ -464,6 +466,9 @@ int choose_cfg_raw(const std::string &layer, int ks, int stride, int c0, int c1,
                 for (int k = 0; k < 4; ++k) {
                     ConvConfig cc;
                     if (cand[k] < 0 || find_cfg(cand[k], cc) || !cfg_valid(cc, ks, stride, c0, c1, cout) || !tile_fit_ok(cc, Ho, Wo)) continue;
+                    // F(2x4) on 32-channel layers pays only where its 8 x 32 regions fill the map (U-Net 128 x 128: 177 -> 150 us; FCN 96 x 104: 81 %
+                    // fill against 100 % of the 16 x 8 F(2x2) regions, no gain)
+                    if (cand[k] == 307 && (Ho % 8 || Wo % 32)) continue;
                     if (Ho % cc.th == 0 && Wo % cc.tw == 0) return cand[k];      // tiles divide the map: straight-line producer applies
                     if (first_ok < 0) first_ok = cand[k];
                 }
@@ -475,6 +480,7 @@ int choose_cfg_raw(const std::string &layer, int ks, int stride, int c0, int c1,
         // skip-concat conv of the U-Net's level 1 (network_ao.py:51-53, 32 + 32 -> 32): the two-source Winograd kernel in its
         // 32-channel form (r02 sweep at 256x256, N = 100: 345 us against 544 for the best direct tiling)
         ConvConfig cw;
+        if (Ho % 8 == 0 && Wo % 32 == 0 && find_cfg(307, cw) == 0 && cfg_valid(cw, ks, stride, c0, c1, cout)) return 307;   // F(2x4): 321 -> 252 us (r04)
         if (find_cfg(301, cw) == 0 && cfg_valid(cw, ks, stride, c0, c1, cout) && tile_fit_ok(cw, Ho, Wo)) return 301;
     }
     double best = 1e300;
@@ -526,7 +532,7 @@ int ensure_packed(ukbb_fcn_handle *h, int layer, const ConvConfig &c, const floa
     snprintf(key, sizeof key, "%s/pk%s_mb%d_kc%d_g%d", L.name.c_str(), bfpk ? "bf16" : w24 ? "wino24" : c.pc == 4 ? "wino" : "", c.mb, c.kc, c.wm * c.cb);
     if (!dev_ptr(h, key)) {
         std::vector<float> pk(w24 ? (size_t)24 * L.cin * L.cout : c.pc == 4 ? (size_t)16 * L.cin * L.cout : (size_t)L.ks * L.ks * L.cin * coutp);
-        if (w24) pack_wino24_weights(L.w.data(), L.cin, L.cout, pk.data());
+        if (w24) pack_wino24_weights(L.w.data(), L.cin, L.cout, c.wm, pk.data());
         else if (c.pc == 4) pack_wino_weights(L.w.data(), L.cin, L.cout, c.wm, pk.data());
         else if (bfpk && coutp != L.cout) {           // zero rows up to the MFMA's 32
             std::vector<float> wp((size_t)L.ks * L.ks * L.cin * coutp, 0.f);

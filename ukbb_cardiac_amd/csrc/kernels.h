@@ -154,10 +154,11 @@ hipError_t launch_wino(const ConvArgs &a, int ncb /*16-channel blocks per item: 
                        hipStream_t s);
 size_t pack_wino_weights(const float *w /*[3][3][cin][cout] folded*/, int cin, int cout, int ncb, float *dst /*16*cin*cout*/);
 int wino_lds_bytes();
-// Winograd F(2x4,3x3) (kernels_wino24.hip): 64-channel output groups, 8 x 32- or 8 x 16-pixel regions, ConvConfig::pc == 4, ids 304 / 305 / 306 (306: 8 x 16 over image pairs)
+// Winograd F(2x4,3x3) (kernels_wino24.hip): 64-channel output groups, 8 x 32- or 8 x 16-pixel regions, ConvConfig::pc == 4, ids 304 / 305 / 306 / 307 (306: 8 x 16 over image pairs; 307: 32-channel items)
 inline bool is_wino24(const ConvConfig &c) { return c.pc == 4 && c.id >= 304; }
-hipError_t launch_wino24(const ConvArgs &a, int tile_cols /*32 | 16*/, int pair /*id 306: image pairs with seam regions, Ho % 8 == 4*/, hipStream_t s);
-size_t pack_wino24_weights(const float *w /*[3][3][cin][cout] folded*/, int cin, int cout, float *dst /*24*cin*cout*/);
+hipError_t launch_wino24(const ConvArgs &a, int tile_cols /*32 | 16*/, int pair /*id 306: image pairs with seam regions, Ho % 8 == 4*/, int ncb /*4 | 2 (id 307)*/,
+                         hipStream_t s);
+size_t pack_wino24_weights(const float *w /*[3][3][cin][cout] folded*/, int cin, int cout, int ncb, float *dst /*24*cin*cout*/);
 int wino24_lds_bytes(int tbw, int pair);
 
 // ---------------------------------------------------------------------------

@@ -1353,7 +1353,8 @@ static const ConvConfig g_cfgs[] = {UKBB_CONV_CONFIGS(UKBB_CFG_ENTRY) UKBB_PC_CO
                                     {303, 3, 1, 16, 16, 8, 16, 2, 1, 1, 125184, 4, "winogradF2x2_3x3_t16x8_kc16_cout32"},
                                     {304, 3, 1, 16, 8, 32, 16, 4, 1, 1, 152960, 4, "winogradF2x4_3x3_t8x32_kc16_cout64"},
                                     {305, 3, 1, 16, 8, 16, 16, 4, 1, 1, 87808, 4, "winogradF2x4_3x3_t8x16_kc16_cout64"},
-                                    {306, 3, 1, 16, 8, 16, 16, 4, 1, 1, 95488, 4, "winogradF2x4_3x3_t8x16pair_kc16_cout64"}};
+                                    {306, 3, 1, 16, 8, 16, 16, 4, 1, 1, 95488, 4, "winogradF2x4_3x3_t8x16pair_kc16_cout64"},
+                                    {307, 3, 1, 16, 8, 32, 16, 2, 1, 1, 152960, 4, "winogradF2x4_3x3_t8x32_kc16_cout32"}};
 
 static constexpr int N_BASE_CFGS = (int)(sizeof(g_cfgs) / sizeof(g_cfgs[0]));
 int num_conv_configs() { return N_BASE_CFGS + num_pk16_configs() + num_ws_configs(); }
@@ -1416,7 +1417,7 @@ hipError_t launch_conv(int cfg_id, const ConvArgs &a_in, hipStream_t s) {
     for (const auto &e : g_cfgs) if (e.id == cfg_id) c = &e;
     if (!c) return hipErrorInvalidValue;
     const int group = c->mb * c->cb * c->wm;
-    if (c->pc == 4) return is_wino24(*c) ? launch_wino24(a, c->tw, c->id == 306, s) : launch_wino(a, c->wm, c->th / 2, s);
+    if (c->pc == 4) return is_wino24(*c) ? launch_wino24(a, c->tw, c->id == 306, c->wm, s) : launch_wino(a, c->wm, c->th / 2, s);
     if (a.in0_map) return hipErrorInvalidValue;       // image remapping exists in the Winograd kernel only
     if (c->pc == 2) {
         if (!a.first_w || !a.first_b || a.Cout != group) return hipErrorInvalidValue;

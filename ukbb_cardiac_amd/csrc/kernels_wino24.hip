@@ -107,9 +107,13 @@ __device__ unsigned long long g_w24stamps[8];
 #define STAMP(v)
 #define STAMP_DO(...)
 #endif
-template <int TBW, bool PAIR>
+// NCB = 16-channel blocks per item: 4 (64 output channels, consumer wave w = block w, all tile blocks) or 2 (32 output channels, TBW = 2 only:
+// wave w = block w & 1 of tile block w >> 1 -- layers with 32 output channels, which are bound by the producers in the F(2x2) kernel)
+template <int TBW, bool PAIR, int NCB>
 __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
     using G = W24<TBW, PAIR>;
+    static_assert(NCB == 4 || (NCB == 2 && TBW == 2 && !PAIR), "32-channel items come with 8 x 32-pixel regions");
+    constexpr int CTB = NCB == 2 ? 1 : TBW;             // tile blocks per consumer wave
     constexpr int NT = G::NT, TRX = G::TRX, WIH = G::WIH, WIW = G::WIW, WHP = G::WHP, NITX = G::NITX, RS = G::RS, XSZ = G::XSZ, VSZ = G::VSZ, L_XS = G::L_XS, L_VS = G::L_VS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int cin = a.C0 + a.C1;
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
     const int regs_y = PAIR ? 2 * pm + 1 : (a.Ho + 2 * TRY - 1) / (2 * TRY);
     const int regions = regs_x * regs_y;
     const int per_group = (PAIR ? (a.N + 1) / 2 : a.N) * regions;
-    const int nitems = per_group * (a.Cout / 64);
+    const int nitems = per_group * (a.Cout / (16 * NCB));
     const int my_items = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int nstages = my_items * nchunk;
     const bool producer = __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256;
@@ -310,28 +314,30 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
         }
         STAMP_DO(if (threadIdx.x == 256) { atomicAdd(g_w24stamps + 0, pw); atomicAdd(g_w24stamps + 1, px_); atomicAdd(g_w24stamps + 2, pl); atomicAdd(g_w24stamps + 3, (unsigned long long)nstages); })
     } else {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;      // consumer wave = Cout block within the item
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        const int wave = NCB == 4 ? wid : (wid & 1);                     // Cout block within the item
+        const int tbk = NCB == 4 ? 0 : (wid >> 1);                       // NCB = 2: this wave's tile block
         const int t16 = lane & 15, g = lane >> 4;
         __syncthreads();                                // barrier X
         int s = 0;
-        constexpr int AD = TBW == 2 ? 4 : 8;            // A-fragment queue depth (k positions; 256 / 128 MFMA cycles each)
+        constexpr int AD = CTB == 2 ? 4 : 8;            // A-fragment queue depth (k positions; 256 / 128 MFMA cycles each)
         f32x4 aq[AD];
         STAMP_DO(unsigned long long cw = 0, cc = 0, ce = 0, sc0, sc1, sc2, sc3;)
         // this lane's B operand of tile block tb: tile t = 16 tb + t16, quad g -> slot g ^ (3 * ((t >> 3) & 1))
-        const int vofs0 = t16 * WKC + 4 * (g ^ (3 * ((t16 >> 3) & 1)));
-        const int vofs1 = (TBW == 2 ? 16 + t16 : t16) * WKC + 4 * (g ^ (3 * ((t16 >> 3) & 1)));
+        const int vofs0 = (16 * tbk + t16) * WKC + 4 * (g ^ (3 * ((t16 >> 3) & 1)));
+        const int vofs1 = (CTB == 2 ? 16 + t16 : t16) * WKC + 4 * (g ^ (3 * ((t16 >> 3) & 1)));
         for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
             const int grp = item / per_group, rest = item - grp * per_group;
             const int n = rest / regions;               // PAIR: pair index
             const int r = rest - n * regions;
             const int ry = r / regs_x, rx = r - ry * regs_x;
-            const int co = (grp * 4 + wave) * 16 + 4 * g;
+            const int co = (grp * NCB + wave) * 16 + 4 * g;
             const f32x4 bias = ld4(a.bias + co);
             // the folded-BN bias rides through the output transform as M[1][1] (k = 7): A_y^T column 1 and A_x^T column 1 are all ones
-            f32x4 acc[NK][TBW];
-            const float *wbase = a.wpk + ((size_t)grp * nchunk * 4 + wave) * (NK * 64 * 4) + lane * 4;
+            f32x4 acc[NK][CTB];
+            const float *wbase = a.wpk + ((size_t)grp * nchunk * NCB + wave) * (NK * 64 * 4) + lane * 4;
             const int item_n = item + (int)gridDim.x < nitems ? item + (int)gridDim.x : item;
-            const float *wnext = a.wpk + ((size_t)(item_n / per_group) * nchunk * 4 + wave) * (NK * 64 * 4) + lane * 4;
+            const float *wnext = a.wpk + ((size_t)(item_n / per_group) * nchunk * NCB + wave) * (NK * 64 * 4) + lane * 4;
             if (item == (int)blockIdx.x) {
 #pragma unroll
                 for (int i = 0; i < AD; ++i) aq[i] = ld4(wbase + i * 64 * 4);
@@ -342,9 +348,9 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
                 __syncthreads();                        // barrier #s
                 STAMP(sc1)
                 const float *vs = lds + L_VS + (s & 1) * VSZ;
-                const float *wp = wbase + (size_t)ch * 4 * (NK * 64 * 4);
-                const float *wn = ch + 1 < nchunk ? wp + 4 * (NK * 64 * 4) : wnext;
-                if constexpr (TBW == 1) {
+                const float *wp = wbase + (size_t)ch * NCB * (NK * 64 * 4);
+                const float *wn = ch + 1 < nchunk ? wp + NCB * (NK * 64 * 4) : wnext;
+                if constexpr (CTB == 1) {
                     // one tile block per wave: the four MFMAs of a position form a dependent chain, so two positions run interleaved
                     // (stamps of the first build: 4.7 k cycles per stage for 96 MFMAs = 3.1 k)
                     constexpr int BD = 2, BRG = BD + 1;             // B pairs in flight ahead of the MFMAs, ring size
@@ -377,26 +383,26 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
                     });
                 }
                 f32x4 b0[2], b1[2];
-                if constexpr (TBW == 2) { b0[0] = ld4(vs + vofs0); b1[0] = ld4(vs + vofs1); }
-                if constexpr (TBW == 2) unroll_k<NK>([&](auto kc) {
+                if constexpr (CTB == 2) { b0[0] = ld4(vs + vofs0); b1[0] = ld4(vs + vofs1); }
+                if constexpr (CTB == 2) unroll_k<NK>([&](auto kc) {
                     constexpr int k = decltype(kc)::value;
                     const f32x4 av = aq[k % AD];
                     if constexpr (k + AD < NK) aq[k % AD] = ld4(wp + (k + AD) * 64 * 4);
                     else                       aq[k % AD] = ld4(wn + (k + AD - NK) * 64 * 4);
                     if constexpr (k + 1 < NK) {         // B operands of k+1 in flight during the MFMAs of k
                         b0[(k + 1) & 1] = ld4(vs + (k + 1) * NT * WKC + vofs0);
-                        if constexpr (TBW == 2) b1[(k + 1) & 1] = ld4(vs + (k + 1) * NT * WKC + vofs1);
+                        if constexpr (CTB == 2) b1[(k + 1) & 1] = ld4(vs + (k + 1) * NT * WKC + vofs1);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (FIRST) {
                         const f32x4 c0v = k == 7 ? bias : f32x4{0.f, 0.f, 0.f, 0.f};
                         acc[k][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], b0[k & 1][0], c0v, 0, 0, 0);
-                        if constexpr (TBW == 2) acc[k][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], b1[k & 1][0], c0v, 0, 0, 0);
+                        if constexpr (CTB == 2) acc[k][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], b1[k & 1][0], c0v, 0, 0, 0);
                     }
 #pragma unroll
                     for (int i = FIRST ? 1 : 0; i < 4; ++i) {
                         acc[k][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], b0[k & 1][i], acc[k][0], 0, 0, 0);
-                        if constexpr (TBW == 2) acc[k][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], b1[k & 1][i], acc[k][1], 0, 0, 0);
+                        if constexpr (CTB == 2) acc[k][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], b1[k & 1][i], acc[k][1], 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 });
@@ -412,8 +418,8 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
             asm volatile("s_nop 15" ::: "memory");        // MFMA -> VALU wait states before the inline-asm packed adds (kernels_wino.hip)
             const f32x2 c2 = {2.f, 2.f}, c4 = {4.f, 4.f}, c8 = {8.f, 8.f};
 #pragma unroll
-            for (int tb = 0; tb < TBW; ++tb) {
-                const int q = tb * 16 + t16;
+            for (int tb = 0; tb < CTB; ++tb) {
+                const int q = (tb + tbk) * 16 + t16;
                 int oy = (ry * TRY + q / TRX) * 2, on = n;
                 const int ox = (rx * TRX + q % TRX) * 4;
                 if constexpr (PAIR) {
@@ -462,23 +468,23 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
 
 int wino24_lds_bytes(int tbw, int pair) { return (tbw == 2 ? W24<2>::LDS_FLOATS : pair ? W24<1, true>::LDS_FLOATS : W24<1>::LDS_FLOATS) * 4; }
 
-template <int TBW, bool PAIR>
+template <int TBW, bool PAIR, int NCB>
 static hipError_t launch_wino24_t(const ConvArgs &a, hipStream_t s) {
     using G = W24<TBW, PAIR>;
     const int n_cu = device_cu_count();
     static OncePerDevice lds_ok;
-    hipError_t e = allow_dynamic_lds(lds_ok, reinterpret_cast<const void *>(wino24_pc_kernel<TBW, PAIR>), G::LDS_FLOATS * 4);
+    hipError_t e = allow_dynamic_lds(lds_ok, reinterpret_cast<const void *>(wino24_pc_kernel<TBW, PAIR, NCB>), G::LDS_FLOATS * 4);
     if (e != hipSuccess) return e;
     const int regs_x = (a.Wo + 4 * G::TRX - 1) / (4 * G::TRX);
     const long long per_image_or_pair = PAIR ? (long long)(2 * (a.Ho / 8) + 1) * ((a.N + 1) / 2) : (long long)((a.Ho + 2 * TRY - 1) / (2 * TRY)) * a.N;
-    const long long nitems = per_image_or_pair * regs_x * (a.Cout / 64);
+    const long long nitems = per_image_or_pair * regs_x * (a.Cout / (16 * NCB));
     dim3 grid((unsigned)(nitems < n_cu ? nitems : n_cu));
 #ifdef UKBB_WINO_STAMPS
     const bool on = getenv("UKBB_STAMPS") != nullptr;
     unsigned long long z[8] = {0};
     if (on) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_w24stamps), z, 64);
 #endif
-    hipLaunchKernelGGL((wino24_pc_kernel<TBW, PAIR>), grid, dim3(512), G::LDS_FLOATS * 4, s, a);
+    hipLaunchKernelGGL((wino24_pc_kernel<TBW, PAIR, NCB>), grid, dim3(512), G::LDS_FLOATS * 4, s, a);
 #ifdef UKBB_WINO_STAMPS
     if (on) {
         unsigned long long h[8];
@@ -492,29 +498,31 @@ static hipError_t launch_wino24_t(const ConvArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// tile_cols: 32 | 16 (regions of 8 x 32 / 8 x 16 pixels); pair: images in pairs with seam regions (16 only, Ho % 8 == 4)
-hipError_t launch_wino24(const ConvArgs &a, int tile_cols, int pair, hipStream_t s) {
-    if (a.Cout % 64 || (a.C0 + a.C1) % WKC || a.C0 % WKC || a.up2 || a.in0_map) return hipErrorInvalidValue;
-    if (pair) return (tile_cols == 16 && a.Ho % 8 == 4 && a.Ho == a.H) ? launch_wino24_t<1, true>(a, s) : hipErrorInvalidValue;
-    return tile_cols == 32 ? launch_wino24_t<2, false>(a, s) : tile_cols == 16 ? launch_wino24_t<1, false>(a, s) : hipErrorInvalidValue;
+// tile_cols: 32 | 16 (regions of 8 x 32 / 8 x 16 pixels); pair: images in pairs with seam regions (16 only, Ho % 8 == 4); ncb: 4 | 2 (2: tile_cols 32)
+hipError_t launch_wino24(const ConvArgs &a, int tile_cols, int pair, int ncb, hipStream_t s) {
+    if (a.Cout % (16 * ncb) || (a.C0 + a.C1) % WKC || a.C0 % WKC || a.up2 || a.in0_map) return hipErrorInvalidValue;
+    if (ncb == 2) return (tile_cols == 32 && !pair) ? launch_wino24_t<2, false, 2>(a, s) : hipErrorInvalidValue;
+    if (ncb != 4) return hipErrorInvalidValue;
+    if (pair) return (tile_cols == 16 && a.Ho % 8 == 4 && a.Ho == a.H) ? launch_wino24_t<1, true, 4>(a, s) : hipErrorInvalidValue;
+    return tile_cols == 32 ? launch_wino24_t<2, false, 4>(a, s) : tile_cols == 16 ? launch_wino24_t<1, false, 4>(a, s) : hipErrorInvalidValue;
 }
 
-size_t pack_wino24_weights(const float *w, int cin, int cout, float *dst) {
+size_t pack_wino24_weights(const float *w, int cin, int cout, int ncb, float *dst) {
     // w: folded [3][3][cin][cout].  U = G_y g G_x^T per (ci, co); G_y = F(2,3) rows, G_x = F(4,3) columns.
-    // dst[group of 64][chunk][cbl 0..3][k = 6 i + j][lane][s]:  lane = (g << 4) | m, ci = chunk*16 + 4*g + s, co = (group*4 + cbl)*16 + m
+    // dst[group of 16 ncb][chunk][cbl 0..ncb-1][k = 6 i + j][lane][s]:  lane = (g << 4) | m, ci = chunk*16 + 4*g + s, co = (group*ncb + cbl)*16 + m
     static const double GY[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
     static const double GX[6][3] = {{1.0 / 4, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                                     {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
     const int nchunk = cin / WKC;
     size_t o = 0;
-    for (int grp = 0; grp < cout / 64; ++grp)
+    for (int grp = 0; grp < cout / (16 * ncb); ++grp)
         for (int ch = 0; ch < nchunk; ++ch)
-            for (int cbl = 0; cbl < 4; ++cbl)
+            for (int cbl = 0; cbl < ncb; ++cbl)
                 for (int k = 0; k < NK; ++k)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int s = 0; s < 4; ++s) {
                             const int m = lane & 15, g = lane >> 4;
-                            const int ci = ch * WKC + 4 * g + s, co = (grp * 4 + cbl) * 16 + m;
+                            const int ci = ch * WKC + 4 * g + s, co = (grp * ncb + cbl) * 16 + m;
                             const int i = k / 6, j = k % 6;
                             double u = 0.0;
                             for (int p = 0; p < 3; ++p)
