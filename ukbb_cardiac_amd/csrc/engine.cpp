@@ -334,8 +334,8 @@ bool cfg_valid(const ConvConfig &c, int ks, int stride, int c0, int c1, int cout
         if (is_wino24(c)) {                           // F(2x4,3x3), kernels_wino24.hip: 64-channel groups, K >= 64 (the MFMA-bound layers; no frame map)
             static const bool off24 = getenv("UKBB_NO_WINOGRAD24") != nullptr;
             if (off24) return false;
-            if (c.wm == 2) { if (cout != 32) return false; }   // 32-channel items (307): the layers with exactly 32 output channels (never the ConvLSTM gates: frame map)
-            else if (cout % 64 || c0 + c1 < 64) return false;
+            if (c.wm == 2) { if (cout != 32) return false; }   // 32-channel items (307): the layers with exactly 32 output channels
+            else if (cout % 64 || c0 + c1 < 32) return false;   // K = 32: the ConvLSTM gate convs (16 + 16 -> 64)
         }
         return !off && !fused_first && ks == 3 && stride == 1 && cout % (16 * c.wm) == 0 && c0 % 16 == 0 && c1 % 16 == 0;
     }

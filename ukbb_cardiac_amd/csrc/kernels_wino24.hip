@@ -149,7 +149,7 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
         }
         int cur_cs = 0;
         u32x4 xr[NITX];
-        int l_ch = 0, l_item = blockIdx.x, l_n = 0, l_iy0 = 0, l_ix0 = 0;
+        int l_ch = 0, l_item = blockIdx.x, l_n = 0, l_n0 = 0, l_iy0 = 0, l_ix0 = 0;
         bool l_seam = false;                            // PAIR: the cursor's region is a seam region
         auto locate = [&]() {
             const int rest = l_item % per_group;
@@ -162,6 +162,9 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
                 if (ry <= pm) l_n = 2 * l_n;                                     // image A (the seam's raw tile starts in A)
                 else { l_n = 2 * l_n + 1; l_iy0 = 4 + (ry - pm - 1) * 8 - 1; }   // image B, regions from its row 4
             }
+            // ConvLSTM windows index shared feature frames (source 0 only).  readfirstlane: the loaded index arrives in a VGPR, and without it the
+            // buffer descriptors built from it count as divergent -- every halo load became a waterfall loop (kernels_wino.hip, r02)
+            l_n0 = (!PAIR && a.in0_map) ? __builtin_amdgcn_readfirstlane(a.in0_map[l_n]) : l_n;
         };
         locate();
         // The in-image test and the byte offsets of a thread's pieces depend on the region and on the source's channel count only: they are
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
                     vo[it] = ok ? pre[it] : 0x80000000u;    // out of range -> zeros
                 }
             }
-            src += ((long long)(l_n * a.H + l_iy0) * a.W + l_ix0) * cs;   // may point before the tensor; masked lanes never use it
+            src += ((long long)((from0 ? l_n0 : l_n) * a.H + l_iy0) * a.W + l_ix0) * cs;   // may point before the tensor; masked lanes never use it
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
             for (int it = 0; it < NITX; ++it) xr[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo[it], 0, 0);
@@ -500,7 +503,7 @@ static hipError_t launch_wino24_t(const ConvArgs &a, hipStream_t s) {
 
 // tile_cols: 32 | 16 (regions of 8 x 32 / 8 x 16 pixels); pair: images in pairs with seam regions (16 only, Ho % 8 == 4); ncb: 4 | 2 (2: tile_cols 32)
 hipError_t launch_wino24(const ConvArgs &a, int tile_cols, int pair, int ncb, hipStream_t s) {
-    if (a.Cout % (16 * ncb) || (a.C0 + a.C1) % WKC || a.C0 % WKC || a.up2 || a.in0_map) return hipErrorInvalidValue;
+    if (a.Cout % (16 * ncb) || (a.C0 + a.C1) % WKC || a.C0 % WKC || a.up2 || (a.in0_map && pair)) return hipErrorInvalidValue;
     if (ncb == 2) return (tile_cols == 32 && !pair) ? launch_wino24_t<2, false, 2>(a, s) : hipErrorInvalidValue;
     if (ncb != 4) return hipErrorInvalidValue;
     if (pair) return (tile_cols == 16 && a.Ho % 8 == 4 && a.Ho == a.H) ? launch_wino24_t<1, true, 4>(a, s) : hipErrorInvalidValue;
