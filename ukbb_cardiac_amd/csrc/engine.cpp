@@ -276,7 +276,7 @@ struct Tuned { int ks, stride, cin, cout, cfg, alt, alt2, alt3 = -1; };   // alt
 const Tuned g_tuned_large[] = {
     {3, 1, 16, 16, 11, -1, -1}, {3, 2, 16, 32, 120, 123, -1},  {3, 1, 32, 32, 307, 301, -1},
     {3, 2, 32, 64, 124, 123, 142, 145},  {3, 1, 64, 64, 304, 300, -1},  {3, 2, 64, 128, 124, 123, 142, 145},
-    {3, 1, 128, 128, 304, 300, -1},  {3, 2, 128, 256, 124, 123, 142, 145}, {3, 1, 256, 256, 300, -1, -1},
+    {3, 1, 128, 128, 304, 300, -1},  {3, 2, 128, 256, 124, 123, 142, 145}, {3, 1, 256, 256, 304, 305, 300},
 };      // r03: 13x16 tiles (145) divide the 208x256 pyramid (52x64, 26x32, 13x16: conv2_0 112 -> 86 us, conv3_0 / conv4_0 -6 / -7 at N = 64);
         // r02: the stride-2 layers moved to the producer/consumer kernel once its loads ran two stages ahead (profiles/r02_notes.md);
         // its straight-line producer needs tiles that divide the map: 12x13 tiles for the 192x208 pyramid, 8x16 (123) for the
@@ -298,7 +298,8 @@ bool tile_fit_ok(const ConvConfig &c, int Ho, int Wo) {
     const int th = c.th, tw = c.tw;
     const double covered = (double)((Ho + th - 1) / th * th) * ((Wo + tw - 1) / tw * tw);
     // Winograd kept its lead over the direct tilings down to 61 % region fill (12x13 maps, r01 sweep)
-    return (double)Ho * Wo >= (c.pc == 4 ? 0.5 : 0.8) * covered;
+    // F(2x4) regions: below 75 % fill the F(2x2) kernel with its half regions issues no more MFMAs (12 x 13 maps: 61 % against 81 %)
+    return (double)Ho * Wo >= (is_wino24(c) ? 0.75 : c.pc == 4 ? 0.5 : 0.8) * covered;
 }
 // Fallback preference (small tiles / high occupancy won everywhere in the sweep).
 const int g_pref[] = {4, 5, 18, 3, 11, 7, 31, 23, 22, 29, 27, 26};
@@ -391,9 +392,11 @@ int pick_wino24(int id, int ks, int stride, int c0, int c1, int cout, int Ho, in
         if (find_cfg(cand, c) || !cfg_valid(c, ks, stride, c0, c1, cout) || !tile_fit_ok(c, Ho, Wo)) continue;
         const long long items = (long long)N * ((Ho + c.th - 1) / c.th) * ((Wo + c.tw - 1) / c.tw) * (cout / 64);
         const long long rounds = (items + cus - 1) / cus;
-        double eff = (double)items / (double)(rounds * cus);
+        // makespan in units of an 8 x 16 region's work (an 8 x 32 item is two): the shorter wins -- that counts the padding columns of the
+        // wider regions as well as the idle CUs of the last round
+        double eff = 1.0 / (double)(rounds * (c.tw / 16));
         if (N <= SMALL_BATCH) eff = cand == 305 ? 2.0 : 1.0;          // fewer items than CUs either way: more of them
-        if (eff > best_eff + 1e-9) { best_eff = eff; best = cand; }
+        if (eff > best_eff + 1e-12) { best_eff = eff; best = cand; }
     }
     return best;
 }
