@@ -298,8 +298,8 @@ bool tile_fit_ok(const ConvConfig &c, int Ho, int Wo) {
     const int th = c.th, tw = c.tw;
     const double covered = (double)((Ho + th - 1) / th * th) * ((Wo + tw - 1) / tw * tw);
     // Winograd kept its lead over the direct tilings down to 61 % region fill (12x13 maps, r01 sweep)
-    // F(2x4) regions: below 75 % fill the F(2x2) kernel with its half regions issues no more MFMAs (12 x 13 maps: 61 % against 81 %)
-    return (double)Ho * Wo >= (is_wino24(c) ? 0.75 : c.pc == 4 ? 0.5 : 0.8) * covered;
+    // F(2x4) regions: at 61 % fill (12 x 13 maps) the F(2x2) kernel with its half regions (81 %) is as fast, at 74 % (44 x 52, 22 x 26) F(2x4) still wins by 2 %
+    return (double)Ho * Wo >= (is_wino24(c) ? 0.7 : c.pc == 4 ? 0.5 : 0.8) * covered;
 }
 // Fallback preference (small tiles / high occupancy won everywhere in the sweep).
 const int g_pref[] = {4, 5, 18, 3, 11, 7, 31, 23, 22, 29, 27, 26};
