@@ -11,11 +11,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _tool(name, *args):
+def _tool(name, *args, **extra_env):
     env = dict(os.environ)
     env['PYTHONPATH'] = ROOT + os.pathsep + env.get('PYTHONPATH', '')
     for k in ('UKBB_CONV_CFG', 'UKBB_NO_FUSE_TAIL', 'UKBB_NO_FUSE_STEM'):
         env.pop(k, None)
+    env.update(extra_env)
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', name)] + [str(a) for a in args], env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == 'OK', r.stdout[-3000:]
@@ -35,6 +36,13 @@ def test_weight_stationary_tilings_match_the_tile_per_workgroup_kernels():
     out = _tool('check_ws.py', 2, 64, 96, 'up3_0:420,421,422,423', 'conv4_1:421,423', 'conv3_1:421', 'up2_0:420,422', 'conv2_1:420')
     assert 'NOT TAKEN' not in out
     _tool('check_ws.py', 3, 256, 256, 'up3_0:420,422', 'conv4_1:422')
+    # under the XCD-contiguous tile order (maps >= 128 x 128, forced here on every map) the ring-streamed form took its
+    # workgroup's round count from the wrong worker id and the four-wave tilings 420 / 421 dropped their last tiles whenever
+    # ntiles % nworkers fell between the two ids.  Batches chosen so that the tile counts sweep the remainders.
+    for n in (1, 2, 3, 5, 7):
+        out = _tool('check_ws.py', n, 64, 96, 'up3_0:420,421,422,423', 'conv3_1:421', 'up2_0:420', 'conv2_1:420,400', UKBB_WS_XCD_LOCAL='1')
+        assert 'NOT TAKEN' not in out
+    _tool('check_ws.py', 3, 256, 256, 'conv1_1:420,421,401', 'up1_0:420', UKBB_WS_XCD_LOCAL='1')
 
 
 def test_fused_tail_matches_the_unfused_plan():

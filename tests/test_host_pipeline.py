@@ -510,6 +510,47 @@ def test_gunzip_agrees_with_zlib_on_corrupted_and_random_streams():
             assert _labelgz.lib.ukbb_fcn_gzip_crc(init, d.ctypes.data, n) == zlib.crc32(d.tobytes(), init)
 
 
+def test_gunzip_never_writes_behind_the_capacity_on_long_matches():
+    """the fast loop's slack check has to hold for the position AFTER a match.  Streams of back-to-back 258-byte
+    matches whose content is longer than the capacity (-> UKBB_ENOMEM, nothing stored behind dst + cap), exact-size buffers followed
+    by zero padding or a second member, and every capacity around the end of a run.  The buffers here are exactly cap (+ 1 canary)
+    bytes, so under the address sanitiser (test_label_gzip_clean_under_address_and_ub_sanitizers) any overshoot aborts."""
+    rng = np.random.default_rng(11)
+    head = rng.integers(0, 256, 2000, dtype=np.uint8).tobytes()
+    for run in (bytes(200000), b'\x01\x02' * 100000, b'abcd' * 50000, rng.integers(0, 256, 9, dtype=np.uint8).tobytes() * 22000,
+                rng.integers(0, 256, 300, dtype=np.uint8).tobytes() * 700):
+        raw = head + run
+        for level in (1, 6, 9):
+            g = _deflate(raw, level)
+            for cap in (0, 1, 319, 320, 321, 600, 2000, 2322, 2322 + 258, 5000, len(raw) - 259, len(raw) - 17, len(raw) - 1):
+                assert _gunzip(g, cap)[0] == -4, (len(run), level, cap)
+            for extra in (b'', bytes(64), bytes(1000)):
+                assert _gunzip(g + extra, len(raw)) == (len(raw), raw)
+            # second member: the first one ends exactly at its share of the buffer, the second does not fit / fits exactly
+            g2 = _deflate(run[:70000], level)
+            assert _gunzip(g + g2, len(raw) + 70000) == (len(raw) + 70000, raw + run[:70000])
+            for short in (1, 16, 200, 320, 69999):
+                assert _gunzip(g + g2, len(raw) + 70000 - short)[0] == -4
+    # a distance code set with ONE code longer than one bit is incomplete in zlib's eyes: refused here too (ADVICE r04, low)
+    import zlib
+    # hand-made dynamic block: HLIT 257, HDIST 1, code-length code gives lengths {0: 1 bit, 2: ... } -- easier: flip bits of a valid
+    # header and require agreement with zlib whenever the stream is accepted (the builder's rule is zlib's)
+    g = bytearray(_deflate(b'abcabcabcabc' * 50 + bytes(range(256)), 9))
+    accepted = 0
+    for pos in range(10, min(len(g), 120)):
+        for bit in range(8):
+            bad = bytes(g[:pos]) + bytes([g[pos] ^ (1 << bit)]) + bytes(g[pos + 1:])
+            r, out = _gunzip(bad, 4096, verify=0)
+            if r >= 0:
+                z = zlib.decompressobj(-15)
+                try:
+                    ref = z.decompress(bad[10:])
+                except zlib.error:
+                    ref = None
+                assert ref is not None and ref[:r] == out, (pos, bit)
+                accepted += 1
+
+
 def test_load_takes_the_whole_file_decoder_and_falls_back_to_zlib(tmp_path):
     """nifti.load of a .nii.gz: same arrays from the whole-file decoder and from the zlib reader (plain, alloc'd, alloc'd with headroom
     = decoded in place, big-endian, scaled); streams the decoder refuses still load -- or raise -- through zlib as before."""
@@ -1015,6 +1056,15 @@ def test_stale_tmp_files_of_dead_writers_are_swept_and_noise_fallback_keeps_the_
     dead.write_bytes(b'x' * 100)
     alive = tmp_path / ('seg_sa.nii.gz.tmp.%d.777' % os.getppid())       # the parent is alive: not ours to touch
     alive.write_bytes(b'y')
+    # names carry a host tag; the pid probe only applies to this host's files, another host's file goes by age alone
+    dead_here = tmp_path / ('seg_sa.nii.gz.tmp.%d.5.%s' % (p.pid, nifti._host_tag()))
+    dead_here.write_bytes(b'z')
+    foreign_young = tmp_path / ('seg_sa.nii.gz.tmp.%d.5.h0123456789' % p.pid)          # "dead" pid here, but a live writer elsewhere
+    foreign_young.write_bytes(b'w')
+    foreign_old = tmp_path / ('seg_sa.nii.gz.tmp.%d.6.h0123456789' % os.getppid())     # "live" pid here, abandoned a day ago elsewhere
+    foreign_old.write_bytes(b'v')
+    os.utime(str(foreign_old), (1.0e9, 1.0e9))
+    assert nifti._tmp_name(str(target)).endswith('.' + nifti._host_tag())
     lab = np.random.default_rng(7).integers(0, 4, size=(48, 40, 3, 4)).astype(np.uint8)
     raws = {}
     try:
@@ -1023,6 +1073,7 @@ def test_stale_tmp_files_of_dead_writers_are_swept_and_noise_fallback_keeps_the_
             nifti.save(lab, str(target), np.eye(4), as_dtype=np.float64)
             raws[mode] = target.read_bytes()
             assert not dead.exists() and alive.exists()
+            assert not dead_here.exists() and foreign_young.exists() and not foreign_old.exists()
     finally:
         nifti.set_label_gzip('small')
     assert raws['small'][:10] == raws['zlib'][:10] == bytes([0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 4, 0xff])

@@ -58,7 +58,9 @@ int build_table(const uint8_t *lens, int n, int kind, uint32_t *tab, int root) {
     long left = 1;                                          // Kraft sum bookkeeping, as a count of unassigned codes
     for (int l = 1; l <= 15; ++l) { left = (left << 1) - count[l]; if (left < 0) return -1; }
     bool incomplete = left > 0;
-    if (incomplete && !(kind == 1 && used <= 1)) return -1; // only "at most one distance code" may be incomplete
+    // only "at most one distance code" may be incomplete, and (as zlib's inflate_table demands) that one code has length 1: a
+    // longer single code would leave second-level slots unwritten
+    if (incomplete && !(kind == 1 && (used == 0 || (used == 1 && count[1] == 1)))) return -1;
     const int nroot = 1 << root;
     if (incomplete || used == 0) for (int i = 0; i < nroot; ++i) tab[i] = mk(0, 0, 1, K_BAD);
     if (used == 0) return 0;                                // block with literals only: any distance code is an error when met
@@ -90,7 +92,7 @@ int build_table(const uint8_t *lens, int n, int kind, uint32_t *tab, int root) {
         for (int p = 0; p < nroot; ++p)
             if (sub_bits[p]) {
                 tab[p] = mk(base, sub_bits[p], root, K_SUB);
-                // an incomplete code cannot reach here (handled above), so every second-level slot gets filled below
+                // an incomplete code cannot reach here (the one allowed has length 1 <= root), so every second-level slot gets filled below
                 base += 1u << sub_bits[p];
             }
     }
@@ -256,6 +258,10 @@ int64_t inflate_stream(Bits &b, uint8_t *const out, uint64_t pos, const uint64_t
         uint8_t *o = out + pos;
         uint8_t *const o_end = out + cap;
         // ---- fast loop: at least 24 input bytes and 320 output bytes of slack, no bounds checks inside ------------------------
+        // Invariant at the top of every iteration: o < o_fast, i.e. more than 320 bytes of output left.  One iteration stores at most
+        // 2 + 2 bytes of literals (the second byte of a one-literal entry is scratch) and one match of <= 258 bytes whose 16-byte
+        // steps overshoot by <= 15: 277 bytes, all inside the buffer.  The check that re-establishes the invariant is made on the
+        // position AFTER the match (o + len), never on the one before it.
         if (b.over == 0) {
             // whole bytes of the careful reader's bit buffer go back to the input: the refill below wants cnt < 64
             const uint8_t *in = b.in - (b.cnt >> 3);
@@ -303,7 +309,7 @@ int64_t inflate_stream(Bits &b, uint8_t *const out, uint64_t pos, const uint64_t
                     const uint32_t dist = (d >> 16) + (uint32_t)((saved >> ((d & 63) - xd)) & ((1u << xd) - 1));
                     if (__builtin_expect(dist > (uint64_t)(o - out), 0)) { err = E_DATA; done = true; break; }
                     // next symbol's entry on its way while the bytes are copied
-                    const bool more = end - in > 24 && o < o_fast;
+                    const bool more = end - in > 24 && o + len < o_fast;     // o + len: where the NEXT iteration starts
                     uint32_t e_next = 0;
                     if (more) { REFILL(); LOOKUP_LL(e_next); }
                     const uint8_t *s = o - dist;

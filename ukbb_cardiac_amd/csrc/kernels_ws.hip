@@ -525,8 +525,11 @@ __device__ __forceinline__ void wr_main(const ConvArgs &a, const int grp, const 
     const int per_xcd_ = nwalk / 8, chunk_ = (nwalk % 8 == 0) ? (walker & 7) * per_xcd_ + (walker >> 3) : walker;
     const int worker = a.xcd_local ? chunk_ * NW + wave : wave * nwalk + walker, nworkers = nwalk * NW;
     const int my = worker < ntiles ? (ntiles - worker + nworkers - 1) / nworkers : 0;
-    // rounds of the whole workgroup = the largest tile count among its waves (wave 0 has it: worker ids grow with the wave index)
-    const int rounds = walker < ntiles ? (ntiles - walker + nworkers - 1) / nworkers : 0;
+    // rounds of the whole workgroup = the largest tile count among its waves = that of wave 0, whose worker id is the smallest of the
+    // workgroup in EITHER numbering (wave-major: walker; xcd_local: chunk_ * NW -- not walker: ADVICE r04, tiles were dropped when
+    // ntiles % nworkers fell between the two)
+    const int w0 = a.xcd_local ? chunk_ * NW : walker;
+    const int rounds = w0 < ntiles ? (ntiles - w0 + nworkers - 1) / nworkers : 0;
     if (rounds == 0) return;                            // uniform over the workgroup
 
     // ---- staging geometry of the activations (as ws_main) ----

@@ -68,14 +68,37 @@ class _GzWriter:
         self._raw.__exit__(*exc)
 
 
+def _host_tag():
+    """Short tag of this host *instance* (hostname + boot id): a pid only means something inside the namespace that issued it."""
+    global _HOST_TAG
+    if _HOST_TAG is None:
+        import hashlib
+        import socket
+        boot = ''
+        try:
+            with open('/proc/sys/kernel/random/boot_id') as f:
+                boot = f.read().strip()
+        except OSError:
+            pass
+        _HOST_TAG = 'h' + hashlib.sha1((socket.gethostname() + '|' + boot).encode()).hexdigest()[:10]
+    return _HOST_TAG
+
+
+_HOST_TAG = None
+_FOREIGN_TMP_MAX_AGE_S = 6 * 3600.0                         # a writer on another host gets this long before its file counts as abandoned
+
+
 def _tmp_name(path):
-    return '%s.tmp.%d.%d' % (path, os.getpid(), threading.get_ident())
+    return '%s.tmp.%d.%d.%s' % (path, os.getpid(), threading.get_ident(), _host_tag())
 
 
 def _sweep_stale_tmp(path):
-    """Remove ``<path>.tmp.<pid>.<thread>`` files whose writing process no longer exists: what a worker killed mid-write (the case
-    _AtomicFile exists for) leaves behind; without this, reruns accumulate multi-megabyte partial files in the subject directories.
-    Files of live processes (another worker writing the same target right now) are left alone."""
+    """Remove ``<path>.tmp.<pid>.<thread>.<host>`` files whose writing process no longer exists: what a worker killed mid-write (the
+    case _AtomicFile exists for) leaves behind; without this, reruns accumulate multi-megabyte partial files in the subject
+    directories.  Files of live processes (another worker writing the same target right now) are left alone.  The pid probe is only
+    valid for files written on THIS host (same host tag, or the untagged names of earlier versions); a file tagged by another host
+    or container sharing the data directory (multi-node shards) is removed by age alone, never by a pid that means nothing here."""
+    import time
     d, base = os.path.split(path)
     prefix = base + '.tmp.'
     try:
@@ -85,8 +108,20 @@ def _sweep_stale_tmp(path):
     for nm in names:
         if not nm.startswith(prefix):
             continue
-        pid = nm[len(prefix):].split('.')[0]
-        if not pid.isdigit() or int(pid) == os.getpid():
+        parts = nm[len(prefix):].split('.')
+        pid = parts[0]
+        if not pid.isdigit():
+            continue
+        tag = parts[2] if len(parts) > 2 else None
+        full = os.path.join(d, nm)
+        if tag is not None and tag != _host_tag():
+            try:
+                if time.time() - os.path.getmtime(full) > _FOREIGN_TMP_MAX_AGE_S:
+                    os.remove(full)
+            except OSError:
+                pass
+            continue
+        if int(pid) == os.getpid():
             continue
         try:
             os.kill(int(pid), 0)                               # signal 0: existence check only
@@ -96,14 +131,14 @@ def _sweep_stale_tmp(path):
         except OSError:                                         # e.g. EPERM: exists under another user
             continue
         try:
-            os.remove(os.path.join(d, nm))
+            os.remove(full)
         except OSError:
             pass
 
 
 class _AtomicFile:
     """Binary output file that only appears under its final name once it is complete: written as
-    ``<path>.tmp.<pid>.<thread>`` and ``os.replace``d into place on a clean exit, removed otherwise.  A worker
+    ``<path>.tmp.<pid>.<thread>.<host>`` and ``os.replace``d into place on a clean exit, removed otherwise.  A worker
     killed mid-write therefore never leaves a truncated ``seg_*.nii.gz`` behind -- that file is the 'already
     segmented, skip' marker of the deploy loops (common/deploy_network.py:66-67)."""
 
