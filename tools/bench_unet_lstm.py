@@ -18,6 +18,10 @@ if __name__ == '__main__':
     arch = MODELS['UNet-LSTM_ao']
     eng = Engine(arch, synthetic_params(arch, 1234))
     F, H, W = 100, 256, 256
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 5                  # timed cines (profilers pass a small count)
+    prec = sys.argv[2] if len(sys.argv) > 2 else 'fp32'
+    if prec != 'fp32':
+        eng.set_precision(prec)
     x = torch.randn((F, H, W), device='cuda')
     prob = torch.empty((F, H, W, 3), device='cuda')
     pred = torch.empty((F, H, W), dtype=torch.int32, device='cuda')
@@ -29,15 +33,15 @@ if __name__ == '__main__':
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    n = 5
     for _ in range(n):
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
+    print('cines_total=%d' % (n + 2))
     unet = 3183.5e6 * 2                      # FLOP per 256x256 frame through the U-Net
     lstm = 2 * 9 * 256 * 256 * (9 * 32 * 64) * 2 + 9 * 256 * 256 * 32 * 3 * 2     # per window: 18 gate convs + 9 output convs
     ref_flop = F * (9 * unet + lstm)         # the reference recomputes the U-Net for each of the 9 window positions
     our_flop = F * (unet + lstm)
-    print('UNet-LSTM cine, %d frames of %dx%d, fp32: %.1f ms per slice position = %.0f frames/s' % (F, H, W, dt * 1e3, F / dt))
+    print('UNet-LSTM cine, %d frames of %dx%d, %s: %.2f ms per slice position = %.0f frames/s' % (F, H, W, prec, dt * 1e3, F / dt))
     print('   work as the reference executes it: %.2f TFLOP (U-Net 9x per frame) -> %.0f TFLOP/s equivalent; '
           'as executed here (features once): %.2f TFLOP -> %.0f TFLOP/s' % (ref_flop / 1e12, ref_flop / dt / 1e12, our_flop / 1e12, our_flop / dt / 1e12))
