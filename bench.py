@@ -121,7 +121,26 @@ def smi_sclk_mhz():
         return None
 
 
-def sustained_probe(step, n, dev_index, seconds=3.0, est_ms=1.3):
+def smi_showuse():
+    """`rocm-smi --showuse` as this container sees it (text), or why it could not be run.  Printed beside `sustained` so that a reader
+    of the driver's own GPU-busy samples can tell an idle GPU from a tool that reports nothing inside the container."""
+    import shutil
+    import subprocess
+    if any('rocprof' in os.environ.get(k, '').lower() for k in ('LD_PRELOAD', 'HSA_TOOLS_LIB', 'ROCP_TOOL_LIBRARIES')):
+        return 'skipped under a profiler'
+    tool = shutil.which('rocm-smi')
+    if tool is None:
+        return 'rocm-smi not on PATH'
+    env = {k: v for k, v in os.environ.items() if k not in ('LD_PRELOAD', 'HSA_TOOLS_LIB')}
+    try:
+        r = subprocess.run([sys.executable, tool, '--showuse'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=15, env=env)
+        lines = [l.strip() for l in r.stdout.splitlines() if 'use' in l.lower() or 'busy' in l.lower() or 'error' in l.lower() or 'warn' in l.lower()]
+        return ' | '.join(lines)[:400] or r.stdout.strip()[-400:]
+    except Exception as e:
+        return repr(e)[-200:]
+
+
+def sustained_probe(step, n, dev_index, seconds=10.0, est_ms=1.3):
     """Reported beside the headline: the SAME step looped for >= `seconds` of GPU time (a cohort runs for hours, the headline
     region is a 26 ms burst), with the shader clock the chip held DURING the loop: a one-wave probe (ukbb_fcn_clock_probe:
     s_memtime against the 100 MHz s_memrealtime) on a stream of its own while the steps are queued on the bench stream."""
@@ -131,6 +150,15 @@ def sustained_probe(step, n, dev_index, seconds=3.0, est_ms=1.3):
     chunk = max(8, int(0.25 / (est_ms * 1e-3)))                       # about a quarter second of steps per enqueue round
     clocks, smi = [], []
     done = 0
+    # `rocm-smi --showuse` from a thread while the steps keep being queued: what a sampler sees of this loop from inside the container
+    import threading
+    use = {}
+
+    def sample_use():
+        time.sleep(min(2.0, seconds / 3))
+        use['text'] = smi_showuse()
+    th = threading.Thread(target=sample_use, daemon=True)
+    th.start()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     while True:
@@ -147,12 +175,14 @@ def sustained_probe(step, n, dev_index, seconds=3.0, est_ms=1.3):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     s = smi_sclk_mhz()                                                 # right behind the loop (the tool itself takes ~0.1-1 s)
+    th.join(timeout=20)
     clocks.sort()
     med = clocks[len(clocks) // 2] if clocks else None
     return {'value': round(n * done / dt, 1), 'unit': 'slices/s', 'steps': done, 'seconds': round(dt, 3), 'ms_per_step': round(dt / done * 1e3, 4),
             'shader_clock_mhz_in_loop': None if med is None else round(med, 1),
             'shader_clock_samples_mhz': [round(c) for c in clocks],
             'rocm_smi_sclk_mhz_after_loop': s,
+            'rocm_smi_showuse_during_loop': use.get('text'),
             'note': 'same step, same resident batch, looped for %.1f s; clock = median of one-wave s_memtime / s_memrealtime probes that ran '
                     'beside the queued steps' % dt}
 
@@ -379,9 +409,9 @@ def main():
                     help='after the timed region also measure the same steps with two batches in flight on two streams '
                          '(extra field two_batches_in_flight; off by default so that a rocprofv3 trace of the default command '
                          'holds single-stream launches only)')
-    ap.add_argument('--sustained-seconds', type=float, default=3.0,
-                    help='after the timed steps loop the same step for this long and report it as out["sustained"] with the shader clock '
-                         'observed during the loop (0 = skip)')
+    ap.add_argument('--sustained-seconds', type=float, default=10.0,
+                    help='as the LAST thing of the run (after the side probes and the CPU legs) loop the same step for this long and report '
+                         'it as out["sustained"] with the shader clock observed during the loop (0 = skip)')
     ap.add_argument('--rehearsal', action='store_true',
                     help='allow several ranks on one GPU (the 1-GPU rehearsal of the N > 1 launch); without it two ranks that report '
                          'the same PCI bus id make the run fail')
@@ -568,6 +598,18 @@ def main():
         }
         if detail:
             out['roofline_detail'] = detail
+        if world == 1 and args.inflight_probe:
+            out['two_batches_in_flight'] = inflight_probe(arch, params, x, n, args.steps)
+        if world == 1 and not args.no_f32x3_probe:
+            out['f32x3'] = f32x3_probe(eng, x, n, args.steps, eng.kernel_names().index('head'))
+        if world == 1 and not args.no_other_configs:
+            try:
+                out['other_configs'] = other_configs_probe(dev)
+            except Exception as e:                                    # never lose the headline line to a side probe
+                out['other_configs'] = {'error': repr(e)[-300:]}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        # last, and long enough for an outside sampler at a 5 s period to land inside it at least once
         if world == 1 and args.sustained_seconds > 0:
             try:
                 sus = sustained_probe(step, n, dev_index, args.sustained_seconds, elapsed_max / args.steps * 1e3)
@@ -580,17 +622,6 @@ def main():
                     roofline['observed_clock_mhz'] = sus['shader_clock_mhz_in_loop']
             except Exception as e:
                 out['sustained'] = {'error': repr(e)[-300:]}
-        if world == 1 and args.inflight_probe:
-            out['two_batches_in_flight'] = inflight_probe(arch, params, x, n, args.steps)
-        if world == 1 and not args.no_f32x3_probe:
-            out['f32x3'] = f32x3_probe(eng, x, n, args.steps, eng.kernel_names().index('head'))
-        if world == 1 and not args.no_other_configs:
-            try:
-                out['other_configs'] = other_configs_probe(dev)
-            except Exception as e:                                    # never lose the headline line to a side probe
-                out['other_configs'] = {'error': repr(e)[-300:]}
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:

@@ -135,9 +135,9 @@ struct ukbb_fcn_handle {
 
     // UNet-LSTM (kind 2)
     int feat_buf = -1;                        // activation index of net['conv0_up']
-    int lstm_cfg_fw = -1, lstm_cfg_bw = -1;
-    const float *lstm_wpk_fw = nullptr, *lstm_wpk_bw = nullptr;
-    DevBuf lstm_gates, lstm_h, lstm_c, lstm_probw, lstm_aux;   // lstm_aux: int maps / orders / double weights (raw bytes)
+    int lstm_tile_cols = 0;                   // region shape of the fused gate-conv / cell kernel (kernels_wino24.hip): 32 | 16
+    // lstm_gx / lstm_c1 / lstm_h1: per direction and FRAME (the x pass); lstm_c: per window; lstm_hall: per direction, step and window
+    DevBuf lstm_gx, lstm_c1, lstm_h1, lstm_c, lstm_hall, lstm_probw, lstm_aux;   // lstm_aux: int maps / orders / double weights (raw bytes)
     long long lstm_aux_key = -1;              // which tables lstm_aux holds (shape-keyed, uploaded once per shape)
 
     // image-slice streams (experiment UKBB_SPLIT, run_plan): consecutive conv ops run as S independent image ranges on S streams
@@ -841,21 +841,32 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
             op.macs_per_image = (double)H * W * a.n_filter[0] * a.n_class;
             h->ops.push_back(op);
         } else {
-            // gate convolutions of the two directions: tiling + packed weights chosen once per plan
-            for (const char *nm2 : {"lstm_fw", "lstm_bw"}) {
-                const int li = h->layer_index.at(nm2);
-                const HostLayer &L = h->layers[li];
-                const int cfg = choose_cfg(nm2, 3, 1, a.n_filter[0], a.same_dim, L.cout, H, W, n_hint, false, false);
-                ConvConfig c;
-                if (cfg < 0 || find_cfg(cfg, c) || c.pc != 4) {
-                    set_err("the ConvLSTM gate conv needs the Winograd kernel (unset UKBB_NO_WINOGRAD / UKBB_CONV_CFG overrides)");
-                    return UKBB_EARCH;
+            // ConvLSTM: region shape of the fused gate-conv / cell kernel, chosen once per plan (both shapes give identical bits);
+            // packed filters: the x rows of both directions as ONE 128-channel conv (groups = directions), the h rows per direction
+            const int cfg = choose_cfg("lstm_fw", 3, 1, a.n_filter[0], a.same_dim, 4 * a.same_dim, H, W, n_hint, false, false);
+            ConvConfig c;
+            if (cfg < 0 || find_cfg(cfg, c) || !is_wino24(c) || c.wm != 4 || (c.tw != 32 && c.tw != 16)) {
+                set_err("the ConvLSTM needs the Winograd F(2x4) kernel (unset UKBB_NO_WINOGRAD / UKBB_NO_WINOGRAD24 / UKBB_CONV_CFG overrides)");
+                return UKBB_EARCH;
+            }
+            h->lstm_tile_cols = c.tw;
+            if (!dev_ptr(h, "lstm/wx")) {
+                const size_t per = (size_t)24 * 16 * 64;
+                std::vector<float> wx(2 * per), bx(2 * 64), wh(per);
+                int d = 0;
+                for (const char *nm2 : {"lstm_fw", "lstm_bw"}) {
+                    const HostLayer &L = h->layers[h->layer_index.at(nm2)];
+                    if (L.cin != 32 || L.cout != 64 || L.ks != 3) { set_err("ConvLSTM gate kernel must be 3x3x(16+16)x64"); return UKBB_EARCH; }
+                    pack_lstm_gate_weights(L.w.data(), L.cin, 0, L.b.data(), wx.data() + d * per, bx.data() + d * 64);
+                    pack_lstm_gate_weights(L.w.data(), L.cin, a.n_filter[0], nullptr, wh.data(), nullptr);
+                    int rc = upload(h, std::string(nm2) + "/wh", wh);
+                    if (rc) return rc;
+                    ++d;
                 }
-                const float *wpk = nullptr;
-                int rc = ensure_packed(h, li, c, &wpk);
+                int rc = upload(h, "lstm/wx", wx);
                 if (rc) return rc;
-                (std::string(nm2) == "lstm_fw" ? h->lstm_cfg_fw : h->lstm_cfg_bw) = cfg;
-                (std::string(nm2) == "lstm_fw" ? h->lstm_wpk_fw : h->lstm_wpk_bw) = wpk;
+                rc = upload(h, "lstm/bx", bx);
+                if (rc) return rc;
             }
         }
     }
@@ -1266,47 +1277,56 @@ int ukbb_fcn_forward_host(ukbb_fcn_handle *h, const float *image, int n, int hei
 // ---- UNet-LSTM --------------------------------------------------------------------------------------
 namespace {
 
-// BiConvLSTM over Wn windows of T steps.  map[k*Wn + w] = feature frame of step k of window w.
-// out: per (k, w) n_class floats per pixel at out + k*k_stride + w*w_stride (softmax probabilities);
-// logits / pred optional with the same addressing (pred strides divided by n_class).
-int run_bilstm(ukbb_fcn_handle *h, const float *feat, const int *d_map, int Wn, int H, int W,
-               float *out, long long k_stride, long long w_stride, float *logits, int32_t *pred, hipStream_t s) {
+// BiConvLSTM over Wn windows of T steps on NF cached feature frames.  d_map[k*Wn + w] = feature frame of step k of window w.
+//   x pass (one launch, both directions): per frame gx = W_x * x + b, and the cell's first step from the zero state (:278,:290) c1, h1;
+//   then per direction T - 1 launches of the fused gate-conv (hidden channels only) + cell kernel, every step's hidden map kept
+//   ([dir][k][Wn][HW][16]) for the output conv over concat([h_fw, h_bw]) (:305-312), which the caller runs (lstm_out / lstm_tile).
+int run_bilstm(ukbb_fcn_handle *h, const float *feat, int NF, const int *d_map, int Wn, int H, int W, hipStream_t s) {
     const ukbb_fcn_arch &a = h->arch;
-    const int T = a.fc, NHID = a.same_dim, C = a.n_class;
+    const int T = a.fc, NHID = a.same_dim, tc = h->lstm_tile_cols;
     const size_t HW = (size_t)H * W;
-    HIP_TRY(h->lstm_gates.ensure((size_t)Wn * HW * 4 * NHID), UKBB_ENOMEM);
-    HIP_TRY(h->lstm_h.ensure((size_t)Wn * HW * NHID), UKBB_ENOMEM);
-    HIP_TRY(h->lstm_c.ensure((size_t)Wn * HW * NHID), UKBB_ENOMEM);
-    const float *w_out = dev_ptr(h, "lstm_out/w"), *b_out = dev_ptr(h, "lstm_out/bias");
+    const size_t gxf = wino24_lstm_gx_floats(H, W, tc), cf = wino24_lstm_c_floats(H, W, tc);
+    HIP_TRY(h->lstm_gx.ensure(2 * (size_t)NF * gxf), UKBB_ENOMEM);
+    HIP_TRY(h->lstm_c1.ensure(2 * (size_t)NF * cf), UKBB_ENOMEM);
+    HIP_TRY(h->lstm_h1.ensure(2 * (size_t)NF * HW * NHID), UKBB_ENOMEM);
+    HIP_TRY(h->lstm_c.ensure((size_t)Wn * cf), UKBB_ENOMEM);
+    HIP_TRY(h->lstm_hall.ensure(2 * (size_t)T * Wn * HW * NHID), UKBB_ENOMEM);
+    ConvArgs base{};
+    base.C0 = a.n_filter[0]; base.C1 = 0;
+    base.H = H; base.W = W; base.Ho = H; base.Wo = W;
+    base.pad_y = 1; base.pad_x = 1; base.relu = 0;
+    base.tiles_y = (H + 7) / 8; base.tiles_x = (W + tc - 1) / tc;
+    base.ls_forget_bias = 1.0f;
+    {   // x pass
+        ConvArgs ca = base;
+        ca.in0 = feat; ca.N = NF; ca.Cout = 2 * 4 * NHID;
+        ca.wpk = dev_ptr(h, "lstm/wx"); ca.bias = dev_ptr(h, "lstm/bx");
+        ca.ls_mode = 1; ca.ls_gx = h->lstm_gx.p; ca.ls_c_out = h->lstm_c1.p; ca.out = h->lstm_h1.p;
+        ca.ls_gx_dir = (long long)NF * gxf; ca.ls_c_dir = (long long)NF * cf; ca.ls_h_dir = (long long)NF * HW * NHID;
+        hipError_t e = launch_wino24_lstm(ca, tc, s);
+        if (e != hipSuccess) { set_err("ConvLSTM x-pass launch failed: %s", hipGetErrorString(e)); return UKBB_EDEVICE; }
+    }
+    const size_t kst = (size_t)Wn * HW * NHID;           // one step's hidden maps
     for (int dir = 0; dir < 2; ++dir) {
-        HIP_TRY(hipMemsetAsync(h->lstm_h.p, 0, (size_t)Wn * HW * NHID * sizeof(float), s), UKBB_EDEVICE);   // zero_state (:278,:290)
-        HIP_TRY(hipMemsetAsync(h->lstm_c.p, 0, (size_t)Wn * HW * NHID * sizeof(float), s), UKBB_EDEVICE);
-        const int cfg = dir ? h->lstm_cfg_bw : h->lstm_cfg_fw;
-        ConvConfig c;
-        find_cfg(cfg, c);
-        for (int step = 0; step < T; ++step) {
-            const int k = dir ? T - 1 - step : step;
-            ConvArgs ca{};
-            ca.in0 = feat; ca.in0_map = d_map + (size_t)k * Wn; ca.C0 = a.n_filter[0];
-            ca.in1 = h->lstm_h.p; ca.C1 = NHID;
-            ca.wpk = dir ? h->lstm_wpk_bw : h->lstm_wpk_fw;
-            ca.bias = dev_ptr(h, dir ? "lstm_bw/bias" : "lstm_fw/bias");
-            ca.out = h->lstm_gates.p;
-            ca.N = Wn; ca.H = H; ca.W = W; ca.Ho = H; ca.Wo = W; ca.Cout = 4 * NHID;
-            ca.pad_y = 1; ca.pad_x = 1;
-            ca.tiles_y = (H + c.th - 1) / c.th; ca.tiles_x = (W + c.tw - 1) / c.tw;
-            ca.relu = 0;
-            hipError_t e = launch_conv(cfg, ca, s);
-            if (e != hipSuccess) { set_err("ConvLSTM gate conv launch failed: %s", hipGetErrorString(e)); return UKBB_EDEVICE; }
-            LstmCellArgs la{};
-            la.gates = h->lstm_gates.p; la.c = h->lstm_c.p; la.h = h->lstm_h.p;
-            la.w_out = w_out + (size_t)dir * NHID * C; la.b_out = b_out;
-            la.acc = out + (size_t)k * k_stride; la.m_stride = w_stride;
-            la.logits = (dir && logits) ? logits + (size_t)k * k_stride : nullptr;
-            la.pred = (dir && pred) ? pred + (size_t)k * (k_stride / C) : nullptr;
-            la.M = Wn; la.HW = (int)HW; la.n_class = C; la.forget_bias = 1.0f; la.finish = dir;
-            e = launch_lstm_cell(la, s);
-            if (e != hipSuccess) { set_err("ConvLSTM cell launch failed: %s", hipGetErrorString(e)); return UKBB_EDEVICE; }
+        float *const hall = h->lstm_hall.p + (size_t)dir * T * kst;
+        for (int step = 1; step < T; ++step) {
+            const int k = dir ? T - 1 - step : step, kprev = dir ? k + 1 : k - 1;
+            ConvArgs ca = base;
+            ca.N = Wn; ca.Cout = 4 * NHID;
+            ca.wpk = dev_ptr(h, dir ? "lstm_bw/wh" : "lstm_fw/wh"); ca.bias = nullptr;
+            ca.ls_mode = 2;
+            ca.ls_gx = h->lstm_gx.p + (size_t)dir * NF * gxf; ca.ls_gx_map = d_map + (size_t)k * Wn;
+            if (step == 1) {                                // previous state = the x pass's per-frame first step
+                ca.in0 = h->lstm_h1.p + (size_t)dir * NF * HW * NHID; ca.in0_map = d_map + (size_t)kprev * Wn;
+                ca.ls_c_in = h->lstm_c1.p + (size_t)dir * NF * cf;
+            } else {
+                ca.in0 = hall + (size_t)kprev * kst; ca.in0_map = nullptr;
+                ca.ls_c_in = h->lstm_c.p;
+            }
+            ca.ls_c_out = h->lstm_c.p;
+            ca.out = hall + (size_t)k * kst;
+            hipError_t e = launch_wino24_lstm(ca, tc, s);
+            if (e != hipSuccess) { set_err("ConvLSTM step launch failed: %s", hipGetErrorString(e)); return UKBB_EDEVICE; }
         }
     }
     return UKBB_OK;
@@ -1344,12 +1364,30 @@ int ukbb_fcn_forward_seq(ukbb_fcn_handle *h, const float *image, int n_seq, int 
         h->lstm_aux_key = key;
     }
     float *out = prob;
-    if (!out) {                                                              // the cell kernel needs an accumulator
+    if (!out) {                                                              // the output kernel always forms the probabilities
         HIP_TRY(h->lstm_probw.ensure((size_t)n_seq * T * HW * C), UKBB_ENOMEM);
         out = h->lstm_probw.p;
     }
-    return run_bilstm(h, h->act[h->feat_buf]->p, reinterpret_cast<const int *>(h->lstm_aux.p), n_seq, height, width,
-                      out, (long long)HW * C, (long long)T * HW * C, logits, pred, s);
+    const int NF = n_seq * T, NHID = h->arch.same_dim;
+    const int *d_map = reinterpret_cast<const int *>(h->lstm_aux.p);
+    rc = run_bilstm(h, h->act[h->feat_buf]->p, NF, d_map, n_seq, height, width, s);
+    if (rc) return rc;
+    const size_t kst = (size_t)n_seq * HW * NHID;
+    for (int k = 0; k < T; ++k) {                                            // outputs straight into [N][T] order
+        LstmOutArgs oa{};
+        oa.hf = k == 0 ? h->lstm_h1.p : h->lstm_hall.p + (size_t)k * kst;
+        oa.mapf = k == 0 ? d_map : nullptr;
+        oa.hb = k == T - 1 ? h->lstm_h1.p + (size_t)NF * HW * NHID : h->lstm_hall.p + (size_t)T * kst + (size_t)k * kst;
+        oa.mapb = k == T - 1 ? d_map + (size_t)(T - 1) * n_seq : nullptr;
+        oa.w_out = dev_ptr(h, "lstm_out/w"); oa.b_out = dev_ptr(h, "lstm_out/bias");
+        oa.prob = out + (size_t)k * HW * C;
+        oa.logits = logits ? logits + (size_t)k * HW * C : nullptr;
+        oa.pred = pred ? pred + (size_t)k * HW : nullptr;
+        oa.m_stride = (long long)T * HW * C; oa.M = n_seq; oa.HW = (int)HW; oa.n_class = C;
+        hipError_t e = launch_lstm_out(oa, s);
+        if (e != hipSuccess) { set_err("ConvLSTM output kernel launch failed: %s", hipGetErrorString(e)); return UKBB_EDEVICE; }
+    }
+    return UKBB_OK;
 }
 
 int ukbb_fcn_forward_cine(ukbb_fcn_handle *h, const float *image, int n_frames, int height, int width,
@@ -1414,12 +1452,17 @@ int ukbb_fcn_forward_cine(ukbb_fcn_handle *h, const float *image, int n_frames, 
         h->lstm_aux_key = key;
     }
     char *aux = reinterpret_cast<char *>(h->lstm_aux.p);
-    HIP_TRY(h->lstm_probw.ensure((size_t)T * Wn * HW * C), UKBB_ENOMEM);
-    rc = run_bilstm(h, h->act[h->feat_buf]->p, reinterpret_cast<const int *>(aux), Wn, height, width,
-                    h->lstm_probw.p, (long long)Wn * HW * C, (long long)HW * C, nullptr, nullptr, s);
+    const int *d_map = reinterpret_cast<const int *>(aux);
+    rc = run_bilstm(h, h->act[h->feat_buf]->p, F, d_map, Wn, height, width, s);
     if (rc) return rc;
+    const int NHID = h->arch.same_dim;
     LstmTileArgs ta{};
-    ta.probw = h->lstm_probw.p; ta.order = reinterpret_cast<const int *>(aux + off_ord);
+    ta.k_stride = (long long)Wn * HW * NHID;
+    ta.hf = h->lstm_hall.p; ta.hb = h->lstm_hall.p + (size_t)T * ta.k_stride;
+    ta.h1f = h->lstm_h1.p; ta.h1b = h->lstm_h1.p + (size_t)F * HW * NHID;
+    ta.map_first = d_map; ta.map_last = d_map + (size_t)(T - 1) * Wn;
+    ta.w_out = dev_ptr(h, "lstm_out/w"); ta.b_out = dev_ptr(h, "lstm_out/bias");
+    ta.order = reinterpret_cast<const int *>(aux + off_ord);
     ta.wk = reinterpret_cast<const double *>(aux + off_wk); ta.wsum = reinterpret_cast<const double *>(aux + off_ws);
     ta.prob = prob; ta.pred = pred; ta.F = F; ta.K = T; ta.Wn = Wn; ta.HW = (int)HW; ta.C = C;
     hipError_t e = launch_lstm_tile(ta, s);
@@ -1533,6 +1576,20 @@ int64_t ukbb_fcn_get_activation(ukbb_fcn_handle *h, const char *name, float *dst
         }
         if (hipSetDevice(h->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
             hipMemcpy(dst, h->act[i]->p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
+            set_err("get_activation: device copy failed");
+            return UKBB_EDEVICE;
+        }
+        return n;
+    }
+    // ConvLSTM working buffers, raw (tools/debug_lstm.py decodes the lane-native ones): whatever the last sequence call left in them
+    for (const auto &kv : {std::pair<const char *, const DevBuf *>{"lstm:h1", &h->lstm_h1}, {"lstm:hall", &h->lstm_hall}, {"lstm:gx", &h->lstm_gx},
+                           {"lstm:c1", &h->lstm_c1}, {"lstm:c", &h->lstm_c}}) {
+        if (strcmp(kv.first, name)) continue;
+        const int64_t n = (int64_t)kv.second->n;
+        if (!dst) return n;
+        if (cap < n) { set_err("get_activation: buffer too small (%lld < %lld)", (long long)cap, (long long)n); return UKBB_EINVAL; }
+        if (hipSetDevice(h->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+            hipMemcpy(dst, kv.second->p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
             set_err("get_activation: device copy failed");
             return UKBB_EDEVICE;
         }

@@ -97,6 +97,22 @@ struct ConvArgs {
     int xcd_local;      // kernels_ws.hip only: tile order (set by launch_conv_ws)
     int cout_store;     // bf16-storage tilings (ConvConfig::pc == 5) only: real channel count of `out` when Cout is the zero-padded
                         // count the weights were packed for (a 16-channel layer on the 32-row MFMA); 0 = Cout
+    // ---- ConvLSTM cell in the epilogue of the F(2x4) Winograd kernel (kernels_wino24.hip, launch_wino24_lstm; network_ao.py:255-319) ----
+    // ls_mode 1 ("x pass", once per call): in0 = the U-Net feature frames [N][H][W][16], Cout = 64 per direction (groups = directions),
+    //   filter = the x rows of the gate kernel, bias = the gate bias.  Per frame and direction the epilogue stores gx = W_x * x + b
+    //   (ls_gx), and the cell's first step from the zero state: c1 (ls_c_out), h1 (out, [N][H][W][16]).
+    // ls_mode 2 (one time step of one direction): in0 = the previous hidden state [N][H][W][16] (image n reads in0_map[n] if given),
+    //   Cout = 64, filter = the h rows of the gate kernel, bias = nullptr; gates = W_h * h + gx[ls_gx_map[n]], cell state read from
+    //   ls_c_in (entry in0_map[n] if given, else n) and written to ls_c_out[n], h written to out.
+    // gx / c live in the consumer lanes' own order ("lane-native": [image][region][wave][tile block][pixel of the 2x4 tile][lane]), the gate
+    // channels are packed so that one lane holds i, j, f, o of ONE hidden channel (pack_lstm_gate_weights).
+    int ls_mode;
+    float *ls_gx;               // mode 1: written; mode 2: read (const in effect)
+    const int *ls_gx_map;       // mode 2: frame whose gx window n adds at this step
+    const float *ls_c_in;       // mode 2
+    float *ls_c_out;
+    long long ls_gx_dir, ls_c_dir, ls_h_dir;   // mode 1: floats between the two directions' halves of ls_gx / ls_c_out / out
+    float ls_forget_bias;
 };
 
 // One compiled tiling of the conv kernel.
@@ -160,6 +176,15 @@ hipError_t launch_wino24(const ConvArgs &a, int tile_cols /*32 | 16*/, int pair 
                          hipStream_t s);
 size_t pack_wino24_weights(const float *w /*[3][3][cin][cout] folded*/, int cin, int cout, int ncb, float *dst /*24*cin*cout*/);
 int wino24_lds_bytes(int tbw, int pair);
+// ConvLSTM forms of the same kernel (ConvArgs::ls_mode 1 | 2): tile_cols 32 | 16.  Both region shapes give identical bits.
+hipError_t launch_wino24_lstm(const ConvArgs &a, int tile_cols, hipStream_t s);
+// floats of the lane-native gx / c buffers per image (frame or window) for maps of Ho x Wo
+size_t wino24_lstm_gx_floats(int Ho, int Wo, int tile_cols);
+size_t wino24_lstm_c_floats(int Ho, int Wo, int tile_cols);
+// gate filter rows [3][3][cin_total][64] (HWIO, channels i | j | f | o x 16 hidden) -> packed F(2x4) A fragments of the input-channel slice
+// [c_first, c_first + 16) with the output channels permuted so that MFMA row 4 g + e of 16-channel block w is gate e of hidden channel
+// 4 w + g; `bias_perm` (optional, 64) receives the bias in the same order.  Returns floats written to dst (24 * 16 * 64).
+size_t pack_lstm_gate_weights(const float *w, int cin_total, int c_first, const float *bias, float *dst, float *bias_perm);
 
 // ---------------------------------------------------------------------------
 // First layer: conv3x3, C_in = 1 (network.py:186 with l = 0), direct stencil.
@@ -266,24 +291,25 @@ struct LogitsArgs {         // 1x1 conv C -> n_class + bias, softmax / argmax (n
 hipError_t launch_logits(const LogitsArgs &a, hipStream_t s);
 
 // ---- BiConvLSTM head of the aortic UNet-LSTM (network_ao.py:255-319), kernels_lstm.hip ----
-struct LstmCellArgs {       // one ConvLSTM step after the gate conv: state update + this direction's half of the 1x1 output conv
-    const float *gates;     // [M][HW][4*NH] pre-activations in the order i, j, f, o (bias already added by the conv)
-    float *c;               // [M][HW][NH] cell state, updated in place
-    float *h;               // [M][HW][NH] hidden state, overwritten
-    const float *w_out;     // [NH][n_class]: this direction's rows of the output conv kernel [2*NH][n_class]
-    const float *b_out;     // [n_class] (used in the finishing pass)
-    float *acc;             // per (window m, pixel): n_class floats at acc + m*m_stride + pix*n_class
-    float *logits;          // optional, same addressing: the finished logits (finishing pass only)
-    int32_t *pred;          // optional: argmax at pred + m*(m_stride/n_class) + pix (finishing pass only)
-    long long m_stride;     // floats between consecutive windows in acc / logits
+struct LstmOutArgs {        // one time step's outputs from the two directions' hidden maps (1x1 output conv + bias, softmax, argmax)
+    const float *hf, *hb;   // [.][HW][NH] hidden maps of the forward / backward cell at this step
+    const int *mapf, *mapb; // optional: window m reads entry mapf[m] / mapb[m] (the first step of a direction lives per FRAME)
+    const float *w_out;     // [2*NH][n_class] (forward rows first, network_ao.py:305-312)
+    const float *b_out;     // [n_class]
+    float *prob;            // per (window m, pixel): n_class floats at prob + m*m_stride + pix*n_class
+    float *logits;          // optional, same addressing
+    int32_t *pred;          // optional: argmax at pred + m*(m_stride/n_class) + pix
+    long long m_stride;     // floats between consecutive windows in prob / logits
     int M, HW, n_class;
-    float forget_bias;
-    int finish;             // 0: acc = W.h (forward direction);  1: acc = softmax(acc + W.h + b) (backward direction)
 };
-hipError_t launch_lstm_cell(const LstmCellArgs &a, hipStream_t s);
+hipError_t launch_lstm_out(const LstmOutArgs &a, hipStream_t s);
 
-struct LstmTileArgs {       // weighted tiling of the window probabilities, deploy_network_ao.py:176-183
-    const float *probw;     // [K][Wn][HW][C] window probabilities (K = window length, Wn = F windows, centre t = w)
+struct LstmTileArgs {       // per-(window, step) outputs + the weighted tiling of deploy_network_ao.py:176-183 in one pass
+    const float *hf, *hb;   // [K][Wn][HW][NH] hidden maps per step k and window (entry k = 0 of hf / k = K-1 of hb unused, see h1f / h1b)
+    const float *h1f, *h1b; // [frames][HW][NH]: the first step of each direction, per frame (the x pass of the fused kernel)
+    const int *map_first, *map_last;   // [Wn]: frame of window w at step 0 / at step K-1
+    long long k_stride;     // floats between steps in hf / hb
+    const float *w_out, *b_out;
     const int *order;       // [F][K] for frame f: the <= K contributing (window w, position k) pairs packed w*K + k (-1 ends the list),
                             //        sorted the way the reference's loop over t adds them
     const double *wk;       // [K] window weights

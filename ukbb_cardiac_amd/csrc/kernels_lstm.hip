@@ -1,15 +1,15 @@
 // BiConvLSTM head of the aortic UNet-LSTM model (reference common/network_ao.py:255-319 with
-// tf.contrib.rnn.Conv2DLSTMCell semantics, SURVEY.md App. B.6 [TF-recall]).  The gate convolution
-// (3x3 over concat([x_t, h]) -> 4*16 channels) runs on the Winograd MFMA kernel; what is left per step is
-// HBM-bound element-wise work, fused here into one pass per step:
+// tf.contrib.rnn.Conv2DLSTMCell semantics, SURVEY.md App. B.6 [TF-recall]).
 //
-//   i, j, f, o = split(gates);  c' = sigmoid(f + 1) * c + sigmoid(i) * tanh(j);  h' = tanh(c') * sigmoid(o)
-//   + this direction's half of the 1x1 output conv (16 -> n_class) accumulated per pixel, and in the
-//   backward direction's pass the bias, softmax and argmax (network_ao.py:305-312, 396-397),
-//
-// so the per-step hidden maps of the two directions are never stored for a later concat.
-// lstm_tile_kernel then performs the weighted circular tiling of deploy_network_ao.py:176-183 in the
-// reference's accumulation order and arithmetic (float32 accumulator updated through float64).
+// r05: the gate convolution AND the cell update run in one kernel (kernels_wino24.hip, ConvArgs::ls_mode): the x half of the gate
+// conv (W_x * x_t + b, the same for every window a frame is part of) is evaluated once per frame and direction, each time step
+// then convolves the 16 hidden channels only and forms  c' = sigmoid(f + 1) * c + sigmoid(i) * tanh(j);  h' = tanh(c') * sigmoid(o)
+// in the epilogue -- the 64-channel gate map never exists in HBM.  What is left for this file:
+//   lstm_out_kernel   prob / pred / logits of one time step from the two directions' hidden maps: the 1x1 output conv over
+//                     concat([h_fw, h_bw]) + bias, softmax, argmax (network_ao.py:305-312, 396-397);
+//   lstm_tile_kernel  the same per (window, step) and, fused behind it, the weighted circular tiling of
+//                     deploy_network_ao.py:176-183 in the reference's accumulation order and arithmetic (float32 accumulator
+//                     updated through float64) -- the per-window probabilities are never stored.
 #include "kernels.h"
 
 namespace ukbb {
@@ -20,80 +20,67 @@ namespace {
 
 constexpr int NH = 16;                       // hidden channels (train_network_ao.py num_hidden = 16)
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float tanhf_(float x) {
-    // tanh(x) = 1 - 2 / (exp(2x) + 1); exact enough in fp32 (|err| ~ 1e-7) and saturates cleanly
-    const float e = __expf(2.0f * x);
-    return 1.0f - 2.0f / (e + 1.0f);
+// logits of one pixel: W[0:16] . h_fw + W[16:32] . h_bw + b (each direction's sum formed on its own, ascending hidden channel)
+template <int NCLS>
+__device__ __forceinline__ void out_conv(const float *hf, const float *hb, const float (&w)[2 * NH][NCLS], const float (&b)[NCLS], float (&lg)[NCLS]) {
+    float pf[NCLS], pb[NCLS];
+#pragma unroll
+    for (int k = 0; k < NCLS; ++k) { pf[k] = 0.f; pb[k] = 0.f; }
+#pragma unroll
+    for (int q = 0; q < NH / 4; ++q) {
+        const f32x4 vf = *reinterpret_cast<const f32x4 *>(hf + 4 * q), vb = *reinterpret_cast<const f32x4 *>(hb + 4 * q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int k = 0; k < NCLS; ++k) { pf[k] = fmaf(vf[i], w[4 * q + i][k], pf[k]); pb[k] = fmaf(vb[i], w[NH + 4 * q + i][k], pb[k]); }
+    }
+#pragma unroll
+    for (int k = 0; k < NCLS; ++k) lg[k] = (pf[k] + pb[k]) + b[k];
 }
 
-// One thread = 4 hidden channels of one pixel; 4 consecutive lanes = one pixel.
 template <int NCLS>
-__global__ __launch_bounds__(256) void lstm_cell_kernel(const LstmCellArgs a) {
-    const long long total = (long long)a.M * a.HW * (NH / 4);
-    const int q = threadIdx.x & 3;
-    float w[4][NCLS];
+__device__ __forceinline__ void load_out_weights(const float *w_out, const float *b_out, float (&w)[2 * NH][NCLS], float (&b)[NCLS]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2 * NH; ++i)
 #pragma unroll
-        for (int c = 0; c < NCLS; ++c) w[i][c] = a.w_out[(4 * q + i) * NCLS + c];
+        for (int k = 0; k < NCLS; ++k) w[i][k] = w_out[i * NCLS + k];
+#pragma unroll
+    for (int k = 0; k < NCLS; ++k) b[k] = b_out[k];
+}
+
+// one thread = one pixel of one window
+template <int NCLS>
+__global__ __launch_bounds__(256) void lstm_out_kernel(const LstmOutArgs a) {
+    float w[2 * NH][NCLS], b[NCLS];
+    load_out_weights<NCLS>(a.w_out, a.b_out, w, b);
+    const long long total = (long long)a.M * a.HW;
     for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
-        const long long px = id >> 2;                                   // global pixel index m*HW + pix
-        const float *g = a.gates + px * (4 * NH) + 4 * q;
-        const f32x4 gi = *reinterpret_cast<const f32x4 *>(g);
-        const f32x4 gj = *reinterpret_cast<const f32x4 *>(g + NH);
-        const f32x4 gf = *reinterpret_cast<const f32x4 *>(g + 2 * NH);
-        const f32x4 go = *reinterpret_cast<const f32x4 *>(g + 3 * NH);
-        f32x4 c = *reinterpret_cast<const f32x4 *>(a.c + px * NH + 4 * q);
-        f32x4 h;
-        float part[NCLS];
+        const long long m = id / a.HW, pix = id - m * a.HW;
+        const long long mf = a.mapf ? a.mapf[m] : m, mb = a.mapb ? a.mapb[m] : m;
+        float lg[NCLS], pr[NCLS];
+        out_conv<NCLS>(a.hf + (mf * a.HW + pix) * NH, a.hb + (mb * a.HW + pix) * NH, w, b, lg);
+        const int best = softmax_argmax<NCLS>(lg, pr);
+        float *po = a.prob + m * a.m_stride + pix * NCLS;
 #pragma unroll
-        for (int k = 0; k < NCLS; ++k) part[k] = 0.f;
+        for (int k = 0; k < NCLS; ++k) po[k] = pr[k];
+        if (a.logits) {
+            float *lo = a.logits + m * a.m_stride + pix * NCLS;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            c[i] = sigmoidf_(gf[i] + a.forget_bias) * c[i] + sigmoidf_(gi[i]) * tanhf_(gj[i]);
-            h[i] = tanhf_(c[i]) * sigmoidf_(go[i]);
-#pragma unroll
-            for (int k = 0; k < NCLS; ++k) part[k] = fmaf(h[i], w[i][k], part[k]);
+            for (int k = 0; k < NCLS; ++k) lo[k] = lg[k];
         }
-        *reinterpret_cast<f32x4 *>(a.c + px * NH + 4 * q) = c;
-        *reinterpret_cast<f32x4 *>(a.h + px * NH + 4 * q) = h;
-#pragma unroll
-        for (int k = 0; k < NCLS; ++k) {                                // reduce the 4 channel quads of the pixel
-            part[k] += __shfl_xor(part[k], 1);
-            part[k] += __shfl_xor(part[k], 2);
-        }
-        if (q == 0) {
-            const long long m = px / a.HW, pix = px - m * a.HW;
-            float *acc = a.acc + m * a.m_stride + pix * NCLS;
-            if (!a.finish) {
-#pragma unroll
-                for (int k = 0; k < NCLS; ++k) acc[k] = part[k];
-            } else {
-                float lg[NCLS];
-#pragma unroll
-                for (int k = 0; k < NCLS; ++k) lg[k] = acc[k] + part[k] + a.b_out[k];
-                if (a.logits) {
-                    float *lo = a.logits + m * a.m_stride + pix * NCLS;
-#pragma unroll
-                    for (int k = 0; k < NCLS; ++k) lo[k] = lg[k];
-                }
-                float pr[NCLS];
-                const int best = softmax_argmax<NCLS>(lg, pr);
-#pragma unroll
-                for (int k = 0; k < NCLS; ++k) acc[k] = pr[k];
-                if (a.pred) a.pred[m * (a.m_stride / NCLS) + pix] = best;
-            }
-        }
+        if (a.pred) a.pred[m * (a.m_stride / NCLS) + pix] = best;
     }
 }
 
-// prob[f] = (sum over the <= K windows containing f, in the reference's order, of probw * w_k) / wsum[f]
+// prob[f] = (sum over the <= K windows containing f, in the reference's order, of prob(window w, step k) * w_k) / wsum[f]
+//   prob(w, k) = softmax(out_conv(h_fw[k][w], h_bw[k][w])) exactly as lstm_out_kernel forms it (forward_seq of that window);
 //   a frame no window reaches (time_step > window) has wsum = 0: 0/0 = NaN and argmax 0, as numpy gives the reference
 //   reference arithmetic: prob is float32, `prob[..., idx] += prob_idx * w` runs in float64 and is cast back
 //   per addition; `prob /= weight` likewise (deploy_network_ao.py:176-183).
 template <int NCLS>
 __global__ __launch_bounds__(256) void lstm_tile_kernel(const LstmTileArgs a) {
+    float w[2 * NH][NCLS], b[NCLS];
+    load_out_weights<NCLS>(a.w_out, a.b_out, w, b);
     const long long total = (long long)a.F * a.HW;
     for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
         const int f = (int)(id / a.HW);
@@ -104,8 +91,14 @@ __global__ __launch_bounds__(256) void lstm_tile_kernel(const LstmTileArgs a) {
         for (int j = 0; j < a.K; ++j) {
             const int wk_ = a.order[f * a.K + j];
             if (wk_ < 0) break;                                             // fewer than K windows reach this frame (time_step > 1, F < K)
-            const int w = wk_ / a.K, k = wk_ - w * a.K;
-            const float *p = a.probw + (((long long)k * a.Wn + w) * a.HW + pix) * NCLS;
+            const int wi = wk_ / a.K, k = wk_ - wi * a.K;
+            // the first step of a direction comes from the per-FRAME maps of the x pass, later steps from that direction's per-window maps
+            const long long mf = k == 0 ? a.map_first[wi] : wi, mb = k == a.K - 1 ? a.map_last[wi] : wi;
+            const float *hf = (k == 0 ? a.h1f : a.hf + (long long)k * a.k_stride) + (mf * a.HW + pix) * NH;
+            const float *hb = (k == a.K - 1 ? a.h1b : a.hb + (long long)k * a.k_stride) + (mb * a.HW + pix) * NH;
+            float lg[NCLS], p[NCLS];
+            out_conv<NCLS>(hf, hb, w, b, lg);
+            (void)softmax_argmax<NCLS>(lg, p);
             const double wt = a.wk[k];
 #pragma unroll
             for (int c = 0; c < NCLS; ++c) acc[c] = (float)((double)acc[c] + (double)p[c] * wt);
@@ -125,14 +118,14 @@ __global__ __launch_bounds__(256) void lstm_tile_kernel(const LstmTileArgs a) {
 
 }  // namespace
 
-hipError_t launch_lstm_cell(const LstmCellArgs &a, hipStream_t s) {
-    const long long total = (long long)a.M * a.HW * (NH / 4);
+hipError_t launch_lstm_out(const LstmOutArgs &a, hipStream_t s) {
+    const long long total = (long long)a.M * a.HW;
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     switch (a.n_class) {
-        case 2: hipLaunchKernelGGL(lstm_cell_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, a); break;
-        case 3: hipLaunchKernelGGL(lstm_cell_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, s, a); break;
-        case 4: hipLaunchKernelGGL(lstm_cell_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(lstm_out_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL(lstm_out_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL(lstm_out_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

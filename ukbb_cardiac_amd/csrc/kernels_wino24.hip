@@ -98,6 +98,20 @@ __device__ __forceinline__ void bx_transform(const V4 (&d)[6], V4 (&r)[6]) {
 
 }  // namespace
 
+// ---- ConvLSTM cell pieces (tf.contrib.rnn.Conv2DLSTMCell): v_exp_f32 / v_rcp_f32 (1 ulp each) ----
+namespace {
+__device__ __forceinline__ float ls_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504f)); }
+__device__ __forceinline__ float ls_tanh(float x) {      // 1 - 2 / (e^2x + 1): saturates cleanly at both ends (rcp(inf) = 0)
+    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x * 2.88539008f) + 1.0f), 1.0f);
+}
+// gates g = (i, j, f, o) of one hidden channel of one pixel, old cell state c -> new cell state (returned through c) and hidden state
+__device__ __forceinline__ float ls_cell(const f32x4 &g, float &c, float forget_bias) {
+    const float sf = ls_sigmoid(g[2] + forget_bias), si = ls_sigmoid(g[0]), tj = ls_tanh(g[1]);
+    c = __builtin_fmaf(sf, c, si * tj);
+    return ls_tanh(c) * ls_sigmoid(g[3]);
+}
+}  // namespace
+
 // Diagnostic only (-DUKBB_WINO_STAMPS + UKBB_STAMPS=1): s_memtime stamps around the phases of a stage (perturbs the MFMA stream)
 #ifdef UKBB_WINO_STAMPS
 #define STAMP(v) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); }
@@ -109,10 +123,12 @@ __device__ unsigned long long g_w24stamps[8];
 #endif
 // NCB = 16-channel blocks per item: 4 (64 output channels, consumer wave w = block w, all tile blocks) or 2 (32 output channels, TBW = 2 only:
 // wave w = block w & 1 of tile block w >> 1 -- layers with 32 output channels, which are bound by the producers in the F(2x2) kernel)
-template <int TBW, bool PAIR, int NCB>
+// LS: 0 = plain conv; 1 | 2 = ConvLSTM cell in the epilogue (ConvArgs::ls_mode; the producers and the MFMA phase are the plain ones)
+template <int TBW, bool PAIR, int NCB, int LS = 0>
 __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
     using G = W24<TBW, PAIR>;
     static_assert(NCB == 4 || (NCB == 2 && TBW == 2 && !PAIR), "32-channel items come with 8 x 32-pixel regions");
+    static_assert(LS == 0 || (NCB == 4 && !PAIR), "the ConvLSTM epilogue needs the four gate blocks of a hidden channel quad in one wave");
     constexpr int CTB = NCB == 2 ? 1 : TBW;             // tile blocks per consumer wave
     constexpr int NT = G::NT, TRX = G::TRX, WIH = G::WIH, WIW = G::WIW, WHP = G::WHP, NITX = G::NITX, RS = G::RS, XSZ = G::XSZ, VSZ = G::VSZ, L_XS = G::L_XS, L_VS = G::L_VS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -335,7 +351,8 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
             const int r = rest - n * regions;
             const int ry = r / regs_x, rx = r - ry * regs_x;
             const int co = (grp * NCB + wave) * 16 + 4 * g;
-            const f32x4 bias = ld4(a.bias + co);
+            f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (LS != 2) bias = ld4(a.bias + co);   // LS 2: the gate bias is part of gx
             // the folded-BN bias rides through the output transform as M[1][1] (k = 7): A_y^T column 1 and A_x^T column 1 are all ones
             f32x4 acc[NK][CTB];
             const float *wbase = a.wpk + ((size_t)grp * nchunk * NCB + wave) * (NK * 64 * 4) + lane * 4;
@@ -420,6 +437,79 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
             // ---- output transform Y = A_y^T M A_x, ReLU, NHWC stores ----
             asm volatile("s_nop 15" ::: "memory");        // MFMA -> VALU wait states before the inline-asm packed adds (kernels_wino.hip)
             const f32x2 c2 = {2.f, 2.f}, c4 = {4.f, 4.f}, c8 = {8.f, 8.f};
+            if constexpr (LS != 0) {
+                // ---- ConvLSTM: gates = A_y^T M A_x (+ gx), cell update, c lane-native, h as NHWC ----
+                // this lane: hidden channel 4 wave + g of the 2 x 4 pixels of tile q; its f32x4 after the output transform is (i, j, f, o)
+                const size_t rows_per_wave = (size_t)CTB * 8;
+                const size_t row_w = (((size_t)n * regions + r) * 4 + wave) * rows_per_wave;          // this item's lane-slot rows (c_out, mode 1 gx)
+                float *const c_out = a.ls_c_out + (LS == 1 ? (size_t)grp * a.ls_c_dir : 0) + row_w * 64 + lane;
+                float *const h_out = a.out + (LS == 1 ? (size_t)grp * a.ls_h_dir : 0);
+                f32x4 gxv[CTB][8];
+                float cv[CTB][8];
+                V4 T0[CTB][6], T1[CTB][6];
+                [[maybe_unused]] const float *gx_r = nullptr, *c_r = nullptr;
+                [[maybe_unused]] float *gx_w = nullptr;
+                if constexpr (LS == 2) {
+                    const int fm = __builtin_amdgcn_readfirstlane(a.ls_gx_map[n]);
+                    const int ci = a.in0_map ? __builtin_amdgcn_readfirstlane(a.in0_map[n]) : n;
+                    gx_r = a.ls_gx + ((((size_t)fm * regions + r) * 4 + wave) * rows_per_wave * 64 + lane) * 4;
+                    c_r = a.ls_c_in + (((size_t)ci * regions + r) * 4 + wave) * rows_per_wave * 64 + lane;
+                } else {
+                    gx_w = a.ls_gx + (size_t)grp * a.ls_gx_dir + (row_w * 64 + lane) * 4;
+                }
+#pragma unroll
+                for (int tb = 0; tb < CTB; ++tb) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {       // rows: t = A_y^T M
+                        const V4 m0 = to4(acc[j][tb]), m1 = to4(acc[6 + j][tb]), m2 = to4(acc[12 + j][tb]), m3 = to4(acc[18 + j][tb]);
+                        T0[tb][j] = (m0 + m1) + m2;
+                        T1[tb][j] = (m1 - m2) - m3;
+                    }
+                    if constexpr (LS == 2) {            // this tile block's gx and c on their way while the next block's rows are formed
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            gxv[tb][e] = ld4(gx_r + (size_t)(tb * 8 + e) * 256);
+                            cv[tb][e] = c_r[(size_t)(tb * 8 + e) * 64];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int tb = 0; tb < CTB; ++tb) {
+                    const int q = (tb + tbk) * 16 + t16;
+                    const int oy = (ry * TRY + q / TRX) * 2, ox = (rx * TRX + q % TRX) * 4;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const V4 (&t)[6] = i == 0 ? T0[tb] : T1[tb];
+                        const V4 s1 = t[1] + t[2], d1 = t[1] - t[2], s2 = t[3] + t[4], d2 = t[3] - t[4];
+                        V4 y[4];
+                        y[0] = (t[0] + s1) + s2;
+                        y[1] = fma4(d2, c2, d1);
+                        y[2] = fma4(s2, c4, s1);
+                        y[3] = fma4(d2, c8, d1) + t[5];
+                        unsigned hb[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            f32x4 gt = from4(y[j]);
+                            float c = 0.f;
+                            if constexpr (LS == 2) { gt += gxv[tb][i * 4 + j]; c = cv[tb][i * 4 + j]; }
+                            else st4(gx_w + (size_t)(tb * 8 + i * 4 + j) * 256, gt);
+                            const float hv = ls_cell(gt, c, a.ls_forget_bias);
+                            c_out[(size_t)(tb * 8 + i * 4 + j) * 64] = c;
+                            hb[j] = __builtin_bit_cast(unsigned, hv);
+                        }
+                        // 4 x 4 transpose over (pixel column j, lane group g): afterwards register e of lane group g is hidden channel 4 wave + e
+                        // of pixel column g -- one 16-byte piece of the NHWC map per lane
+                        const auto s02 = __builtin_amdgcn_permlane32_swap(hb[0], hb[2], false, false);
+                        const auto s13 = __builtin_amdgcn_permlane32_swap(hb[1], hb[3], false, false);
+                        const auto p01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+                        const auto p23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+                        // (elements copied to scalars first: __builtin_bit_cast on a vector ELEMENT expression reads element 0, hipcc 7.2)
+                        const unsigned u0 = p01[0], u1 = p01[1], u2 = p23[0], u3 = p23[1];
+                        const f32x4 hv4 = {__builtin_bit_cast(float, u0), __builtin_bit_cast(float, u1), __builtin_bit_cast(float, u2), __builtin_bit_cast(float, u3)};
+                        if (oy + i < a.Ho && ox + g < a.Wo) st4(h_out + ((size_t)(n * a.Ho + oy + i) * a.Wo + ox + g) * 16 + 4 * wave, hv4);
+                    }
+                }
+            } else {
 #pragma unroll
             for (int tb = 0; tb < CTB; ++tb) {
                 const int q = (tb + tbk) * 16 + t16;
@@ -461,6 +551,7 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
                         if (oy + i < a.Ho && ox + j < a.Wo) st4(o00 + i * dy + j * dx, v);
                     }
                 }
+            }
             }
             STAMP(sc3)
             STAMP_DO(ce += sc3 - sc2;)
@@ -508,6 +599,46 @@ hipError_t launch_wino24(const ConvArgs &a, int tile_cols, int pair, int ncb, hi
     if (ncb != 4) return hipErrorInvalidValue;
     if (pair) return (tile_cols == 16 && a.Ho % 8 == 4 && a.Ho == a.H) ? launch_wino24_t<1, true, 4>(a, s) : hipErrorInvalidValue;
     return tile_cols == 32 ? launch_wino24_t<2, false, 4>(a, s) : tile_cols == 16 ? launch_wino24_t<1, false, 4>(a, s) : hipErrorInvalidValue;
+}
+
+template <int TBW, int LS>
+static hipError_t launch_wino24_lstm_t(const ConvArgs &a, hipStream_t s) {
+    using G = W24<TBW, false>;
+    const int n_cu = device_cu_count();
+    static OncePerDevice lds_ok;
+    hipError_t e = allow_dynamic_lds(lds_ok, reinterpret_cast<const void *>(wino24_pc_kernel<TBW, false, 4, LS>), G::LDS_FLOATS * 4);
+    if (e != hipSuccess) return e;
+    const int regs_x = (a.Wo + 4 * G::TRX - 1) / (4 * G::TRX);
+    const long long nitems = (long long)((a.Ho + 2 * TRY - 1) / (2 * TRY)) * a.N * regs_x * (a.Cout / 64);
+    dim3 grid((unsigned)(nitems < n_cu ? nitems : n_cu));
+    hipLaunchKernelGGL((wino24_pc_kernel<TBW, false, 4, LS>), grid, dim3(512), G::LDS_FLOATS * 4, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_wino24_lstm(const ConvArgs &a, int tile_cols, hipStream_t s) {
+    if ((a.ls_mode != 1 && a.ls_mode != 2) || a.C0 != WKC || a.C1 || a.up2 || a.H != a.Ho || a.W != a.Wo || (tile_cols != 32 && tile_cols != 16)) return hipErrorInvalidValue;
+    if (a.ls_mode == 1 ? (a.Cout != 64 && a.Cout != 128) || a.in0_map || !a.bias || !a.ls_gx || !a.ls_c_out : a.Cout != 64 || !a.ls_gx || !a.ls_gx_map || !a.ls_c_in || !a.ls_c_out)
+        return hipErrorInvalidValue;
+    if (a.ls_mode == 1) return tile_cols == 32 ? launch_wino24_lstm_t<2, 1>(a, s) : launch_wino24_lstm_t<1, 1>(a, s);
+    return tile_cols == 32 ? launch_wino24_lstm_t<2, 2>(a, s) : launch_wino24_lstm_t<1, 2>(a, s);
+}
+
+static size_t lstm_regions(int Ho, int Wo, int tile_cols) { return (size_t)((Ho + 7) / 8) * ((Wo + tile_cols - 1) / tile_cols); }
+// per region: 4 consumer waves x (tile_cols / 16 tile blocks x 8 pixels of a tile) x 64 lanes, one float (c) or four (gx) each
+size_t wino24_lstm_c_floats(int Ho, int Wo, int tile_cols) { return lstm_regions(Ho, Wo, tile_cols) * 4 * (size_t)(tile_cols / 16) * 8 * 64; }
+size_t wino24_lstm_gx_floats(int Ho, int Wo, int tile_cols) { return 4 * wino24_lstm_c_floats(Ho, Wo, tile_cols); }
+
+size_t pack_wino24_weights(const float *w, int cin, int cout, int ncb, float *dst);
+size_t pack_lstm_gate_weights(const float *w, int cin_total, int c_first, const float *bias, float *dst, float *bias_perm) {
+    // packed channel P = 16 w + m (MFMA row m = 4 g + e of block w)  <-  original channel 16 e + (4 w + g): gate e of hidden channel 4 w + g
+    float tmp[9 * WKC * 64];
+    for (int P = 0; P < 64; ++P) {
+        const int wv = P / 16, m = P % 16, orig = (m % 4) * 16 + 4 * wv + m / 4;
+        if (bias_perm) bias_perm[P] = bias ? bias[orig] : 0.f;
+        for (int t = 0; t < 9; ++t)
+            for (int ci = 0; ci < WKC; ++ci) tmp[(t * WKC + ci) * 64 + P] = w[((size_t)t * cin_total + c_first + ci) * 64 + orig];
+    }
+    return pack_wino24_weights(tmp, WKC, 64, 4, dst);
 }
 
 size_t pack_wino24_weights(const float *w, int cin, int cout, int ncb, float *dst) {
