@@ -344,13 +344,70 @@ def other_configs_probe(device):
         t16 = rate(eng, x, n, 256, 256, pred)
         p16 = pred.cpu().numpy()
         launches = len(eng.kernel_names())
+    from ukbb_cardiac_amd.arch import fcn_macs_per_slice
+    m3u, m1u = fcn_macs_per_slice(arch, 256, 256)
+    flop5 = 2.0 * (m3u + m1u) * n
+    # algorithmic HBM bytes of the bf16 plan (tools/unet_roofline.py: every stored bf16 map written once and read once per consumer, image
+    # in, labels out; no halos, no weights); measured traffic only from a counter file collected from these very sources
+    lv = [256 * 256 * 16, 128 * 128 * 32, 64 * 64 * 64, 32 * 32 * 128, 16 * 16 * 256]
+    alg5 = 256 * 256 * 4 * 2 + lv[0] * 2 * 3 + sum(lv[l] * 2 * 2 + lv[l] * 2 * (3 if l < 4 else 2) for l in range(1, 5)) + \
+        sum(lv[l] * 2 * 2 * (3 if l > 0 else 1) for l in range(3, -1, -1))
+    alg5 *= n
+    tr5, tr5_src = None, 'no counter file of this build (tools/profile_unet.sh)'
+    try:
+        import glob
+        for c in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_unet_traffic.json')), reverse=True):
+            tj = json.load(open(c))
+            if tj.get('kernel_source_sha') == kernel_source_sha():
+                tr5, tr5_src = tj['hbm_bytes_per_forward'], os.path.relpath(c, ROOT)
+                break
+    except Exception:
+        pass
     out['config5_aortic_unet'] = {
+        'roofline': {'mfma': {'dtype': 'bf16', 'achieved': round(flop5 / t16 / 1e12, 1), 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': round(flop5 / t16 / 2.5e15, 4),
+                              'flop_per_forward': flop5, 'note': 'algorithmic FLOPs of the 100-slice forward / wall time of the bf16 forward'},
+                     'hbm': {'achieved': round(alg5 / t16 / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(alg5 / t16 / 8e12, 4),
+                             'algorithmic_bytes_per_forward': alg5, 'traffic': tr5, 'traffic_source': tr5_src,
+                             'frac_measured_traffic': None if tr5 is None else round(tr5 / t16 / 8e12, 4)},
+                     'bound': 'neither roof binds: per-kernel table in profiles/'},
         'workload': 'UNet_ao (network_ao.py:18-64), N = 100 x 256x256 resident in HBM, int32 labels out',
         'fp32': {'value': round(n / t32, 1), 'unit': 'slices/s', 'ms_per_step': round(t32 * 1e3, 4)},
         'bf16': {'value': round(n / t16, 1), 'unit': 'slices/s', 'ms_per_step': round(t16 * 1e3, 4), 'dtype': 'bf16 MFMA operands, fp32 accumulation, '
                  'bf16 activations in HBM', 'kernel_launches': launches,
                  'dice_vs_fp32': {'class1': round(float(np_categorical_dice(p16, p32, 1)), 4), 'class2': round(float(np_categorical_dice(p16, p32, 2)), 4)},
                  'label_disagreement': round(float((p16 != p32).mean()), 5)}}
+    # the reference's DEFAULT aortic model (demo_pipeline.py:116-117): one slice position, 100 frames, circular 9-frame windows
+    arch = MODELS['UNet-LSTM_ao']
+    F = 100
+    prob = torch.empty((F, 256, 256, 3), dtype=torch.float32, device=device)
+    with Engine(arch, synthetic_params(arch, 1234), device=device.index) as eng:
+        def cine(k):
+            for _ in range(k):
+                eng.run_cine_device(x.data_ptr(), F, 256, 256, prob.data_ptr(), pred.data_ptr())
+            torch.cuda.synchronize()
+        cine(2)
+        t0 = time.perf_counter()
+        cine(5)
+        tl = (time.perf_counter() - t0) / 5
+    # reference-graph FLOPs with the features computed once per frame (the reference recomputes the U-Net for each of the 9 window positions):
+    # U-Net + per window 18 gate convs (3x3, 32 -> 64) + 9 output convs -- an "effective" figure, not a utilisation (the x half of the gate
+    # conv is hoisted out of the time loop and the rest runs as Winograd F(2x4))
+    hw = 256 * 256
+    flop_l = F * (2.0 * (m3u + m1u) + 2 * 9 * hw * (9 * 32 * 64) * 2.0 + 9 * hw * 32 * 3 * 2.0)
+    # algorithmic HBM bytes of the ConvLSTM part as this implementation lays it out (fp32): per time step gx 64 ch + h in 16 + c in / out 16 + 16 +
+    # h out 16 (16 steps), the x pass (x in 16, gx out 2 x 64, c1 / h1 out 2 x 32), the output pass (18 hidden maps in, prob + labels out)
+    px = F * hw * 4.0
+    bytes_l = 16 * (64 + 16 + 32 + 16) * px + (16 + 128 + 64) * px + (18 * 16 + 4) * px
+    out['unet_lstm_cine'] = {
+        'workload': 'UNet-LSTM_ao (network_ao.py:255-399 + the window tiling of deploy_network_ao.py:129-183): one slice position, 100 frames '
+                    'of 256x256 resident in HBM, fp32; prob [F,H,W,3] + int32 labels out',
+        'value': round(F / tl, 1), 'unit': 'frames/s', 'ms_per_cine': round(tl * 1e3, 3),
+        'roofline': {'bound': 'hbm', 'peak': 8000.0, 'unit': 'GB/s',
+                     'achieved': round(bytes_l / tl / 1e9, 1), 'frac': round(bytes_l / tl / 8e12, 4),
+                     'algorithmic_bytes_lstm_part': bytes_l, 'traffic': None,
+                     'note': 'ConvLSTM part only (the U-Net features of the 100 frames add ~4 ms of MFMA-bound work to the same wall time, so this '
+                             'is a lower bound of the rate the LSTM kernels reach); per-kernel times and counter traffic: profiles/r05_unet_lstm_*',
+                     'effective_tflops_reference_graph_features_once': round(flop_l / tl / 1e12, 1)}}
     arch = MODELS['FCN_sa']
     x10 = torch.from_numpy(uniform_slices(10, H, W, seed=1)).to(device)
     pred10 = torch.empty((10, H, W), dtype=torch.int32, device=device)

@@ -233,3 +233,35 @@ def test_aortic_script_read_ahead_write_behind_gives_the_sequential_files(tmp_pa
     assert sorted(out[0][0]) == ['s00/seg_ao.nii.gz', 's01/seg_ao.nii.gz', 's02/seg_ao.nii.gz', 's04/seg_ao.nii.gz']
     assert out[0][0] == out[3][0]
     assert out[0][1] == out[3][1]                                           # same log lines in the same order
+
+
+def test_bf16_cine_dice_vs_fp32(model):
+    """ukbb_fcn_set_precision(UKBB_PREC_BF16) on a UNet-LSTM handle (the script accepts --precision bf16 with the default
+    model): the U-Net runs its bf16-storage plan, the ConvLSTM keeps gx and the hidden maps as bf16 in HBM (cell state and arithmetic
+    fp32).  One 100-frame 256 x 256 cine against the fp32 path of the same handle: per-class Dice (common/image_utils.py:171-175) >= 0.98
+    over the cine and >= 0.97 on every frame where the class is populated; pred = argmax(prob); switching back is exact."""
+    from ukbb_cardiac_amd.image_utils import np_categorical_dice
+    from ukbb_cardiac_amd.phantom import cine_phantom
+    arch, params, eng = model
+    frames = ((cine_phantom(100, 256, 256, seed=17)[..., 0] - 0.3) / 0.25).astype(np.float32)
+    prob32, pred32 = eng.run_cine(frames)
+    eng.set_precision('bf16')
+    try:
+        prob16, pred16 = eng.run_cine(frames)
+        names = eng.kernel_names()
+        seq16 = eng.run_seq(frames[None, :9], want_logits=True)
+    finally:
+        eng.set_precision('fp32')
+    again = eng.run_cine(frames)
+    assert np.array_equal(again[0], prob32) and np.array_equal(again[1], pred32)
+    assert names[0] == 'conv0_0+conv0_1', names                             # the bf16-storage plan (fused stem), not the r01 operand-only mode
+    assert np.array_equal(pred16, np.argmax(prob16, -1)) and np.isfinite(prob16).all()
+    assert np.array_equal(seq16['pred'], np.argmax(seq16['prob'], -1))
+    rel = np.abs(prob16 - prob32).max()
+    assert 1e-6 < rel < 0.5, rel                                             # really another precision, and sane
+    assert len(np.unique(pred32)) == 3
+    for k in (1, 2):
+        d = float(np_categorical_dice(pred16, pred32, k))
+        worst = min(float(np_categorical_dice(pred16[i], pred32[i], k)) for i in range(100) if (pred32[i] == k).sum() > 500)
+        assert d >= 0.98 and worst >= 0.97, (k, d, worst)
+    assert (pred16 != pred32).mean() < 0.02

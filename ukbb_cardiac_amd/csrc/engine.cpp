@@ -560,7 +560,9 @@ int ensure_packed(ukbb_fcn_handle *h, int layer, const ConvConfig &c, const floa
 
 // UKBB_PREC_BF16 on the aortic U-Net: bf16 operands AND bf16 activations in HBM between all layers (r03);
 // on the other graphs: bf16 operands, fp32 storage (r01).
-int bf16_mode(const ukbb_fcn_handle *h) { return h->precision != 1 ? 0 : h->arch.kind == UKBB_KIND_UNET ? 2 : 1; }
+// r05: the U-Net of a UNet-LSTM handle takes the same bf16-storage plan (its last map, net['conv0_up'], feeds the ConvLSTM as bf16; the
+// LSTM then keeps gx and the hidden maps in bf16 as well, cell state and arithmetic fp32: run_bilstm)
+int bf16_mode(const ukbb_fcn_handle *h) { return h->precision != 1 ? 0 : h->arch.kind != UKBB_KIND_FCN ? 2 : 1; }
 
 // bf16 storage: the fused variants of the level-0 tilings (ConvConfig::fuse: 1 = first layer in the staging, 2 = logits in the
 // epilogue), first fit in measured order; -1 if none fits (the plan then keeps that layer as a launch of its own).
@@ -695,7 +697,7 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
                                   (bf16_mode(h) != 2 || pick_fused_bf_cfg("conv0_1", 3, 1, 16, 0, 16, H, W, 1) >= 0);
             // bf16 storage with the standard 1 -> 16 -> 16 stem: conv0_0 and conv0_1 as ONE launch of kernels_stem.hip
             // (UKBB_NO_FUSE_STEM=1: the r03 form, conv0_0 evaluated in conv0_1's staging)
-            const bool stem = a.kind == UKBB_KIND_UNET && bf16_mode(h) == 2 && getenv("UKBB_NO_FUSE_STEM") == nullptr && a.n_block[0] >= 2 &&
+            const bool stem = a.kind != UKBB_KIND_FCN && bf16_mode(h) == 2 && getenv("UKBB_NO_FUSE_STEM") == nullptr && a.n_block[0] >= 2 &&
                               a.n_filter[0] == 16 && override_cfg("conv0_1") < 0;
             if (l == 0 && i == 0 && stem) continue;
             if (l == 0 && i == 1 && stem) {
@@ -1291,7 +1293,11 @@ int run_bilstm(ukbb_fcn_handle *h, const float *feat, int NF, const int *d_map, 
     HIP_TRY(h->lstm_h1.ensure(2 * (size_t)NF * HW * NHID), UKBB_ENOMEM);
     HIP_TRY(h->lstm_c.ensure((size_t)Wn * cf), UKBB_ENOMEM);
     HIP_TRY(h->lstm_hall.ensure(2 * (size_t)T * Wn * HW * NHID), UKBB_ENOMEM);
+    const bool bf = h->plan_bfio;                        // bf16 plan: features, gx and hidden maps are bf16 in HBM
+    const size_t esz = bf ? 2 : 4;
+    auto at = [esz](float *p, size_t elems) { return reinterpret_cast<float *>(reinterpret_cast<char *>(p) + elems * esz); };
     ConvArgs base{};
+    base.ls_bf16 = bf ? 1 : 0;
     base.C0 = a.n_filter[0]; base.C1 = 0;
     base.H = H; base.W = W; base.Ho = H; base.Wo = W;
     base.pad_y = 1; base.pad_x = 1; base.relu = 0;
@@ -1308,23 +1314,23 @@ int run_bilstm(ukbb_fcn_handle *h, const float *feat, int NF, const int *d_map, 
     }
     const size_t kst = (size_t)Wn * HW * NHID;           // one step's hidden maps
     for (int dir = 0; dir < 2; ++dir) {
-        float *const hall = h->lstm_hall.p + (size_t)dir * T * kst;
+        float *const hall = at(h->lstm_hall.p, (size_t)dir * T * kst);
         for (int step = 1; step < T; ++step) {
             const int k = dir ? T - 1 - step : step, kprev = dir ? k + 1 : k - 1;
             ConvArgs ca = base;
             ca.N = Wn; ca.Cout = 4 * NHID;
             ca.wpk = dev_ptr(h, dir ? "lstm_bw/wh" : "lstm_fw/wh"); ca.bias = nullptr;
             ca.ls_mode = 2;
-            ca.ls_gx = h->lstm_gx.p + (size_t)dir * NF * gxf; ca.ls_gx_map = d_map + (size_t)k * Wn;
+            ca.ls_gx = at(h->lstm_gx.p, (size_t)dir * NF * gxf); ca.ls_gx_map = d_map + (size_t)k * Wn;
             if (step == 1) {                                // previous state = the x pass's per-frame first step
-                ca.in0 = h->lstm_h1.p + (size_t)dir * NF * HW * NHID; ca.in0_map = d_map + (size_t)kprev * Wn;
+                ca.in0 = at(h->lstm_h1.p, (size_t)dir * NF * HW * NHID); ca.in0_map = d_map + (size_t)kprev * Wn;
                 ca.ls_c_in = h->lstm_c1.p + (size_t)dir * NF * cf;
             } else {
-                ca.in0 = hall + (size_t)kprev * kst; ca.in0_map = nullptr;
+                ca.in0 = at(hall, (size_t)kprev * kst); ca.in0_map = nullptr;
                 ca.ls_c_in = h->lstm_c.p;
             }
             ca.ls_c_out = h->lstm_c.p;
-            ca.out = hall + (size_t)k * kst;
+            ca.out = at(hall, (size_t)k * kst);
             hipError_t e = launch_wino24_lstm(ca, tc, s);
             if (e != hipSuccess) { set_err("ConvLSTM step launch failed: %s", hipGetErrorString(e)); return UKBB_EDEVICE; }
         }
@@ -1375,9 +1381,12 @@ int ukbb_fcn_forward_seq(ukbb_fcn_handle *h, const float *image, int n_seq, int 
     const size_t kst = (size_t)n_seq * HW * NHID;
     for (int k = 0; k < T; ++k) {                                            // outputs straight into [N][T] order
         LstmOutArgs oa{};
-        oa.hf = k == 0 ? h->lstm_h1.p : h->lstm_hall.p + (size_t)k * kst;
+        const size_t esz = h->plan_bfio ? 2 : 4;
+        auto at = [esz](const float *p, size_t elems) { return reinterpret_cast<const float *>(reinterpret_cast<const char *>(p) + elems * esz); };
+        oa.h_bf16 = h->plan_bfio ? 1 : 0;
+        oa.hf = k == 0 ? h->lstm_h1.p : at(h->lstm_hall.p, (size_t)k * kst);
         oa.mapf = k == 0 ? d_map : nullptr;
-        oa.hb = k == T - 1 ? h->lstm_h1.p + (size_t)NF * HW * NHID : h->lstm_hall.p + (size_t)T * kst + (size_t)k * kst;
+        oa.hb = k == T - 1 ? at(h->lstm_h1.p, (size_t)NF * HW * NHID) : at(h->lstm_hall.p, (size_t)T * kst + (size_t)k * kst);
         oa.mapb = k == T - 1 ? d_map + (size_t)(T - 1) * n_seq : nullptr;
         oa.w_out = dev_ptr(h, "lstm_out/w"); oa.b_out = dev_ptr(h, "lstm_out/bias");
         oa.prob = out + (size_t)k * HW * C;
@@ -1458,8 +1467,13 @@ int ukbb_fcn_forward_cine(ukbb_fcn_handle *h, const float *image, int n_frames, 
     const int NHID = h->arch.same_dim;
     LstmTileArgs ta{};
     ta.k_stride = (long long)Wn * HW * NHID;
-    ta.hf = h->lstm_hall.p; ta.hb = h->lstm_hall.p + (size_t)T * ta.k_stride;
-    ta.h1f = h->lstm_h1.p; ta.h1b = h->lstm_h1.p + (size_t)F * HW * NHID;
+    {
+        const size_t esz = h->plan_bfio ? 2 : 4;
+        auto at = [esz](const float *p, size_t elems) { return reinterpret_cast<const float *>(reinterpret_cast<const char *>(p) + elems * esz); };
+        ta.h_bf16 = h->plan_bfio ? 1 : 0;
+        ta.hf = h->lstm_hall.p; ta.hb = at(h->lstm_hall.p, (size_t)T * ta.k_stride);
+        ta.h1f = h->lstm_h1.p; ta.h1b = at(h->lstm_h1.p, (size_t)F * HW * NHID);
+    }
     ta.map_first = d_map; ta.map_last = d_map + (size_t)(T - 1) * Wn;
     ta.w_out = dev_ptr(h, "lstm_out/w"); ta.b_out = dev_ptr(h, "lstm_out/bias");
     ta.order = reinterpret_cast<const int *>(aux + off_ord);

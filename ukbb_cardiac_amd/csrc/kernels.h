@@ -113,6 +113,8 @@ struct ConvArgs {
     float *ls_c_out;
     long long ls_gx_dir, ls_c_dir, ls_h_dir;   // mode 1: floats between the two directions' halves of ls_gx / ls_c_out / out
     float ls_forget_bias;
+    int ls_bf16;                // 1: in0, gx and the hidden maps (out) are bf16 in HBM (UKBB_PREC_BF16 on a UNet-LSTM handle); c stays fp32.
+                                //    Strides (ls_*_dir) still count ELEMENTS; ls_gx_dir counts gx values (4 per lane-slot)
 };
 
 // One compiled tiling of the conv kernel.
@@ -301,6 +303,7 @@ struct LstmOutArgs {        // one time step's outputs from the two directions' 
     int32_t *pred;          // optional: argmax at pred + m*(m_stride/n_class) + pix
     long long m_stride;     // floats between consecutive windows in prob / logits
     int M, HW, n_class;
+    int h_bf16;             // 1: hf / hb hold bf16
 };
 hipError_t launch_lstm_out(const LstmOutArgs &a, hipStream_t s);
 
@@ -317,6 +320,7 @@ struct LstmTileArgs {       // per-(window, step) outputs + the weighted tiling 
     float *prob;            // [F][HW][C]
     int32_t *pred;          // [F][HW]
     int F, K, Wn, HW, C;
+    int h_bf16;             // 1: hf / hb / h1f / h1b hold bf16 (k_stride still counts elements)
 };
 hipError_t launch_lstm_tile(const LstmTileArgs &a, hipStream_t s);
 

@@ -20,20 +20,43 @@ namespace {
 
 constexpr int NH = 16;                       // hidden channels (train_network_ao.py num_hidden = 16)
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// 16 hidden channels of one pixel, fp32 or bf16 in memory
+template <bool BF>
+__device__ __forceinline__ void load_h16(const float *base, long long elem, float (&v)[NH]) {
+    if constexpr (BF) {
+        const u32x4 *p = reinterpret_cast<const u32x4 *>(reinterpret_cast<const unsigned short *>(base) + elem);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const u32x4 d = p[q];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned w = d[i];
+                v[8 * q + 2 * i] = __builtin_bit_cast(float, w << 16);
+                v[8 * q + 2 * i + 1] = __builtin_bit_cast(float, w & 0xffff0000u);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < NH / 4; ++q) {
+            const f32x4 d = *reinterpret_cast<const f32x4 *>(base + elem + 4 * q);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[4 * q + i] = d[i];
+        }
+    }
+}
+
 // logits of one pixel: W[0:16] . h_fw + W[16:32] . h_bw + b (each direction's sum formed on its own, ascending hidden channel)
 template <int NCLS>
-__device__ __forceinline__ void out_conv(const float *hf, const float *hb, const float (&w)[2 * NH][NCLS], const float (&b)[NCLS], float (&lg)[NCLS]) {
+__device__ __forceinline__ void out_conv(const float (&vf)[NH], const float (&vb)[NH], const float (&w)[2 * NH][NCLS], const float (&b)[NCLS], float (&lg)[NCLS]) {
     float pf[NCLS], pb[NCLS];
 #pragma unroll
     for (int k = 0; k < NCLS; ++k) { pf[k] = 0.f; pb[k] = 0.f; }
 #pragma unroll
-    for (int q = 0; q < NH / 4; ++q) {
-        const f32x4 vf = *reinterpret_cast<const f32x4 *>(hf + 4 * q), vb = *reinterpret_cast<const f32x4 *>(hb + 4 * q);
+    for (int i = 0; i < NH; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int k = 0; k < NCLS; ++k) { pf[k] = fmaf(vf[i], w[4 * q + i][k], pf[k]); pb[k] = fmaf(vb[i], w[NH + 4 * q + i][k], pb[k]); }
-    }
+        for (int k = 0; k < NCLS; ++k) { pf[k] = fmaf(vf[i], w[i][k], pf[k]); pb[k] = fmaf(vb[i], w[NH + i][k], pb[k]); }
 #pragma unroll
     for (int k = 0; k < NCLS; ++k) lg[k] = (pf[k] + pb[k]) + b[k];
 }
@@ -49,7 +72,7 @@ __device__ __forceinline__ void load_out_weights(const float *w_out, const float
 }
 
 // one thread = one pixel of one window
-template <int NCLS>
+template <int NCLS, bool BF>
 __global__ __launch_bounds__(256) void lstm_out_kernel(const LstmOutArgs a) {
     float w[2 * NH][NCLS], b[NCLS];
     load_out_weights<NCLS>(a.w_out, a.b_out, w, b);
@@ -57,8 +80,10 @@ __global__ __launch_bounds__(256) void lstm_out_kernel(const LstmOutArgs a) {
     for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
         const long long m = id / a.HW, pix = id - m * a.HW;
         const long long mf = a.mapf ? a.mapf[m] : m, mb = a.mapb ? a.mapb[m] : m;
-        float lg[NCLS], pr[NCLS];
-        out_conv<NCLS>(a.hf + (mf * a.HW + pix) * NH, a.hb + (mb * a.HW + pix) * NH, w, b, lg);
+        float lg[NCLS], pr[NCLS], vf[NH], vb[NH];
+        load_h16<BF>(a.hf, (mf * a.HW + pix) * NH, vf);
+        load_h16<BF>(a.hb, (mb * a.HW + pix) * NH, vb);
+        out_conv<NCLS>(vf, vb, w, b, lg);
         const int best = softmax_argmax<NCLS>(lg, pr);
         float *po = a.prob + m * a.m_stride + pix * NCLS;
 #pragma unroll
@@ -77,7 +102,7 @@ __global__ __launch_bounds__(256) void lstm_out_kernel(const LstmOutArgs a) {
 //   a frame no window reaches (time_step > window) has wsum = 0: 0/0 = NaN and argmax 0, as numpy gives the reference
 //   reference arithmetic: prob is float32, `prob[..., idx] += prob_idx * w` runs in float64 and is cast back
 //   per addition; `prob /= weight` likewise (deploy_network_ao.py:176-183).
-template <int NCLS>
+template <int NCLS, bool BF>
 __global__ __launch_bounds__(256) void lstm_tile_kernel(const LstmTileArgs a) {
     float w[2 * NH][NCLS], b[NCLS];
     load_out_weights<NCLS>(a.w_out, a.b_out, w, b);
@@ -94,10 +119,10 @@ __global__ __launch_bounds__(256) void lstm_tile_kernel(const LstmTileArgs a) {
             const int wi = wk_ / a.K, k = wk_ - wi * a.K;
             // the first step of a direction comes from the per-FRAME maps of the x pass, later steps from that direction's per-window maps
             const long long mf = k == 0 ? a.map_first[wi] : wi, mb = k == a.K - 1 ? a.map_last[wi] : wi;
-            const float *hf = (k == 0 ? a.h1f : a.hf + (long long)k * a.k_stride) + (mf * a.HW + pix) * NH;
-            const float *hb = (k == a.K - 1 ? a.h1b : a.hb + (long long)k * a.k_stride) + (mb * a.HW + pix) * NH;
-            float lg[NCLS], p[NCLS];
-            out_conv<NCLS>(hf, hb, w, b, lg);
+            float lg[NCLS], p[NCLS], vf[NH], vb[NH];
+            load_h16<BF>(k == 0 ? a.h1f : a.hf, (k == 0 ? 0 : (long long)k * a.k_stride) + (mf * a.HW + pix) * NH, vf);
+            load_h16<BF>(k == a.K - 1 ? a.h1b : a.hb, (k == a.K - 1 ? 0 : (long long)k * a.k_stride) + (mb * a.HW + pix) * NH, vb);
+            out_conv<NCLS>(vf, vb, w, b, lg);
             (void)softmax_argmax<NCLS>(lg, p);
             const double wt = a.wk[k];
 #pragma unroll
@@ -122,10 +147,14 @@ hipError_t launch_lstm_out(const LstmOutArgs &a, hipStream_t s) {
     const long long total = (long long)a.M * a.HW;
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    switch (a.n_class) {
-        case 2: hipLaunchKernelGGL(lstm_out_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, a); break;
-        case 3: hipLaunchKernelGGL(lstm_out_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, s, a); break;
-        case 4: hipLaunchKernelGGL(lstm_out_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, a); break;
+    const dim3 g((unsigned)blocks), t(256);
+    switch (a.n_class * 2 + (a.h_bf16 ? 1 : 0)) {
+        case 4: hipLaunchKernelGGL((lstm_out_kernel<2, false>), g, t, 0, s, a); break;
+        case 5: hipLaunchKernelGGL((lstm_out_kernel<2, true>), g, t, 0, s, a); break;
+        case 6: hipLaunchKernelGGL((lstm_out_kernel<3, false>), g, t, 0, s, a); break;
+        case 7: hipLaunchKernelGGL((lstm_out_kernel<3, true>), g, t, 0, s, a); break;
+        case 8: hipLaunchKernelGGL((lstm_out_kernel<4, false>), g, t, 0, s, a); break;
+        case 9: hipLaunchKernelGGL((lstm_out_kernel<4, true>), g, t, 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -135,10 +164,14 @@ hipError_t launch_lstm_tile(const LstmTileArgs &a, hipStream_t s) {
     const long long total = (long long)a.F * a.HW;
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    switch (a.C) {
-        case 2: hipLaunchKernelGGL(lstm_tile_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, a); break;
-        case 3: hipLaunchKernelGGL(lstm_tile_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, s, a); break;
-        case 4: hipLaunchKernelGGL(lstm_tile_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, a); break;
+    const dim3 g((unsigned)blocks), t(256);
+    switch (a.C * 2 + (a.h_bf16 ? 1 : 0)) {
+        case 4: hipLaunchKernelGGL((lstm_tile_kernel<2, false>), g, t, 0, s, a); break;
+        case 5: hipLaunchKernelGGL((lstm_tile_kernel<2, true>), g, t, 0, s, a); break;
+        case 6: hipLaunchKernelGGL((lstm_tile_kernel<3, false>), g, t, 0, s, a); break;
+        case 7: hipLaunchKernelGGL((lstm_tile_kernel<3, true>), g, t, 0, s, a); break;
+        case 8: hipLaunchKernelGGL((lstm_tile_kernel<4, false>), g, t, 0, s, a); break;
+        case 9: hipLaunchKernelGGL((lstm_tile_kernel<4, true>), g, t, 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -30,6 +30,8 @@ namespace ukbb {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -124,8 +126,11 @@ __device__ unsigned long long g_w24stamps[8];
 // NCB = 16-channel blocks per item: 4 (64 output channels, consumer wave w = block w, all tile blocks) or 2 (32 output channels, TBW = 2 only:
 // wave w = block w & 1 of tile block w >> 1 -- layers with 32 output channels, which are bound by the producers in the F(2x2) kernel)
 // LS: 0 = plain conv; 1 | 2 = ConvLSTM cell in the epilogue (ConvArgs::ls_mode; the producers and the MFMA phase are the plain ones)
-template <int TBW, bool PAIR, int NCB, int LS = 0>
+// BF (LS != 0 only; UKBB_PREC_BF16 on a UNet-LSTM handle): source 0, gx and the hidden maps are bf16 in HBM (the arithmetic stays fp32
+// Winograd on the widened values, the cell state stays fp32): the time steps are bound by their bytes, not by the matrix pipe
+template <int TBW, bool PAIR, int NCB, int LS = 0, bool BF = false>
 __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
+    static_assert(!BF || LS != 0, "bf16 storage exists in the ConvLSTM forms only");
     using G = W24<TBW, PAIR>;
     static_assert(NCB == 4 || (NCB == 2 && TBW == 2 && !PAIR), "32-channel items come with 8 x 32-pixel regions");
     static_assert(LS == 0 || (NCB == 4 && !PAIR), "the ConvLSTM epilogue needs the four gate blocks of a hidden channel quad in one wave");
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
                 if (!PAIR && cs != cur_cs) {
                     cur_cs = cs;
 #pragma unroll
-                    for (int it = 0; it < NITX; ++it) pre[it] = pixoff[it] * (unsigned)(cs * 4) + 16u * c4;
+                    for (int it = 0; it < NITX; ++it) pre[it] = BF ? pixoff[it] * (unsigned)(cs * 2) + 8u * c4 : pixoff[it] * (unsigned)(cs * 4) + 16u * c4;
                 }
                 if constexpr (PAIR) {                   // the seam's lower six raw rows lie two flat rows earlier: offsets per item
                     cur_cs = cs;
@@ -220,16 +225,30 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
                     vo[it] = ok ? pre[it] : 0x80000000u;    // out of range -> zeros
                 }
             }
+            if constexpr (BF) {                         // 16 bf16 channels per pixel: 8 bytes per thread, widened in storex
+                const unsigned short *sb = reinterpret_cast<const unsigned short *>(a.in0) + l_ch * WKC + ((long long)(l_n0 * a.H + l_iy0) * a.W + l_ix0) * cs;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)sb, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+                for (int it = 0; it < NITX; ++it) {
+                    const u32x2 d = __builtin_amdgcn_raw_buffer_load_b64(rs, vo[it], 0, 0);
+                    xr[it][0] = d[0]; xr[it][1] = d[1];
+                }
+            } else {
             src += ((long long)((from0 ? l_n0 : l_n) * a.H + l_iy0) * a.W + l_ix0) * cs;   // may point before the tensor; masked lanes never use it
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
             for (int it = 0; it < NITX; ++it) xr[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo[it], 0, 0);
+            }
             if (++l_ch == nchunk) { l_ch = 0; l_item += gridDim.x; if (l_item < nitems) locate(); }
         };
         auto storex = [&](auto par) {
             constexpr int B = decltype(par)::value;
 #pragma unroll
-            for (int it = 0; it < NITX; ++it) *reinterpret_cast<u32x4 *>(lds + L_XS + B * XSZ + xoff[it]) = xr[it];
+            for (int it = 0; it < NITX; ++it) {
+                u32x4 v = xr[it];
+                if constexpr (BF) { const unsigned d0 = xr[it][0], d1 = xr[it][1]; v = u32x4{d0 << 16, d0 & 0xffff0000u, d1 << 16, d1 & 0xffff0000u}; }
+                *reinterpret_cast<u32x4 *>(lds + L_XS + B * XSZ + xoff[it]) = v;
+            }
         };
         // V = B_y^T d B_x per (tile, channel quad).  The producer waves split the row positions i = 0..3 of B_y^T d
         //   (d0 - d2, d1 + d2, d2 - d1, d1 - d3):
@@ -443,19 +462,21 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
                 const size_t rows_per_wave = (size_t)CTB * 8;
                 const size_t row_w = (((size_t)n * regions + r) * 4 + wave) * rows_per_wave;          // this item's lane-slot rows (c_out, mode 1 gx)
                 float *const c_out = a.ls_c_out + (LS == 1 ? (size_t)grp * a.ls_c_dir : 0) + row_w * 64 + lane;
-                float *const h_out = a.out + (LS == 1 ? (size_t)grp * a.ls_h_dir : 0);
+                constexpr int HB = BF ? 2 : 4, GB = BF ? 8 : 16;        // bytes per hidden value / per lane-slot of gx (four gates)
+                unsigned char *const h_out = reinterpret_cast<unsigned char *>(a.out) + (LS == 1 ? (size_t)grp * a.ls_h_dir * HB : 0);
                 f32x4 gxv[CTB][8];
                 float cv[CTB][8];
                 V4 T0[CTB][6], T1[CTB][6];
-                [[maybe_unused]] const float *gx_r = nullptr, *c_r = nullptr;
-                [[maybe_unused]] float *gx_w = nullptr;
+                [[maybe_unused]] const unsigned char *gx_r = nullptr;
+                [[maybe_unused]] const float *c_r = nullptr;
+                [[maybe_unused]] unsigned char *gx_w = nullptr;
                 if constexpr (LS == 2) {
                     const int fm = __builtin_amdgcn_readfirstlane(a.ls_gx_map[n]);
                     const int ci = a.in0_map ? __builtin_amdgcn_readfirstlane(a.in0_map[n]) : n;
-                    gx_r = a.ls_gx + ((((size_t)fm * regions + r) * 4 + wave) * rows_per_wave * 64 + lane) * 4;
+                    gx_r = reinterpret_cast<const unsigned char *>(a.ls_gx) + ((((size_t)fm * regions + r) * 4 + wave) * rows_per_wave * 64 + lane) * GB;
                     c_r = a.ls_c_in + (((size_t)ci * regions + r) * 4 + wave) * rows_per_wave * 64 + lane;
                 } else {
-                    gx_w = a.ls_gx + (size_t)grp * a.ls_gx_dir + (row_w * 64 + lane) * 4;
+                    gx_w = reinterpret_cast<unsigned char *>(a.ls_gx) + ((size_t)grp * a.ls_gx_dir / 4 + row_w * 64 + lane) * GB;
                 }
 #pragma unroll
                 for (int tb = 0; tb < CTB; ++tb) {
@@ -468,7 +489,14 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
                     if constexpr (LS == 2) {            // this tile block's gx and c on their way while the next block's rows are formed
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
-                            gxv[tb][e] = ld4(gx_r + (size_t)(tb * 8 + e) * 256);
+                            if constexpr (BF) {
+                                const u32x2 d = *reinterpret_cast<const u32x2 *>(gx_r + (size_t)(tb * 8 + e) * 64 * GB);
+                                const unsigned d0 = d[0], d1 = d[1];
+                                gxv[tb][e] = f32x4{__builtin_bit_cast(float, d0 << 16), __builtin_bit_cast(float, d0 & 0xffff0000u),
+                                                   __builtin_bit_cast(float, d1 << 16), __builtin_bit_cast(float, d1 & 0xffff0000u)};
+                            } else {
+                                gxv[tb][e] = ld4(reinterpret_cast<const float *>(gx_r + (size_t)(tb * 8 + e) * 64 * GB));
+                            }
                             cv[tb][e] = c_r[(size_t)(tb * 8 + e) * 64];
                         }
                     }
@@ -492,13 +520,19 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
                             f32x4 gt = from4(y[j]);
                             float c = 0.f;
                             if constexpr (LS == 2) { gt += gxv[tb][i * 4 + j]; c = cv[tb][i * 4 + j]; }
-                            else st4(gx_w + (size_t)(tb * 8 + i * 4 + j) * 256, gt);
+                            else if constexpr (BF) {    // the steps add the ROUNDED gx: the x pass's own first step uses the same values
+                                const bf16x2 lo = __builtin_convertvector(f32x2{gt[0], gt[1]}, bf16x2), hi = __builtin_convertvector(f32x2{gt[2], gt[3]}, bf16x2);
+                                const unsigned d0 = __builtin_bit_cast(unsigned, lo), d1 = __builtin_bit_cast(unsigned, hi);
+                                *reinterpret_cast<u32x2 *>(gx_w + (size_t)(tb * 8 + i * 4 + j) * 64 * GB) = u32x2{d0, d1};
+                                gt = f32x4{__builtin_bit_cast(float, d0 << 16), __builtin_bit_cast(float, d0 & 0xffff0000u),
+                                           __builtin_bit_cast(float, d1 << 16), __builtin_bit_cast(float, d1 & 0xffff0000u)};
+                            } else st4(reinterpret_cast<float *>(gx_w + (size_t)(tb * 8 + i * 4 + j) * 64 * GB), gt);
                             const float hv = ls_cell(gt, c, a.ls_forget_bias);
                             c_out[(size_t)(tb * 8 + i * 4 + j) * 64] = c;
                             hb[j] = __builtin_bit_cast(unsigned, hv);
                         }
                         // 4 x 4 transpose over (pixel column j, lane group g): afterwards register e of lane group g is hidden channel 4 wave + e
-                        // of pixel column g -- one 16-byte piece of the NHWC map per lane
+                        // of pixel column g -- one 16-byte (bf16: 8-byte) piece of the NHWC map per lane
                         const auto s02 = __builtin_amdgcn_permlane32_swap(hb[0], hb[2], false, false);
                         const auto s13 = __builtin_amdgcn_permlane32_swap(hb[1], hb[3], false, false);
                         const auto p01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
@@ -506,7 +540,13 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
                         // (elements copied to scalars first: __builtin_bit_cast on a vector ELEMENT expression reads element 0, hipcc 7.2)
                         const unsigned u0 = p01[0], u1 = p01[1], u2 = p23[0], u3 = p23[1];
                         const f32x4 hv4 = {__builtin_bit_cast(float, u0), __builtin_bit_cast(float, u1), __builtin_bit_cast(float, u2), __builtin_bit_cast(float, u3)};
-                        if (oy + i < a.Ho && ox + g < a.Wo) st4(h_out + ((size_t)(n * a.Ho + oy + i) * a.Wo + ox + g) * 16 + 4 * wave, hv4);
+                        if (oy + i < a.Ho && ox + g < a.Wo) {
+                            unsigned char *const hp = h_out + (((size_t)(n * a.Ho + oy + i) * a.Wo + ox + g) * 16 + 4 * wave) * HB;
+                            if constexpr (BF) {
+                                const bf16x2 lo = __builtin_convertvector(f32x2{hv4[0], hv4[1]}, bf16x2), hi = __builtin_convertvector(f32x2{hv4[2], hv4[3]}, bf16x2);
+                                *reinterpret_cast<u32x2 *>(hp) = u32x2{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+                            } else st4(reinterpret_cast<float *>(hp), hv4);
+                        }
                     }
                 }
             } else {
@@ -601,17 +641,17 @@ hipError_t launch_wino24(const ConvArgs &a, int tile_cols, int pair, int ncb, hi
     return tile_cols == 32 ? launch_wino24_t<2, false, 4>(a, s) : tile_cols == 16 ? launch_wino24_t<1, false, 4>(a, s) : hipErrorInvalidValue;
 }
 
-template <int TBW, int LS>
+template <int TBW, int LS, bool BF>
 static hipError_t launch_wino24_lstm_t(const ConvArgs &a, hipStream_t s) {
     using G = W24<TBW, false>;
     const int n_cu = device_cu_count();
     static OncePerDevice lds_ok;
-    hipError_t e = allow_dynamic_lds(lds_ok, reinterpret_cast<const void *>(wino24_pc_kernel<TBW, false, 4, LS>), G::LDS_FLOATS * 4);
+    hipError_t e = allow_dynamic_lds(lds_ok, reinterpret_cast<const void *>(wino24_pc_kernel<TBW, false, 4, LS, BF>), G::LDS_FLOATS * 4);
     if (e != hipSuccess) return e;
     const int regs_x = (a.Wo + 4 * G::TRX - 1) / (4 * G::TRX);
     const long long nitems = (long long)((a.Ho + 2 * TRY - 1) / (2 * TRY)) * a.N * regs_x * (a.Cout / 64);
     dim3 grid((unsigned)(nitems < n_cu ? nitems : n_cu));
-    hipLaunchKernelGGL((wino24_pc_kernel<TBW, false, 4, LS>), grid, dim3(512), G::LDS_FLOATS * 4, s, a);
+    hipLaunchKernelGGL((wino24_pc_kernel<TBW, false, 4, LS, BF>), grid, dim3(512), G::LDS_FLOATS * 4, s, a);
     return hipGetLastError();
 }
 
@@ -619,8 +659,12 @@ hipError_t launch_wino24_lstm(const ConvArgs &a, int tile_cols, hipStream_t s) {
     if ((a.ls_mode != 1 && a.ls_mode != 2) || a.C0 != WKC || a.C1 || a.up2 || a.H != a.Ho || a.W != a.Wo || (tile_cols != 32 && tile_cols != 16)) return hipErrorInvalidValue;
     if (a.ls_mode == 1 ? (a.Cout != 64 && a.Cout != 128) || a.in0_map || !a.bias || !a.ls_gx || !a.ls_c_out : a.Cout != 64 || !a.ls_gx || !a.ls_gx_map || !a.ls_c_in || !a.ls_c_out)
         return hipErrorInvalidValue;
-    if (a.ls_mode == 1) return tile_cols == 32 ? launch_wino24_lstm_t<2, 1>(a, s) : launch_wino24_lstm_t<1, 1>(a, s);
-    return tile_cols == 32 ? launch_wino24_lstm_t<2, 2>(a, s) : launch_wino24_lstm_t<1, 2>(a, s);
+    if (a.ls_bf16) {
+        if (a.ls_mode == 1) return tile_cols == 32 ? launch_wino24_lstm_t<2, 1, true>(a, s) : launch_wino24_lstm_t<1, 1, true>(a, s);
+        return tile_cols == 32 ? launch_wino24_lstm_t<2, 2, true>(a, s) : launch_wino24_lstm_t<1, 2, true>(a, s);
+    }
+    if (a.ls_mode == 1) return tile_cols == 32 ? launch_wino24_lstm_t<2, 1, false>(a, s) : launch_wino24_lstm_t<1, 1, false>(a, s);
+    return tile_cols == 32 ? launch_wino24_lstm_t<2, 2, false>(a, s) : launch_wino24_lstm_t<1, 2, false>(a, s);
 }
 
 static size_t lstm_regions(int Ho, int Wo, int tile_cols) { return (size_t)((Ho + 7) / 8) * ((Wo + tile_cols - 1) / tile_cols); }
