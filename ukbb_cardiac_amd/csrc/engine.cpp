@@ -1303,6 +1303,7 @@ int run_bilstm(ukbb_fcn_handle *h, const float *feat, int NF, const int *d_map, 
     base.pad_y = 1; base.pad_x = 1; base.relu = 0;
     base.tiles_y = (H + 7) / 8; base.tiles_x = (W + tc - 1) / tc;
     base.ls_forget_bias = 1.0f;
+    { const char *dg = getenv("UKBB_LSTM_DIAG"); base.diag = dg ? atoi(dg) : 0; }      // honoured by diagnostic builds (-DUKBB_DIAG) only
     {   // x pass
         ConvArgs ca = base;
         ca.in0 = feat; ca.N = NF; ca.Cout = 2 * 4 * NHID;

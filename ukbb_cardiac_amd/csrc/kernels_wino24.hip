@@ -470,6 +470,13 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
                 [[maybe_unused]] const unsigned char *gx_r = nullptr;
                 [[maybe_unused]] const float *c_r = nullptr;
                 [[maybe_unused]] unsigned char *gx_w = nullptr;
+#ifdef UKBB_DIAG
+                // ablation bits (UKBB_LSTM_DIAG, results are garbage): 1 = no cell arithmetic, 2 = no gx / c loads, 4 = no c / h stores, 8 = no epilogue at all
+                const int dg = a.diag;
+#else
+                constexpr int dg = 0;
+#endif
+                if (dg & 8) continue;
                 if constexpr (LS == 2) {
                     const int fm = __builtin_amdgcn_readfirstlane(a.ls_gx_map[n]);
                     const int ci = a.in0_map ? __builtin_amdgcn_readfirstlane(a.in0_map[n]) : n;
@@ -489,6 +496,7 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
                     if constexpr (LS == 2) {            // this tile block's gx and c on their way while the next block's rows are formed
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
+                            if (dg & 2) { gxv[tb][e] = f32x4{0.f, 0.f, 0.f, 0.f}; cv[tb][e] = 0.f; continue; }
                             if constexpr (BF) {
                                 const u32x2 d = *reinterpret_cast<const u32x2 *>(gx_r + (size_t)(tb * 8 + e) * 64 * GB);
                                 const unsigned d0 = d[0], d1 = d[1];
@@ -527,8 +535,8 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
                                 gt = f32x4{__builtin_bit_cast(float, d0 << 16), __builtin_bit_cast(float, d0 & 0xffff0000u),
                                            __builtin_bit_cast(float, d1 << 16), __builtin_bit_cast(float, d1 & 0xffff0000u)};
                             } else st4(reinterpret_cast<float *>(gx_w + (size_t)(tb * 8 + i * 4 + j) * 64 * GB), gt);
-                            const float hv = ls_cell(gt, c, a.ls_forget_bias);
-                            c_out[(size_t)(tb * 8 + i * 4 + j) * 64] = c;
+                            const float hv = (dg & 1) ? gt[0] + c : ls_cell(gt, c, a.ls_forget_bias);
+                            if (!(dg & 4)) c_out[(size_t)(tb * 8 + i * 4 + j) * 64] = c;
                             hb[j] = __builtin_bit_cast(unsigned, hv);
                         }
                         // 4 x 4 transpose over (pixel column j, lane group g): afterwards register e of lane group g is hidden channel 4 wave + e
@@ -540,7 +548,7 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
                         // (elements copied to scalars first: __builtin_bit_cast on a vector ELEMENT expression reads element 0, hipcc 7.2)
                         const unsigned u0 = p01[0], u1 = p01[1], u2 = p23[0], u3 = p23[1];
                         const f32x4 hv4 = {__builtin_bit_cast(float, u0), __builtin_bit_cast(float, u1), __builtin_bit_cast(float, u2), __builtin_bit_cast(float, u3)};
-                        if (oy + i < a.Ho && ox + g < a.Wo) {
+                        if (oy + i < a.Ho && ox + g < a.Wo && !(dg & 4)) {
                             unsigned char *const hp = h_out + (((size_t)(n * a.Ho + oy + i) * a.Wo + ox + g) * 16 + 4 * wave) * HB;
                             if constexpr (BF) {
                                 const bf16x2 lo = __builtin_convertvector(f32x2{hv4[0], hv4[1]}, bf16x2), hi = __builtin_convertvector(f32x2{hv4[2], hv4[3]}, bf16x2);
