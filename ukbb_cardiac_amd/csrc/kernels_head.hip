@@ -617,7 +617,15 @@ __global__ __launch_bounds__(768) void fcn_head_pc_kernel(const HeadArgs a) {
         // window coordinates and byte offsets are computed once, validity is one and/compare against a
         // per-tile row|column mask, and taps outside the map are buffer loads with an out-of-range
         // offset (the hardware returns 0, border taps are dropped).
+#ifndef UKBB_HEAD_RECOMPUTE_WINDOW_CONSTS
+#define UKBB_HEAD_RECOMPUTE_WINDOW_CONSTS 0
+#endif
+        // r05 experiment (-DUKBB_HEAD_RECOMPUTE_WINDOW_CONSTS=1): the 14 per-thread window constants recomputed inside g_load (once per
+        // tile) instead of living in registers across the stage loop -- removes the 2 spilled VGPRs of the 168-register budget
         unsigned tbit[NIT], goff[NIT];
+        auto window_consts = [&]() {
+        int sp32 = tid >> 4;                            // shadows the outer one: opaque to the optimiser in the recompute form, so that it is not hoisted back
+        if (UKBB_HEAD_RECOMPUTE_WINDOW_CONSTS) asm volatile("" : "+v"(sp32));
         unroll_n<NIT>([&](auto ic) {
             constexpr int it = decltype(ic)::value;
             constexpr int l = it < 3 ? 1 : it < 5 ? 2 : it < 6 ? 3 : 4;
@@ -628,7 +636,10 @@ __global__ __launch_bounds__(768) void fcn_head_pc_kernel(const HeadArgs a) {
             tbit[it] = rel < wn_ * wn_ ? (1u << ry) | (1u << (16 + rx)) : 0x80000000u;   // bit 31 never set in a tile mask
             goff[it] = (unsigned)((ry * (a.W >> l) + rx) * 64 + 4 * c4) * 4u;
         });
+        };
+        if (!UKBB_HEAD_RECOMPUTE_WINDOW_CONSTS) window_consts();
         auto g_load = [&](int k) {                      // G windows of this workgroup's k-th tile -> registers
+            if (UKBB_HEAD_RECOMPUTE_WINDOW_CONSTS) window_consts();
             int bid = blockIdx.x + k * gridDim.x;
             const int tx = bid % tiles_x; bid /= tiles_x;
             const int ty = bid % tiles_y;
