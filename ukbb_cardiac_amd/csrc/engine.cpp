@@ -852,6 +852,7 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
                 return UKBB_EARCH;
             }
             h->lstm_tile_cols = c.tw;
+            if (const char *e = getenv("UKBB_LSTM_TILE_COLS")) { const int v = atoi(e); if (v == 16 || v == 32) h->lstm_tile_cols = v; }   // A/B knob (identical bits)
             if (!dev_ptr(h, "lstm/wx")) {
                 const size_t per = (size_t)24 * 16 * 64;
                 std::vector<float> wx(2 * per), bx(2 * 64), wh(per);
