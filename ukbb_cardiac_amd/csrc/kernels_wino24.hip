@@ -138,7 +138,7 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
     constexpr int NT = G::NT, TRX = G::TRX, WIH = G::WIH, WIW = G::WIW, WHP = G::WHP, NITX = G::NITX, RS = G::RS, XSZ = G::XSZ, VSZ = G::VSZ, L_XS = G::L_XS, L_VS = G::L_VS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int cin = a.C0 + a.C1;
-    const int nchunk = cin / WKC;
+    const int nchunk = LS != 0 ? 1 : cin / WKC;        // ConvLSTM forms: 16 channels in, one stage per item (a compile-time fact for the loops below)
     const int regs_x = (a.Wo + 4 * TRX - 1) / (4 * TRX);
     // PAIR: `regions` counts the regions of an image PAIR (2 m + 1 rows of them), `a.N` images are (N + 1) / 2 pairs
     const int pm = a.Ho / 8;                            // PAIR: m
@@ -381,6 +381,13 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int i = 0; i < AD; ++i) aq[i] = ld4(wbase + i * 64 * 4);
             }
+            // LS 2: the frame indices behind this window, requested NOW -- read at the head of the epilogue they were two serial full-latency
+            // round trips (global_load + vmcnt(0) each) in front of every gx / c load (r05 ISA reading); here they return under the matrix phase
+            [[maybe_unused]] int fm_raw = 0, ci_raw = n;
+            if constexpr (LS == 2) {
+                fm_raw = a.ls_gx_map[n];
+                if (a.in0_map) ci_raw = a.in0_map[n];
+            }
             auto chunk = [&](auto firstc, int ch) {
                 constexpr bool FIRST = decltype(firstc)::value;
                 STAMP(sc0)
@@ -478,8 +485,7 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
 #endif
                 if (dg & 8) continue;
                 if constexpr (LS == 2) {
-                    const int fm = __builtin_amdgcn_readfirstlane(a.ls_gx_map[n]);
-                    const int ci = a.in0_map ? __builtin_amdgcn_readfirstlane(a.in0_map[n]) : n;
+                    const int fm = __builtin_amdgcn_readfirstlane(fm_raw), ci = __builtin_amdgcn_readfirstlane(ci_raw);
                     gx_r = reinterpret_cast<const unsigned char *>(a.ls_gx) + ((((size_t)fm * regions + r) * 4 + wave) * rows_per_wave * 64 + lane) * GB;
                     c_r = a.ls_c_in + (((size_t)ci * regions + r) * 4 + wave) * rows_per_wave * 64 + lane;
                 } else {
