@@ -118,7 +118,7 @@ __device__ __forceinline__ float ls_cell(const f32x4 &g, float &c, float forget_
 #ifdef UKBB_WINO_STAMPS
 #define STAMP(v) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); }
 #define STAMP_DO(...) __VA_ARGS__
-__device__ unsigned long long g_w24stamps[8];
+__device__ unsigned long long g_w24stamps[16];
 #else
 #define STAMP(v)
 #define STAMP_DO(...)
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
         int s = 0;
         constexpr int AD = CTB == 2 ? 4 : 8;            // A-fragment queue depth (k positions; 256 / 128 MFMA cycles each)
         f32x4 aq[AD];
-        STAMP_DO(unsigned long long cw = 0, cc = 0, ce = 0, sc0, sc1, sc2, sc3;)
+        STAMP_DO(unsigned long long cw = 0, cc = 0, ce = 0, sc0, sc1, sc2, sc3, ls_a = 0, ls_b = 0, ls_c = 0;)
         // this lane's B operand of tile block tb: tile t = 16 tb + t16, quad g -> slot g ^ (3 * ((t >> 3) & 1))
         const int vofs0 = (16 * tbk + t16) * WKC + 4 * (g ^ (3 * ((t16 >> 3) & 1)));
         const int vofs1 = (CTB == 2 ? 16 + t16 : t16) * WKC + 4 * (g ^ (3 * ((t16 >> 3) & 1)));
@@ -515,12 +515,14 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
                         }
                     }
                 }
+                STAMP_DO(unsigned long long e0_, e1_ = 0, e2_ = 0; STAMP(e0_) ls_a += e0_ - sc2;)
 #pragma unroll
                 for (int tb = 0; tb < CTB; ++tb) {
                     const int q = (tb + tbk) * 16 + t16;
                     const int oy = (ry * TRY + q / TRX) * 2, ox = (rx * TRX + q % TRX) * 4;
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
+                        STAMP_DO(if (tb == 0 && i == 1) { STAMP(e1_) ls_b += e1_ - e0_; } if (tb == 1 && i == 0) { STAMP(e2_) ls_c += e2_ - e1_; })
                         const V4 (&t)[6] = i == 0 ? T0[tb] : T1[tb];
                         const V4 s1 = t[1] + t[2], d1 = t[1] - t[2], s2 = t[3] + t[4], d2 = t[3] - t[4];
                         V4 y[4];
@@ -610,7 +612,8 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
             STAMP(sc3)
             STAMP_DO(ce += sc3 - sc2;)
         }
-        STAMP_DO(if (threadIdx.x == 0) { atomicAdd(g_w24stamps + 4, cw); atomicAdd(g_w24stamps + 5, cc); atomicAdd(g_w24stamps + 6, ce); })
+        STAMP_DO(if (threadIdx.x == 0) { atomicAdd(g_w24stamps + 4, cw); atomicAdd(g_w24stamps + 5, cc); atomicAdd(g_w24stamps + 6, ce);
+                                         atomicAdd(g_w24stamps + 8, ls_a); atomicAdd(g_w24stamps + 9, ls_b); atomicAdd(g_w24stamps + 10, ls_c); })
     }
 }
 
@@ -665,7 +668,22 @@ static hipError_t launch_wino24_lstm_t(const ConvArgs &a, hipStream_t s) {
     const int regs_x = (a.Wo + 4 * G::TRX - 1) / (4 * G::TRX);
     const long long nitems = (long long)((a.Ho + 2 * TRY - 1) / (2 * TRY)) * a.N * regs_x * (a.Cout / 64);
     dim3 grid((unsigned)(nitems < n_cu ? nitems : n_cu));
+#ifdef UKBB_WINO_STAMPS
+    const bool on = getenv("UKBB_STAMPS") != nullptr;
+    unsigned long long z[16] = {0};
+    if (on) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_w24stamps), z, 128);
+#endif
     hipLaunchKernelGGL((wino24_pc_kernel<TBW, false, 4, LS, BF>), grid, dim3(512), G::LDS_FLOATS * 4, s, a);
+#ifdef UKBB_WINO_STAMPS
+    if (on) {
+        unsigned long long h[16];
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_w24stamps), 128);
+        const double st = (double)h[3];
+        fprintf(stderr, "LSTMSTAMPS LS %d TBW %d bf %d: per item: producer wait %.0f read+store+load %.0f transform %.0f | consumer wait %.0f mfma %.0f epilogue %.0f "
+                        "(row transforms + load issue %.0f, block 0 row 0 %.0f, block 0 row 1 %.0f, rest %.0f) (items/WG %.0f)\n", LS, TBW, (int)BF, h[0] / st, h[1] / st, h[2] / st,
+                h[4] / st, h[5] / st, h[6] / st, h[8] / st, h[9] / st, h[10] / st, (h[6] - h[8] - h[9] - h[10]) / st, st / grid.x);
+    }
+#endif
     return hipGetLastError();
 }
 
