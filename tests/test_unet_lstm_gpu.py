@@ -265,3 +265,17 @@ def test_bf16_cine_dice_vs_fp32(model):
         worst = min(float(np_categorical_dice(pred16[i], pred32[i], k)) for i in range(100) if (pred32[i] == k).sum() > 500)
         assert d >= 0.98 and worst >= 0.97, (k, d, worst)
     assert (pred16 != pred32).mean() < 0.02
+
+
+def test_every_step_of_the_fused_convlstm_matches_numpy():
+    """r05 white box: the x pass's per-frame first step (h1, both directions) and every later step's hidden map of the fused gate-conv / cell
+    kernel (csrc/kernels_wino24.hip, ConvArgs::ls_mode) against oracle conv_lstm_cell on the engine's own feature maps, step by step
+    (tools/debug_lstm.py reads the buffers through ukbb_fcn_get_activation('lstm:h1' / 'lstm:hall')); two map sizes, the second with ragged regions."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for hw in (('32', '48'), ('48', '80')):
+        r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'debug_lstm.py')] + list(hw), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           text=True, timeout=600, env=dict(os.environ, PYTHONPATH=root))
+        assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == 'OK', r.stdout[-2000:]
