@@ -75,6 +75,13 @@ def main(out):
           '%.1f MB per forward = %.2f MB per slice -> traffic / algorithmic = %.2f' % (alg / 1e6, alg / 1e6 / n, hbm / alg))
     if 'fp32' in ms:
         print('fp32 path of the same engine: %.2f ms per forward -> bf16 speed-up %.2fx' % (ms['fp32'], ms['fp32'] / ms['bf16']))
+    # what bench.py quotes as config 5's measured traffic: stamped with the kernel sources it was collected from
+    import json
+    import bench
+    with open(os.path.join(out, 'unet_traffic.json'), 'w') as f:
+        json.dump({'kernel_source_sha': bench.kernel_source_sha(), 'hbm_bytes_per_forward': hbm, 'fetch_size_bytes': fetch, 'write_size_bytes': write,
+                   'algorithmic_bytes_per_forward': alg, 'forwards_counted': forwards, 'ms_per_forward_unprofiled': ms['bf16'],
+                   'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/bench_unet.py 100 bf16 3 (tools/profile_unet.sh); HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB units, gfx950 correction)'}, f)
 
 
 if __name__ == '__main__':

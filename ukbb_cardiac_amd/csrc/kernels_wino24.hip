@@ -64,6 +64,32 @@ template <int TBW, bool PAIR = false> struct W24 {
 };
 
 __device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+#ifndef UKBB_LSTM_NT
+#define UKBB_LSTM_NT 1
+#endif
+// streamed-once data of the ConvLSTM epilogue (gx, c): nontemporal forms (r05 A/B on one box, two alternating rounds: fp32 cine 18.79-18.86 -> 18.67-18.72 ms, bf16
+// 13.07-13.09 -> 12.97; -DUKBB_LSTM_NT=0 gives the plain forms)
+__device__ __forceinline__ f32x4 ld4_s(const float *p) {
+#if UKBB_LSTM_NT
+    return __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+#else
+    return *reinterpret_cast<const f32x4 *>(p);
+#endif
+}
+__device__ __forceinline__ float ld1_s(const float *p) {
+#if UKBB_LSTM_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void st1_s(float *p, float v) {
+#if UKBB_LSTM_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 __device__ __forceinline__ void st4(float *p, const f32x4 &v) { *reinterpret_cast<f32x4 *>(p) = v; }
 
 __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
@@ -509,9 +535,9 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
                                 gxv[tb][e] = f32x4{__builtin_bit_cast(float, d0 << 16), __builtin_bit_cast(float, d0 & 0xffff0000u),
                                                    __builtin_bit_cast(float, d1 << 16), __builtin_bit_cast(float, d1 & 0xffff0000u)};
                             } else {
-                                gxv[tb][e] = ld4(reinterpret_cast<const float *>(gx_r + (size_t)(tb * 8 + e) * 64 * GB));
+                                gxv[tb][e] = ld4_s(reinterpret_cast<const float *>(gx_r + (size_t)(tb * 8 + e) * 64 * GB));
                             }
-                            cv[tb][e] = c_r[(size_t)(tb * 8 + e) * 64];
+                            cv[tb][e] = ld1_s(c_r + (size_t)(tb * 8 + e) * 64);
                         }
                     }
                 }
@@ -544,7 +570,7 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
                                            __builtin_bit_cast(float, d1 << 16), __builtin_bit_cast(float, d1 & 0xffff0000u)};
                             } else st4(reinterpret_cast<float *>(gx_w + (size_t)(tb * 8 + i * 4 + j) * 64 * GB), gt);
                             const float hv = (dg & 1) ? gt[0] + c : ls_cell(gt, c, a.ls_forget_bias);
-                            if (!(dg & 4)) c_out[(size_t)(tb * 8 + i * 4 + j) * 64] = c;
+                            if (!(dg & 4)) st1_s(c_out + (size_t)(tb * 8 + i * 4 + j) * 64, c);
                             hb[j] = __builtin_bit_cast(unsigned, hv);
                         }
                         // 4 x 4 transpose over (pixel column j, lane group g): afterwards register e of lane group g is hidden channel 4 wave + e
