@@ -389,6 +389,17 @@ def other_configs_probe(device):
         t0 = time.perf_counter()
         cine(5)
         tl = (time.perf_counter() - t0) / 5
+        pl32 = pred.cpu().numpy().copy()
+        # UKBB_PREC_BF16 on the same handle: bf16-storage U-Net plan, ConvLSTM as direct convs on the bf16 matrix instruction (cell state fp32)
+        eng.set_precision('bf16')
+        cine(2)
+        t0 = time.perf_counter()
+        cine(5)
+        tl16 = (time.perf_counter() - t0) / 5
+        pl16 = pred.cpu().numpy()
+        lstm_bf16 = {'value': round(F / tl16, 1), 'unit': 'frames/s', 'ms_per_cine': round(tl16 * 1e3, 3),
+                     'dice_vs_fp32': {'class1': round(float(np_categorical_dice(pl16, pl32, 1)), 4), 'class2': round(float(np_categorical_dice(pl16, pl32, 2)), 4)},
+                     'label_disagreement': round(float((pl16 != pl32).mean()), 5)}
     # reference-graph FLOPs with the features computed once per frame (the reference recomputes the U-Net for each of the 9 window positions):
     # U-Net + per window 18 gate convs (3x3, 32 -> 64) + 9 output convs -- an "effective" figure, not a utilisation (the x half of the gate
     # conv is hoisted out of the time loop and the rest runs as Winograd F(2x4))
@@ -401,7 +412,7 @@ def other_configs_probe(device):
     out['unet_lstm_cine'] = {
         'workload': 'UNet-LSTM_ao (network_ao.py:255-399 + the window tiling of deploy_network_ao.py:129-183): one slice position, 100 frames '
                     'of 256x256 resident in HBM, fp32; prob [F,H,W,3] + int32 labels out',
-        'value': round(F / tl, 1), 'unit': 'frames/s', 'ms_per_cine': round(tl * 1e3, 3),
+        'value': round(F / tl, 1), 'unit': 'frames/s', 'ms_per_cine': round(tl * 1e3, 3), 'bf16': lstm_bf16,
         'roofline': {'bound': 'hbm', 'peak': 8000.0, 'unit': 'GB/s',
                      'achieved': round(bytes_l / tl / 1e9, 1), 'frac': round(bytes_l / tl / 8e12, 4),
                      'algorithmic_bytes_lstm_part': bytes_l, 'traffic': None,

@@ -279,3 +279,16 @@ def test_every_step_of_the_fused_convlstm_matches_numpy():
         r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'debug_lstm.py')] + list(hw), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                            text=True, timeout=600, env=dict(os.environ, PYTHONPATH=root))
         assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == 'OK', r.stdout[-2000:]
+
+
+def test_bf16_direct_convlstm_is_deterministic_and_agrees_with_the_winograd_form():
+    """r05: in UKBB_PREC_BF16 the ConvLSTM runs as direct 3x3 convs on v_mfma_f32_32x32x16_bf16 with the cell in the epilogue (csrc/kernels_ws.hip, ws_main LS).
+    tools/check_lstm_bf16.py: seven cine shapes (ragged tiles, time_step 1-3, 9-100 frames): two runs bit-identical, probabilities within bf16-weight precision of
+    the fp32-Winograd-on-bf16-storage form (UKBB_LSTM_BF16_WINOGRAD=1), labels >= 99 % equal."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_lstm_bf16.py')], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900,
+                       env=dict(os.environ, PYTHONPATH=root))
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == 'OK', r.stdout[-2000:]

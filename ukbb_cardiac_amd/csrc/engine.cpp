@@ -870,6 +870,22 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
                 if (rc) return rc;
                 rc = upload(h, "lstm/bx", bx);
                 if (rc) return rc;
+                // bf16 form (kernels_ws.hip, ws_main LS): direct 3x3 conv on the bf16 matrix instruction, its own channel order
+                const size_t perb = (size_t)9 * 16 * 64 / 2;          // dwords
+                std::vector<float> wxb(2 * perb), bxb(2 * 64), whb(perb);
+                d = 0;
+                for (const char *nm2 : {"lstm_fw", "lstm_bw"}) {
+                    const HostLayer &L = h->layers[h->layer_index.at(nm2)];
+                    pack_lstm_gate_weights_bf16(L.w.data(), L.cin, 0, L.b.data(), wxb.data() + d * perb, bxb.data() + d * 64);
+                    pack_lstm_gate_weights_bf16(L.w.data(), L.cin, a.n_filter[0], nullptr, whb.data(), nullptr);
+                    rc = upload(h, std::string(nm2) + "/wh_bf16", whb);
+                    if (rc) return rc;
+                    ++d;
+                }
+                rc = upload(h, "lstm/wx_bf16", wxb);
+                if (rc) return rc;
+                rc = upload(h, "lstm/bx_bf16", bxb);
+                if (rc) return rc;
             }
         }
     }
@@ -1288,7 +1304,10 @@ int run_bilstm(ukbb_fcn_handle *h, const float *feat, int NF, const int *d_map, 
     const ukbb_fcn_arch &a = h->arch;
     const int T = a.fc, NHID = a.same_dim, tc = h->lstm_tile_cols;
     const size_t HW = (size_t)H * W;
-    const size_t gxf = wino24_lstm_gx_floats(H, W, tc), cf = wino24_lstm_c_floats(H, W, tc);
+    // bf16 plan: the direct-conv bf16 form (kernels_ws.hip) unless UKBB_LSTM_BF16_WINOGRAD=1 asks for the fp32 Winograd arithmetic on bf16 storage (A/B)
+    static const bool bf_wino = getenv("UKBB_LSTM_BF16_WINOGRAD") != nullptr;
+    const bool wsf = h->plan_bfio && !bf_wino;
+    const size_t gxf = wsf ? lstm_ws_gx_elems(H, W) : wino24_lstm_gx_floats(H, W, tc), cf = wsf ? lstm_ws_c_floats(H, W) : wino24_lstm_c_floats(H, W, tc);
     HIP_TRY(h->lstm_gx.ensure(2 * (size_t)NF * gxf), UKBB_ENOMEM);
     HIP_TRY(h->lstm_c1.ensure(2 * (size_t)NF * cf), UKBB_ENOMEM);
     HIP_TRY(h->lstm_h1.ensure(2 * (size_t)NF * HW * NHID), UKBB_ENOMEM);
@@ -1308,10 +1327,10 @@ int run_bilstm(ukbb_fcn_handle *h, const float *feat, int NF, const int *d_map, 
     {   // x pass
         ConvArgs ca = base;
         ca.in0 = feat; ca.N = NF; ca.Cout = 2 * 4 * NHID;
-        ca.wpk = dev_ptr(h, "lstm/wx"); ca.bias = dev_ptr(h, "lstm/bx");
+        ca.wpk = dev_ptr(h, wsf ? "lstm/wx_bf16" : "lstm/wx"); ca.bias = dev_ptr(h, wsf ? "lstm/bx_bf16" : "lstm/bx");
         ca.ls_mode = 1; ca.ls_gx = h->lstm_gx.p; ca.ls_c_out = h->lstm_c1.p; ca.out = h->lstm_h1.p;
         ca.ls_gx_dir = (long long)NF * gxf; ca.ls_c_dir = (long long)NF * cf; ca.ls_h_dir = (long long)NF * HW * NHID;
-        hipError_t e = launch_wino24_lstm(ca, tc, s);
+        hipError_t e = wsf ? launch_lstm_ws(ca, s) : launch_wino24_lstm(ca, tc, s);
         if (e != hipSuccess) { set_err("ConvLSTM x-pass launch failed: %s", hipGetErrorString(e)); return UKBB_EDEVICE; }
     }
     const size_t kst = (size_t)Wn * HW * NHID;           // one step's hidden maps
@@ -1321,7 +1340,7 @@ int run_bilstm(ukbb_fcn_handle *h, const float *feat, int NF, const int *d_map, 
             const int k = dir ? T - 1 - step : step, kprev = dir ? k + 1 : k - 1;
             ConvArgs ca = base;
             ca.N = Wn; ca.Cout = 4 * NHID;
-            ca.wpk = dev_ptr(h, dir ? "lstm_bw/wh" : "lstm_fw/wh"); ca.bias = nullptr;
+            ca.wpk = dev_ptr(h, wsf ? (dir ? "lstm_bw/wh_bf16" : "lstm_fw/wh_bf16") : (dir ? "lstm_bw/wh" : "lstm_fw/wh")); ca.bias = nullptr;
             ca.ls_mode = 2;
             ca.ls_gx = at(h->lstm_gx.p, (size_t)dir * NF * gxf); ca.ls_gx_map = d_map + (size_t)k * Wn;
             if (step == 1) {                                // previous state = the x pass's per-frame first step
@@ -1333,7 +1352,7 @@ int run_bilstm(ukbb_fcn_handle *h, const float *feat, int NF, const int *d_map, 
             }
             ca.ls_c_out = h->lstm_c.p;
             ca.out = at(hall, (size_t)k * kst);
-            hipError_t e = launch_wino24_lstm(ca, tc, s);
+            hipError_t e = wsf ? launch_lstm_ws(ca, s) : launch_wino24_lstm(ca, tc, s);
             if (e != hipSuccess) { set_err("ConvLSTM step launch failed: %s", hipGetErrorString(e)); return UKBB_EDEVICE; }
         }
     }

@@ -187,6 +187,12 @@ size_t wino24_lstm_c_floats(int Ho, int Wo, int tile_cols);
 // [c_first, c_first + 16) with the output channels permuted so that MFMA row 4 g + e of 16-channel block w is gate e of hidden channel
 // 4 w + g; `bias_perm` (optional, 64) receives the bias in the same order.  Returns floats written to dst (24 * 16 * 64).
 size_t pack_lstm_gate_weights(const float *w, int cin_total, int c_first, const float *bias, float *dst, float *bias_perm);
+// bf16 form of the same pair of kernels (kernels_ws.hip, ws_main LS): direct 3x3 conv on v_mfma_f32_32x32x16_bf16 (bf16 hidden maps / features / gx, fp32
+// accumulation and cell state), weight-stationary independent waves.  ConvArgs as above with ls_bf16 = 1; its own lane-native layouts and packing:
+hipError_t launch_lstm_ws(const ConvArgs &a, hipStream_t s);
+size_t lstm_ws_gx_elems(int H, int W);      // bf16 values of gx per image (frame)
+size_t lstm_ws_c_floats(int H, int W);      // fp32 values of the cell state per image
+size_t pack_lstm_gate_weights_bf16(const float *w, int cin_total, int c_first, const float *bias, float *dst /*9 * 16 * 64 / 2 dwords*/, float *bias_perm);
 
 // ---------------------------------------------------------------------------
 // First layer: conv3x3, C_in = 1 (network.py:186 with l = 0), direct stencil.

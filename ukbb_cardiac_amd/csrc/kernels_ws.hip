@@ -100,9 +100,17 @@ __host__ __device__ constexpr bool wst_first(int tm, int blk, int a, int b) {
 // KIND: 0 = 3x3 stride 1, 1 = transposed conv (sub-pixel 2x2); TM: KIND 1 only, the block pairing (wst_needed)
 // LG (KIND 0, one block of 16 real channels): the 1x1 logits conv + softmax / argmax of network_ao.py:63,159-160 in the epilogue; the
 //     conv's own output is rounded to bf16 as a store would have done and never written (as conv_mfma_kernel<..., FUSE = 2>)
-template <int KIND, int R, int CB, int NW, int NCH, bool TWO, int TM, bool LG = false>
+// LS (KIND 0, CB = 2, one 16-channel chunk): the ConvLSTM cell of network_ao.py:255-319 in the epilogue (ConvArgs::ls_mode 1 | 2, kernels.h) -- the bf16 form of
+//     the fused gate-conv / cell kernel (UKBB_PREC_BF16 on a UNet-LSTM handle, r05).  The 64 gate channels are packed (pack_lstm_gate_weights_bf16) so that the
+//     accumulators of lane half g ARE the four gates of hidden channels 8 g .. 8 g + 7 of the lane's pixel: block 0 registers 0-7 = i, 8-15 = j, block 1
+//     registers 0-7 = f, 8-15 = o.  No data moves between lanes; gx (bf16) and the cell state (fp32) live in the lanes' own order
+//     ([image][tile][row][16-byte piece][lane]: every load / store instruction is one contiguous KB), h is written as bf16 NHWC (lane half g = channels 8 g ..:
+//     32 pixels x 32 bytes = one contiguous KB per row).  Eight independent waves per workgroup and two per SIMD hide the epilogue's loads and its
+//     transcendental chains behind each other's MFMAs -- what the fp32 Winograd form (kernels_wino24.hip) cannot do with its 192 accumulators per wave.
+template <int KIND, int R, int CB, int NW, int NCH, bool TWO, int TM, bool LG = false, int LS = 0>
 __device__ __forceinline__ void ws_main(const ConvArgs &a, const int grp, const int walker, const int nwalk) {
     static_assert(!LG || (KIND == 0 && CB == 1), "fused logits: 3x3 conv with one Cout block");
+    static_assert(LS == 0 || (KIND == 0 && CB == 2 && NCH == 1 && !TWO && !LG), "ConvLSTM epilogue: 16 channels in, the 64 gate channels of one direction per workgroup");
     constexpr int WS_IW = ws_iw(KIND), HR = ws_hr(KIND, R), TAPS = ws_taps(KIND);
     constexpr int HP = HR * WS_IW, NLD = ws_nld(KIND, R), STAGE = ws_stage_bytes(KIND, R), PLANE = ws_plane_bytes(KIND, R);
     constexpr int WSLAB = NCH * CB * TAPS * 1024;       // bytes: [chunk][cb][tap][lane][16]
@@ -186,9 +194,14 @@ __device__ __forceinline__ void ws_main(const ConvArgs &a, const int grp, const 
     // ---- load cursor: the tile whose chunks are being requested ----
     unsigned voff[NLD];
     __amdgpu_buffer_rsrc_t rs0, rs1;
+    // window -> frame tables (LS 2) through the SCALAR cache (constant address space + a wave-uniform index = s_load_dword, waited for on lgkmcnt): a vector
+    // load would queue behind three tiles of halo prefetch (vmcnt retires in order)
+    typedef const int __attribute__((address_space(4))) *cint_p;
+    [[maybe_unused]] const cint_p map0 = (cint_p)(a.in0_map), mapg = (cint_p)(a.ls_gx_map);
     auto load_setup = [&](int k) {
         int n, oy0, ox0;
         const bool valid = tile_coords(k, n, oy0, ox0);
+        if constexpr (LS == 2) { if (a.in0_map) n = map0[n]; }   // image n reads frame in0_map[n]
         // range = the image's planes of that source: a chunk's plane is selected by the scalar offset of the load
         rs0 = __builtin_amdgcn_make_buffer_rsrc((void *)(in0 + (size_t)n * nb0 * plane_bytes), 0, nb0 * plane_bytes, 0x00020000);
         rs1 = __builtin_amdgcn_make_buffer_rsrc((void *)((TWO ? in1 : in0) + (size_t)n * (TWO ? nb1 : nb0) * plane_bytes), 0, (TWO ? nb1 : nb0) * plane_bytes, 0x00020000);
@@ -231,7 +244,8 @@ __device__ __forceinline__ void ws_main(const ConvArgs &a, const int grp, const 
     for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(a.bias + (grp * CB + cb) * 32 + 8 * j + 4 * g);
+            f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (LS != 2) b4 = *reinterpret_cast<const f32x4 *>(a.bias + (grp * CB + cb) * 32 + 8 * j + 4 * g);   // LS 2: the gate bias is part of gx
 #pragma unroll
             for (int i = 0; i < 4; ++i) biasv[cb][4 * j + i] = b4[i];
         }
@@ -253,6 +267,28 @@ __device__ __forceinline__ void ws_main(const ConvArgs &a, const int grp, const 
                     Aq[GG & 1][cb][kh] = *reinterpret_cast<const u32x4 *>(ws_lane + ((CH * CB + cb) * TAPS + tap) * 1024);
             });
         });
+    };
+    // ---- LS 2: the tile's gx (bf16, four 16-byte pieces per row = one gate of the lane's eight hidden channels each) and cell state (fp32, two pieces per row)
+    //      requested at the START of the tile's matrix phase: they return under its MFMAs and the other waves' work
+    [[maybe_unused]] u32x4 gxq[LS == 2 ? R : 1][4];
+    [[maybe_unused]] f32x4 cq[LS == 2 ? R : 1][2];
+    [[maybe_unused]] auto ls_prefetch = [&](int k) {
+        if constexpr (LS == 2) {
+            int n, oy0, ox0;
+            const bool valid = tile_coords(k, n, oy0, ox0);
+            const int rtile = (oy0 / R) * a.tiles_x + ox0 / WS_TW;
+            const int fm = mapg[n];
+            const int ci = a.in0_map ? map0[n] : n;
+            const unsigned char *gp = reinterpret_cast<const unsigned char *>(a.ls_gx) + ((size_t)fm * tiles + rtile) * (R * 4096) + lane * 16;
+            const unsigned char *cp = reinterpret_cast<const unsigned char *>(a.ls_c_in) + ((size_t)ci * tiles + rtile) * (R * 2048) + lane * 16;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gxq[r][q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(gp + (r * 4 + q) * 1024));
+#pragma unroll
+                for (int q = 0; q < 2; ++q) cq[r][q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(cp + (r * 2 + q) * 1024));
+            }
+        }
     };
     auto compute = [&](auto qc) {                       // position Q of the body: chunk Q % NCH from ring stage Q & 1
         constexpr int Q = decltype(qc)::value, CH = Q % NCH;
@@ -340,6 +376,76 @@ __device__ __forceinline__ void ws_main(const ConvArgs &a, const int grp, const 
     auto epilogue = [&](int k) {
         int n, oy0, ox0;
         const bool valid = tile_coords(k, n, oy0, ox0);
+        if constexpr (LS != 0) {
+            const int rtile = (oy0 / R) * a.tiles_x + ox0 / WS_TW;
+            // mode 1: groups = directions, per-frame outputs side by side (ls_*_dir count elements); mode 2: per window
+            const size_t img = (size_t)n * tiles + rtile;
+            // (wave-uniform bases: a buffer descriptor built from a per-lane pointer makes hipcc loop over the lanes; the lane's 16-byte slot is the vector offset)
+            unsigned char *const cw = reinterpret_cast<unsigned char *>(a.ls_c_out) + (LS == 1 ? (size_t)grp * a.ls_c_dir * 4 : 0) + img * (R * 2048);
+            [[maybe_unused]] unsigned char *const gw = reinterpret_cast<unsigned char *>(a.ls_gx) + (LS == 1 ? (size_t)grp * a.ls_gx_dir * 2 : 0) + img * (R * 4096);
+            const unsigned lvo = (unsigned)lane * 16u;
+            unsigned char *const hbase = outb + (LS == 1 ? (size_t)grp * a.ls_h_dir * 2 : 0) + (size_t)n * a.Ho * a.Wo * 32;
+            const int himg_bytes = a.Ho * a.Wo * 32;
+            const unsigned hvo = ox0 + pl < a.Wo ? (unsigned)(pl * 32 + g * 16) : OOB;
+            const float fb = a.ls_forget_bias;
+            unroll_steps<R>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                const int oy = oy0 + r;
+                float hv[8], cn[8];
+                [[maybe_unused]] unsigned gh[4][8];         // mode 1: the gates rounded to bf16 (halfwords), as stored: [gate][hidden channel of this lane half]
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    // (elements copied to scalars first: __builtin_bit_cast applied to an ext_vector element expression reads element 0, hipcc 7.2)
+                    float gi = acc[0][r][m], gj = acc[0][r][8 + m], gf = acc[1][r][m], go = acc[1][r][8 + m];
+                    float c = 0.f;
+                    if constexpr (LS == 2) {
+                        const unsigned wi = gxq[r][0][m >> 1], wj = gxq[r][1][m >> 1], wf = gxq[r][2][m >> 1], wo = gxq[r][3][m >> 1];
+                        auto wide = [&](unsigned w) { return __builtin_bit_cast(float, (m & 1) ? (w & 0xffff0000u) : (w << 16)); };
+                        gi += wide(wi); gj += wide(wj); gf += wide(wf); go += wide(wo);
+                        const float cold = cq[r][m >> 2][m & 3];
+                        c = cold;
+                    } else {                                // the time steps add the ROUNDED gx: the x pass's own first step uses the same values
+                        auto rnd = [&](float v) { f32x2 t; t.x = v; t.y = 0.f; return __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2)) & 0xffffu; };
+                        gh[0][m] = rnd(gi); gh[1][m] = rnd(gj); gh[2][m] = rnd(gf); gh[3][m] = rnd(go);
+                        gi = __builtin_bit_cast(float, gh[0][m] << 16); gj = __builtin_bit_cast(float, gh[1][m] << 16);
+                        gf = __builtin_bit_cast(float, gh[2][m] << 16); go = __builtin_bit_cast(float, gh[3][m] << 16);
+                    }
+                    const float sgf = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((gf + fb) * -1.44269504f));
+                    const float sgi = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(gi * -1.44269504f));
+                    const float tj = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(gj * 2.88539008f) + 1.0f), 1.0f);
+                    c = __builtin_fmaf(sgf, c, sgi * tj);
+                    const float tc = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(c * 2.88539008f) + 1.0f), 1.0f);
+                    cn[m] = c;
+                    hv[m] = tc * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(go * -1.44269504f));
+                }
+                // stores through descriptors of range 0 for ghost tiles / rows below the map (no branch around a vector-memory instruction)
+                const bool rowok = valid && oy < a.Ho;
+                const __amdgpu_buffer_rsrc_t rc_ = __builtin_amdgcn_make_buffer_rsrc((void *)cw, 0, valid ? R * 2048 : 0, 0x00020000);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const u32x4 v = {__builtin_bit_cast(unsigned, cn[4 * q]), __builtin_bit_cast(unsigned, cn[4 * q + 1]),
+                                     __builtin_bit_cast(unsigned, cn[4 * q + 2]), __builtin_bit_cast(unsigned, cn[4 * q + 3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rc_, lvo, (r * 2 + q) * 1024, 0);
+                }
+                if constexpr (LS == 1) {
+                    const __amdgpu_buffer_rsrc_t rg_ = __builtin_amdgcn_make_buffer_rsrc((void *)gw, 0, valid ? R * 4096 : 0, 0x00020000);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {           // piece q = gate q (i, j, f, o): halfwords m = 0..7
+                        const u32x4 v = {gh[q][0] | (gh[q][1] << 16), gh[q][2] | (gh[q][3] << 16), gh[q][4] | (gh[q][5] << 16), gh[q][6] | (gh[q][7] << 16)};
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rg_, lvo, (r * 4 + q) * 1024, 0);
+                    }
+                }
+                u32x4 hvw;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    f32x2 t; t.x = hv[2 * d]; t.y = hv[2 * d + 1];
+                    hvw[d] = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
+                }
+                const __amdgpu_buffer_rsrc_t rh_ = __builtin_amdgcn_make_buffer_rsrc((void *)hbase, 0, rowok ? himg_bytes : 0, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b128(hvw, rh_, hvo, (oy * a.Wo + ox0) * 32, 0);
+            });
+            return;
+        }
         if constexpr (LG) {
             const int ox = ox0 + pl;
             const int npx = a.Ho * a.Wo;
@@ -476,6 +582,7 @@ __device__ __forceinline__ void ws_main(const ConvArgs &a, const int grp, const 
             constexpr int SETN = (Q + 1) & 1;           // register set / stage of position Q + 1
             if constexpr (SETN == 0) { park(S0); request(S0, std::integral_constant<int, (Q + 3) % U>{}); }
             else                     { park(S1); request(S1, std::integral_constant<int, (Q + 3) % U>{}); }
+            if constexpr (LS == 2) ls_prefetch(bi * TPB + Q / NCH);
             compute(qc);
             if constexpr (Q % NCH == NCH - 1) { epilogue(bi * TPB + Q / NCH); UKBB_WS_STAMP(3 + bi * TPB + Q / NCH) }
         });
@@ -765,6 +872,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void tconv_ws_kernel(const ConvArg
     else ws_main<1, R, 2, NW, NCH, false, 0>(a, grp, walker, nwalk);
 }
 
+// ConvLSTM forms (ConvArgs::ls_mode): 16 channels in, 64 gate channels per group (mode 1: two groups = the two directions), R = 2 rows x 32 pixels per tile
+template <int R, int NW, int LS>
+__global__ __launch_bounds__(NW * 64, NW / 4) void lstm_ws_kernel(const ConvArgs a) {
+    int grp, walker, nwalk;
+    ws_place(a.Cout / 64, grp, walker, nwalk);
+    ws_main<0, R, 2, NW, 1, false, 0, false, LS>(a, grp, walker, nwalk);
+}
+
 }  // namespace
 
 // W(id, R, CB, NW): ConvConfig::pc == 6, 3x3 stride 1, mb 32, th = R, tw = 32, kc 16, wm 1, wn = NW, cb = CB
@@ -882,6 +997,51 @@ hipError_t launch_wst_cfg(const ConvArgs &a, int grid, hipStream_t s) {
     }
 }
 }  // namespace
+
+// ---- bf16 ConvLSTM (UKBB_PREC_BF16 on a UNet-LSTM handle) ----
+namespace { constexpr int LSW_R = 2, LSW_NW = 4; }
+size_t lstm_ws_tiles(int H, int W) { return (size_t)((H + LSW_R - 1) / LSW_R) * ((W + WS_TW - 1) / WS_TW); }
+size_t lstm_ws_gx_elems(int H, int W) { return lstm_ws_tiles(H, W) * LSW_R * 2048; }      // bf16 values per image: 64 lanes x 32 per tile row
+size_t lstm_ws_c_floats(int H, int W) { return lstm_ws_tiles(H, W) * LSW_R * 512; }       // fp32 values per image: 64 lanes x 8 per tile row
+
+hipError_t launch_lstm_ws(const ConvArgs &a_in, hipStream_t s) {
+    ConvArgs a = a_in;
+    if ((a.ls_mode != 1 && a.ls_mode != 2) || !a.ls_bf16 || a.C0 != 16 || a.C1 || a.in1 || a.up2 || a.H != a.Ho || a.W != a.Wo || a.pad_y != 1 || a.pad_x != 1) return hipErrorInvalidValue;
+    if (a.ls_mode == 1 ? (a.Cout != 64 && a.Cout != 128) || a.in0_map || !a.bias || !a.ls_gx || !a.ls_c_out : a.Cout != 64 || !a.ls_gx || !a.ls_gx_map || !a.ls_c_in || !a.ls_c_out)
+        return hipErrorInvalidValue;
+    if ((long long)a.H * a.W * 32 >= 0x7fffffffll) return hipErrorInvalidValue;
+    a.tiles_y = (a.Ho + LSW_R - 1) / LSW_R; a.tiles_x = (a.Wo + WS_TW - 1) / WS_TW;
+    {   // tile order as launch_conv_ws
+        static const char *const force = getenv("UKBB_WS_XCD_LOCAL");
+        a.xcd_local = force ? atoi(force) : ((long long)a.H * a.W >= 128ll * 128);
+    }
+    const int nG = a.Cout / 64;
+    const long long ntiles = (long long)a.N * a.tiles_y * a.tiles_x;
+    const int cus = device_cu_count();
+    long long want = ((ntiles + LSW_NW - 1) / LSW_NW) * nG;
+    int grid = cus >= 8 * nG ? cus / (8 * nG) * (8 * nG) : cus / nG * nG;
+    if (grid < nG) grid = nG;
+    if (want < grid) grid = (int)((want + nG - 1) / nG * nG);
+    constexpr int bytes = ws_lds_bytes(0, LSW_R, 2, LSW_NW, 1);
+    static_assert(bytes <= 160 * 1024, "LDS");
+    static OncePerDevice ok1, ok2;
+    if (a.ls_mode == 1) return launch_ws_kernel(lstm_ws_kernel<LSW_R, LSW_NW, 1>, bytes, LSW_NW * 64, a, grid, s, ok1);
+    return launch_ws_kernel(lstm_ws_kernel<LSW_R, LSW_NW, 2>, bytes, LSW_NW * 64, a, grid, s, ok2);
+}
+
+size_t pack_lstm_gate_weights_bf16(const float *w, int cin_total, int c_first, const float *bias, float *dst, float *bias_perm) {
+    // packed channel P = 32 cb + 8 j + 4 g + i (MFMA row 8 j + 4 g + i of block cb)  <-  gate e = 2 cb + (j >> 1) of hidden channel 8 g + 4 (j & 1) + i:
+    // the accumulator registers of lane half g are then (i | j) in block 0 and (f | o) in block 1, eight hidden channels each (ws_main, LS)
+    std::vector<float> tmp((size_t)9 * 16 * 64);
+    for (int P = 0; P < 64; ++P) {
+        const int cb = P / 32, row = P % 32, j = row / 8, g = (row / 4) & 1, i = row % 4;
+        const int orig = (2 * cb + (j >> 1)) * 16 + 8 * g + 4 * (j & 1) + i;
+        if (bias_perm) bias_perm[P] = bias ? bias[orig] : 0.f;
+        for (int t = 0; t < 9; ++t)
+            for (int ci = 0; ci < 16; ++ci) tmp[((size_t)t * 16 + ci) * 64 + P] = w[((size_t)t * cin_total + c_first + ci) * 64 + orig];
+    }
+    return pack_conv_weights_bf16(tmp.data(), 3, 16, 64, 2, dst);
+}
 
 hipError_t launch_conv_ws(int cfg_id, const ConvArgs &a_in, hipStream_t s) {
     const ConvConfig *c = nullptr;
