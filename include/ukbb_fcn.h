@@ -94,9 +94,9 @@ void ukbb_fcn_destroy(ukbb_fcn_handle *h);
  * 32-row shape), the first layer (fp32 arithmetic) is evaluated inside the second one's staging and
  * the logits conv + softmax / argmax inside the last conv's epilogue: 21 launches, 2.9x the fp32 rate
  * at N = 100 x 256x256.  On a UKBB_KIND_UNET_LSTM handle (round 5) the U-Net runs the same bf16-storage
- * plan and the ConvLSTM keeps its features, the hoisted x half of the gate pre-activations and the hidden
- * maps as bf16 in HBM (cell state and arithmetic fp32): 13 ms instead of 19 per 100-frame cine, per-class
- * Dice >= 0.98 against the fp32 cine.  On FCN handles only the operands are bf16 (fp32 activations in
+ * plan and the ConvLSTM runs as direct 3x3 convs on the bf16 matrix instruction with its features, the
+ * hoisted x half of the gate pre-activations and the hidden maps as bf16 in HBM (accumulation and cell
+ * state fp32): 8-9 ms instead of 19 per 100-frame cine, per-class Dice >= 0.98 against the fp32 cine.  On FCN handles only the operands are bf16 (fp32 activations in
  * HBM; layers without such a tiling stay fp32).  Not bit-compatible with the reference; meant to be
  * judged by Dice against the fp32 result (common/image_utils.py:171-175): 0.993 / 0.992 measured. */
 #define UKBB_PREC_FP32 0
