@@ -49,7 +49,8 @@ def define_flags():
                       '(bit-identical to the host path; --nodevice_preproc restores it).')
     fs.DEFINE_enum('precision', 'fp32', ['fp32', 'bf16'], 'Arithmetic of the U-Net convolutions: fp32 MFMA (default) or bf16 MFMA operands with fp32 '
                    'accumulation (UKBB_PREC_BF16, include/ukbb_fcn.h; --model UNet: bf16 activations in HBM too, 2.8x the fp32 rate, '
-                   'Dice 0.99 against fp32; BASELINE config 5).')
+                   'Dice 0.99 against fp32; BASELINE config 5.  Default UNet-LSTM model: the same U-Net plan, ConvLSTM on the bf16 matrix '
+                   'instruction with bf16 hidden maps and fp32 cell state, 2.3x the fp32 rate, Dice >= 0.98 against fp32).')
     fs.DEFINE_enum('label_gzip', 'small', list(nifti.LABEL_GZIP_MODES), 'Deflate of the label volumes: small = run-length tokens + dynamic Huffman '
                    '(typically below the size of zlib level 1; never above it on segmentation-like volumes), fast = fixed Huffman (larger files), zlib = as nibabel.  Same inflated bytes.')
     fs.DEFINE_string('output_csv', '', 'Sequence mode: also write the spreadsheet of aortic/eval_aortic_area.py (same columns and arithmetic) from '
