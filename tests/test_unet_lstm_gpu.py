@@ -292,3 +292,15 @@ def test_bf16_direct_convlstm_is_deterministic_and_agrees_with_the_winograd_form
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_lstm_bf16.py')], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900,
                        env=dict(os.environ, PYTHONPATH=root))
     assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == 'OK', r.stdout[-2000:]
+
+
+def test_other_window_lengths_and_class_counts():
+    """The fused ConvLSTM for unrolled lengths T in {1, 3, 5, 13} and 2 / 3 / 4 classes (tools/check_lstm_variants.py): fp32 logits within 1e-3 of the fp64
+    restatement, the cine path finite with pred = argmax(prob), the bf16 form >= 97 % label agreement."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_lstm_variants.py')], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900,
+                       env=dict(os.environ, PYTHONPATH=root))
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == 'OK', r.stdout[-2000:]
