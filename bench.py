@@ -397,7 +397,13 @@ def other_configs_probe(device):
         cine(5)
         tl16 = (time.perf_counter() - t0) / 5
         pl16 = pred.cpu().numpy()
+        # algorithmic HBM bytes of the bf16 ConvLSTM part per pixel and cine: 16 steps x (gx 64 x 2 + h in 16 x 2 + c in / out 2 x 16 x 4 + h out 16 x 2), the x pass
+        # (x 16 x 2 in, gx 128 x 2 + 2 x (c1 16 x 4 + h1 16 x 2) out), the output pass (18 hidden maps x 16 x 2 in, prob + labels 16 out)
+        bytes16 = (16 * 320 + 480 + 592) * float(F * 256 * 256)
         lstm_bf16 = {'value': round(F / tl16, 1), 'unit': 'frames/s', 'ms_per_cine': round(tl16 * 1e3, 3),
+                     'roofline': {'bound': 'hbm', 'peak': 8000.0, 'unit': 'GB/s', 'achieved': round(bytes16 / tl16 / 1e9, 1), 'frac': round(bytes16 / tl16 / 8e12, 4),
+                                  'algorithmic_bytes_lstm_part': bytes16, 'traffic': None,
+                                  'note': 'ConvLSTM part only over the whole cine time (the bf16 U-Net features take ~1.3 ms of it); counters: profiles/r05_unet_lstm_bf16*'},
                      'dice_vs_fp32': {'class1': round(float(np_categorical_dice(pl16, pl32, 1)), 4), 'class2': round(float(np_categorical_dice(pl16, pl32, 2)), 4)},
                      'label_disagreement': round(float((pl16 != pl32).mean()), 5)}
     # reference-graph FLOPs with the features computed once per frame (the reference recomputes the U-Net for each of the 9 window positions):
