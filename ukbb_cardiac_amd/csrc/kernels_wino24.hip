@@ -414,6 +414,29 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
                 fm_raw = a.ls_gx_map[n];
                 if (a.in0_map) ci_raw = a.in0_map[n];
             }
+            // LS 2 with ONE tile block per wave (8 x 16-pixel regions: 96 accumulators): room for the whole epilogue's gx / c (40 registers) to be requested inside the
+            // matrix phase, right behind the item's last own weight-fragment request (vmcnt retires in order; the fragments requested behind them are the next item's)
+            constexpr bool PRE = LS == 2 && CTB == 1;
+            [[maybe_unused]] f32x4 gxp[PRE ? 8 : 1];
+            [[maybe_unused]] float cpf[PRE ? 8 : 1];
+            [[maybe_unused]] auto ls_prefetch = [&]() {
+                if constexpr (PRE) {
+                    constexpr int GBp = BF ? 8 : 16;
+                    const int fm = __builtin_amdgcn_readfirstlane(fm_raw), ci = __builtin_amdgcn_readfirstlane(ci_raw);
+                    const unsigned char *gx_r = reinterpret_cast<const unsigned char *>(a.ls_gx) + ((((size_t)fm * regions + r) * 4 + wave) * 8 * 64 + lane) * GBp;
+                    const float *c_r = a.ls_c_in + (((size_t)ci * regions + r) * 4 + wave) * 8 * 64 + lane;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        if constexpr (BF) {
+                            const u32x2 d = *reinterpret_cast<const u32x2 *>(gx_r + (size_t)e * 64 * GBp);
+                            const unsigned d0 = d[0], d1 = d[1];
+                            gxp[e] = f32x4{__builtin_bit_cast(float, d0 << 16), __builtin_bit_cast(float, d0 & 0xffff0000u),
+                                           __builtin_bit_cast(float, d1 << 16), __builtin_bit_cast(float, d1 & 0xffff0000u)};
+                        } else gxp[e] = ld4_s(reinterpret_cast<const float *>(gx_r + (size_t)e * 64 * GBp));
+                        cpf[e] = ld1_s(c_r + (size_t)e * 64);
+                    }
+                }
+            };
             auto chunk = [&](auto firstc, int ch) {
                 constexpr bool FIRST = decltype(firstc)::value;
                 STAMP(sc0)
@@ -436,6 +459,7 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
                         else                        aq[k0 % AD] = ld4(wn + (k0 + AD - NK) * 64 * 4);
                         if constexpr (k1 + AD < NK) aq[k1 % AD] = ld4(wp + (k1 + AD) * 64 * 4);
                         else                        aq[k1 % AD] = ld4(wn + (k1 + AD - NK) * 64 * 4);
+                        if constexpr (PRE && k1 + AD == NK - 1) ls_prefetch();
                         if constexpr (p + BD < NK / 2) {
                             bp[(p + BD) % BRG][0] = ld4(vs + (k0 + 2 * BD) * NT * WKC + vofs0);
                             bp[(p + BD) % BRG][1] = ld4(vs + (k1 + 2 * BD) * NT * WKC + vofs0);
@@ -525,7 +549,10 @@ __global__ __launch_bounds__(512) void wino24_pc_kernel(const ConvArgs a) {
                         T0[tb][j] = (m0 + m1) + m2;
                         T1[tb][j] = (m1 - m2) - m3;
                     }
-                    if constexpr (LS == 2) {            // this tile block's gx and c on their way while the next block's rows are formed
+                    if constexpr (PRE) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { gxv[tb][e] = (dg & 2) ? f32x4{0.f, 0.f, 0.f, 0.f} : gxp[e]; cv[tb][e] = (dg & 2) ? 0.f : cpf[e]; }
+                    } else if constexpr (LS == 2) {     // this tile block's gx and c on their way while the next block's rows are formed
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             if (dg & 2) { gxv[tb][e] = f32x4{0.f, 0.f, 0.f, 0.f}; cv[tb][e] = 0.f; continue; }
