@@ -415,13 +415,26 @@ def other_configs_probe(device):
     # h out 16 (16 steps), the x pass (x in 16, gx out 2 x 64, c1 / h1 out 2 x 32), the output pass (18 hidden maps in, prob + labels out)
     px = F * hw * 4.0
     bytes_l = 16 * (64 + 16 + 32 + 16) * px + (16 + 128 + 64) * px + (18 * 16 + 4) * px
+    def lstm_traffic(tag):
+        # measured HBM bytes per cine of the ConvLSTM kernels from a counter file of these very sources (tools/profile_lstm.sh), or (None, why)
+        try:
+            tj = json.load(open(os.path.join(ROOT, 'profiles', 'r05_unet_lstm%s_traffic.json' % tag)))
+            if tj.get('kernel_source_sha') == kernel_source_sha():
+                return tj['hbm_bytes_per_cine_lstm_kernels'], 'profiles/r05_unet_lstm%s_traffic.json' % tag
+        except Exception:
+            pass
+        return None, 'no counter file of this build (tools/profile_lstm.sh)'
+    tr32, tr32_src = lstm_traffic('')
+    tr16, tr16_src = lstm_traffic('_bf16')
+    lstm_bf16['roofline']['traffic'] = tr16
+    lstm_bf16['roofline']['traffic_source'] = tr16_src
     out['unet_lstm_cine'] = {
         'workload': 'UNet-LSTM_ao (network_ao.py:255-399 + the window tiling of deploy_network_ao.py:129-183): one slice position, 100 frames '
                     'of 256x256 resident in HBM, fp32; prob [F,H,W,3] + int32 labels out',
         'value': round(F / tl, 1), 'unit': 'frames/s', 'ms_per_cine': round(tl * 1e3, 3), 'bf16': lstm_bf16,
         'roofline': {'bound': 'hbm', 'peak': 8000.0, 'unit': 'GB/s',
                      'achieved': round(bytes_l / tl / 1e9, 1), 'frac': round(bytes_l / tl / 8e12, 4),
-                     'algorithmic_bytes_lstm_part': bytes_l, 'traffic': None,
+                     'algorithmic_bytes_lstm_part': bytes_l, 'traffic': tr32, 'traffic_source': tr32_src,
                      'note': 'ConvLSTM part only (the U-Net features of the 100 frames add ~4 ms of MFMA-bound work to the same wall time, so this '
                              'is a lower bound of the rate the LSTM kernels reach); per-kernel times and counter traffic: profiles/r05_unet_lstm_*',
                      'effective_tflops_reference_graph_features_once': round(flop_l / tl / 1e12, 1)}}

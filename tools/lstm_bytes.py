@@ -55,6 +55,18 @@ def main(out):
         print('%-44s %9.1f %9.1f %10.3f %10s %10s %12s' % (k[:44], per, us, ms, '%.1f' % mb if mb is not None else '-',
                                                             '%.2f' % (mb / us) if mb is not None else '-', '%.4g' % mf if mf is not None else '-'))
     print('sum of kernel time %.2f ms per cine; measured HBM bytes %.2f GB per cine' % (total_ms, total_hbm / 1e3))
+    # what bench.py quotes as the cine's measured traffic: stamped with the kernel sources it was collected from
+    import json
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    lstm_mb = sum((2 * tot[k]['FETCH_SIZE'] / cnt[k]['FETCH_SIZE'] + tot[k]['WRITE_SIZE'] / cnt[k]['WRITE_SIZE']) * 1024 / 1e6 * (calls / n_trace)
+                  for k, (calls, us) in stats.items() if ('lstm' in k or 'ls' in k.lower() and 'wino24_pc_kernel' in k and k.rstrip('>').split(',')[3].strip() in ('1', '2'))
+                  and cnt[k].get('FETCH_SIZE') and cnt[k].get('WRITE_SIZE'))
+    with open(os.path.join(out, 'lstm_traffic.json'), 'w') as f:
+        json.dump({'kernel_source_sha': bench.kernel_source_sha(), 'hbm_bytes_per_cine': total_hbm * 1e6, 'hbm_bytes_per_cine_lstm_kernels': lstm_mb * 1e6,
+                   'kernel_ms_per_cine': total_ms,
+                   'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/bench_unet_lstm.py (tools/profile_lstm.sh); HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB units, gfx950 correction), '
+                             'per-kernel means x launches per cine'}, f)
     Wn, HW = 100, 256 * 256
     m = Wn * HW * 4 / 1e6                                               # MB per channel of one step's maps
     print('algorithmic bytes of one LSTM step (MB): read x 16 ch %.0f + h 16 ch %.0f + c %.0f, write c %.0f + h %.0f = %.0f;'
