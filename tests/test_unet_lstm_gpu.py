@@ -304,3 +304,25 @@ def test_other_window_lengths_and_class_counts():
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_lstm_variants.py')], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900,
                        env=dict(os.environ, PYTHONPATH=root))
     assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == 'OK', r.stdout[-2000:]
+
+
+def test_aortic_script_with_precision_bf16_on_the_default_model(tmp_path, model):
+    """`deploy_network_ao.py --precision bf16` with the default model (UNet-LSTM) ran an untested mode.  Now: the script's seg_ao.nii.gz under
+    --precision bf16 against its own fp32 output on the same subject: int32, same shape, >= 98 % of the voxels equal."""
+    from ukbb_cardiac_amd import deploy_network_ao, nifti
+    from ukbb_cardiac_amd.phantom import cine_phantom
+    from ukbb_cardiac_amd.weights import save_blob
+    arch, params, eng = model
+    mp = str(tmp_path / 'UNet-LSTM_ao')
+    save_blob(mp + '.ukbbw', arch, params)
+    vol = np.asfortranarray(np.round(cine_phantom(20, 200, 180, seed=9)[..., 0].transpose(1, 2, 0)[:, :, None, :] * 1000.0).astype(np.float32))
+    segs = {}
+    for prec in ('fp32', 'bf16'):
+        d = tmp_path / prec / 'subj1'
+        d.mkdir(parents=True)
+        nifti.save(vol, str(d / 'ao.nii.gz'), np.diag([1.6, 1.6, 6.0, 1.0]), pixdim=[1, 1.6, 1.6, 6, 0.01, 0, 0, 0])
+        deploy_network_ao.main(['--seq_name', 'ao', '--data_dir', str(tmp_path / prec), '--model_path', mp, '--precision', prec])
+        segs[prec] = nifti.load(str(d / 'seg_ao.nii.gz')).get_data()
+    assert segs['bf16'].dtype == np.int32 and segs['bf16'].shape == vol.shape
+    assert len(np.unique(segs['fp32'])) > 1
+    assert (segs['bf16'] == segs['fp32']).mean() >= 0.98
