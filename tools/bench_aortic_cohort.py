@@ -16,6 +16,7 @@ if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--cohort', type=int, default=24)
     ap.add_argument('--io_threads', default='2,4,8')
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'])
     args = ap.parse_args()
     from ukbb_cardiac_amd import deploy_network_ao, nifti
     from ukbb_cardiac_amd.arch import MODELS
@@ -25,6 +26,8 @@ if __name__ == '__main__':
     arch = MODELS['UNet-LSTM_ao']
     params = synthetic_params(arch, 1234)
     eng = Engine(arch, params)
+    if args.precision != 'fp32':
+        eng.set_precision(args.precision)
     X, Y, T = 240, 196, 100
     vols = [np.asfortranarray(np.round(cine_phantom(T, X, Y, seed=70 + i)[..., 0].transpose(1, 2, 0)[:, :, None, :] * 1000.0).astype(np.float32))
             for i in range(3)]
@@ -37,8 +40,8 @@ if __name__ == '__main__':
             os.makedirs(os.path.join(src, 's%03d' % i))
             nifti.save(vols[i % 3], os.path.join(src, 's%03d' % i, 'ao.nii.gz'), np.diag([1.6, 1.6, 6.0, 1.0]),
                        pixdim=[1, 1.6, 1.6, 6, 0.01, 0, 0, 0])
-        print('aortic cohort: %d subjects of %dx%dx1x%d float32, ao.nii.gz %.1f MB each' %
-              (args.cohort, X, Y, T, os.path.getsize(os.path.join(src, 's000', 'ao.nii.gz')) / 1e6), flush=True)
+        print('aortic cohort (%s): %d subjects of %dx%dx1x%d float32, ao.nii.gz %.1f MB each' %
+              (args.precision, args.cohort, X, Y, T, os.path.getsize(os.path.join(src, 's000', 'ao.nii.gz')) / 1e6), flush=True)
         cine = lambda f, R, r, ts=1: eng.run_cine(f, R, r, ts)[0]
         for thr in [0] + [int(v) for v in args.io_threads.split(',')]:
             work = os.path.join(root, 'run%d' % thr)
