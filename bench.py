@@ -187,6 +187,17 @@ def sustained_probe(step, n, dev_index, seconds=10.0, est_ms=1.3):
                     'beside the queued steps' % dt}
 
 
+def usable_cpus():
+    """CPUs this process can really run on at once: min(scheduler affinity, cgroup bandwidth quota, logical CPUs)."""
+    q = cpu_quota()
+    c = [q['logical_cpus'] or 1]
+    if q.get('sched_affinity_cpus'):
+        c.append(q['sched_affinity_cpus'])
+    if q.get('cgroup_cpus'):
+        c.append(max(1, int(round(q['cgroup_cpus']))))
+    return max(1, min(c))
+
+
 def physical_cores():
     try:
         import psutil
@@ -195,22 +206,26 @@ def physical_cores():
         return os.cpu_count() or 1
 
 
-def cpu_leg(which, target_seconds=6.0):
+def cpu_leg(which, target_seconds=None):
     """Runs in a CHILD process of rank 0 (fresh thread pools, no GPU context; two OpenMP runtimes spinning in one
     process cost an order of magnitude on the 256-thread GPU hosts) and prints one JSON object."""
     from ukbb_cardiac_amd.arch import MODELS
     from ukbb_cardiac_amd.phantom import uniform_slices
     from ukbb_cardiac_amd.weights import pack_flat, synthetic_params
+    if target_seconds is None:
+        target_seconds = float(os.environ.get('UKBB_CPU_LEG_SECONDS', '6.0'))
     arch = MODELS['FCN_sa']
     params = synthetic_params(arch, 1234)
     img64 = uniform_slices(BATCH, H, W, seed=1)
     if which == 'c':
+        # one thread count per child process (OMP_NUM_THREADS is read when the OpenMP runtime starts): cpu_baseline() sweeps
         from oracle import c_oracle
         flat = pack_flat(arch, params)
         img8 = img64[:8]
         rc, nc, tc = _timed(lambda: c_oracle.forward(arch, flat, img8, want_logits=False), 8, target_seconds, 400)
         print(json.dumps({'value': round(rc, 2), 'unit': 'slices/s', 'cores': c_oracle.num_threads(),
-                          'sample': '%d slices (batches of 8) through oracle/fcn_oracle.c (plain C, OpenMP, unfused), %.1f s' % (nc, tc)}))
+                          'sample': '%d slices (batches of 8) through oracle/fcn_oracle.c (plain C, OpenMP, unfused) on %d OpenMP threads, %.1f s'
+                                    % (nc, c_oracle.num_threads(), tc)}))
         return
     import torch
     from oracle.torch_oracle import TorchFCN
@@ -218,7 +233,8 @@ def cpu_leg(which, target_seconds=6.0):
     # thread count: all logical CPUs is what SURVEY.md 8(d) names, but on the SMT hosts of the GPU boxes oneDNN is
     # several times slower there than at the physical core count; take the fastest of a short ascending sweep
     logical, phys = os.cpu_count() or 1, physical_cores()
-    cands = sorted({c for c in (8, 16, 32, 64, phys // 2, phys, logical) if 1 <= c <= logical})
+    usable = usable_cpus()
+    cands = sorted({c for c in (max(1, usable // 2), usable, 2 * usable, 8, 16, 32, 64, phys // 2, phys, logical) if 1 <= c <= logical})
     # swept on the timed batch itself (r02 swept on 4 slices and picked a count that was not the fastest at N = 64)
     probe, best_t, best_n, sweep = img64, None, None, {}
     net(img64[:4])
@@ -266,7 +282,19 @@ def cpu_baseline():
             return {'error': (r.stderr or r.stdout)[-400:]}
         return json.loads(r.stdout.strip().splitlines()[-1])
     torch_leg = child('torch', {})
-    c_leg = child('c', {'OMP_NUM_THREADS': str(physical_cores())})
+    # C/OpenMP port: thread counts around what the container may use (quota / 2, quota, 2 x quota), one short child each, then the
+    # fastest count timed for the full sample; `cores` is the thread count that leg really ran with (r05 reported the 128 threads of
+    # a 16-CPU quota as "cores")
+    usable = usable_cpus()
+    sweep = {}
+    for c in sorted({max(1, usable // 2), usable, min(2 * usable, os.cpu_count() or usable)}):
+        leg = child('c', {'OMP_NUM_THREADS': str(c), 'OMP_DYNAMIC': 'FALSE', 'UKBB_CPU_LEG_SECONDS': '2.0'})
+        sweep[c] = leg.get('value', leg.get('error'))
+    ok_counts = [c for c, v in sweep.items() if isinstance(v, (int, float))]
+    best_c = max(ok_counts, key=lambda c: sweep[c]) if ok_counts else usable
+    c_leg = child('c', {'OMP_NUM_THREADS': str(best_c), 'OMP_DYNAMIC': 'FALSE'})
+    c_leg['thread_sweep_slices_per_s'] = sweep
+    c_leg['usable_cpus'] = usable
     # the headline CPU figure is the FASTEST leg measured (a slow baseline would flatter any GPU/CPU ratio); all legs are kept
     legs = {'torch_cpu': torch_leg, 'c_port': c_leg}
     ok = {k: v for k, v in legs.items() if 'value' in v}
@@ -403,7 +431,7 @@ def other_configs_probe(device):
         lstm_bf16 = {'value': round(F / tl16, 1), 'unit': 'frames/s', 'ms_per_cine': round(tl16 * 1e3, 3),
                      'roofline': {'bound': 'hbm', 'peak': 8000.0, 'unit': 'GB/s', 'achieved': round(bytes16 / tl16 / 1e9, 1), 'frac': round(bytes16 / tl16 / 8e12, 4),
                                   'algorithmic_bytes_lstm_part': bytes16, 'traffic': None,
-                                  'note': 'ConvLSTM part only over the whole cine time (the bf16 U-Net features take ~1.3 ms of it); counters: profiles/r05_unet_lstm_bf16*'},
+                                  'note': 'ConvLSTM part only over the whole cine time (the bf16 U-Net features take ~1.3 ms of it); counters: profiles/r*_unet_lstm_bf16*'},
                      'dice_vs_fp32': {'class1': round(float(np_categorical_dice(pl16, pl32, 1)), 4), 'class2': round(float(np_categorical_dice(pl16, pl32, 2)), 4)},
                      'label_disagreement': round(float((pl16 != pl32).mean()), 5)}
     # reference-graph FLOPs with the features computed once per frame (the reference recomputes the U-Net for each of the 9 window positions):
@@ -417,12 +445,14 @@ def other_configs_probe(device):
     bytes_l = 16 * (64 + 16 + 32 + 16) * px + (16 + 128 + 64) * px + (18 * 16 + 4) * px
     def lstm_traffic(tag):
         # measured HBM bytes per cine of the ConvLSTM kernels from a counter file of these very sources (tools/profile_lstm.sh), or (None, why)
-        try:
-            tj = json.load(open(os.path.join(ROOT, 'profiles', 'r05_unet_lstm%s_traffic.json' % tag)))
-            if tj.get('kernel_source_sha') == kernel_source_sha():
-                return tj['hbm_bytes_per_cine_lstm_kernels'], 'profiles/r05_unet_lstm%s_traffic.json' % tag
-        except Exception:
-            pass
+        import glob
+        for c in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_unet_lstm%s_traffic.json' % tag)), reverse=True):
+            try:
+                tj = json.load(open(c))
+                if tj.get('kernel_source_sha') == kernel_source_sha():
+                    return tj['hbm_bytes_per_cine_lstm_kernels'], os.path.relpath(c, ROOT)
+            except Exception:
+                pass
         return None, 'no counter file of this build (tools/profile_lstm.sh)'
     tr32, tr32_src = lstm_traffic('')
     tr16, tr16_src = lstm_traffic('_bf16')
@@ -436,7 +466,7 @@ def other_configs_probe(device):
                      'achieved': round(bytes_l / tl / 1e9, 1), 'frac': round(bytes_l / tl / 8e12, 4),
                      'algorithmic_bytes_lstm_part': bytes_l, 'traffic': tr32, 'traffic_source': tr32_src,
                      'note': 'ConvLSTM part only (the U-Net features of the 100 frames add ~4 ms of MFMA-bound work to the same wall time, so this '
-                             'is a lower bound of the rate the LSTM kernels reach); per-kernel times and counter traffic: profiles/r05_unet_lstm_*',
+                             'is a lower bound of the rate the LSTM kernels reach); per-kernel times and counter traffic: profiles/r*_unet_lstm_*',
                      'effective_tflops_reference_graph_features_once': round(flop_l / tl / 1e12, 1)}}
     arch = MODELS['FCN_sa']
     x10 = torch.from_numpy(uniform_slices(10, H, W, seed=1)).to(device)
@@ -446,6 +476,104 @@ def other_configs_probe(device):
     out['reference_call_shape_n10'] = {'workload': 'FCN_sa, N = 10 x 192x208 (one sess.run of the reference), own handle', 'value': round(10 / t10, 1),
                                        'unit': 'slices/s', 'ms_per_step': round(t10 * 1e3, 4)}
     return out
+
+
+def config4_cohort_probe(dev_index, rank, world, n_subjects, barrier=None):
+    """BASELINE.json configs[3]: `n_subjects` synthetic 192x208x10x50 subjects generated on the device from
+    seed = subject id, each through the real device stages of common/deploy_network.py:83-131 (exact percentiles, clip / rescale /
+    pad / transpose, forward in 128-slice batches, label unpack + per-frame counts, uint8 labels to pinned host memory; the ES frame
+    is picked from the counts) -- ukbb_cardiac_amd/synthetic_cohort.py.  Subject i runs on rank i mod G, no collective: `barrier`
+    (reached by every rank whatever happened before it) only lines the ranks' clocks up.  Returns this rank's record."""
+    import torch
+    from ukbb_cardiac_amd.arch import MODELS
+    from ukbb_cardiac_amd.engine import Engine
+    from ukbb_cardiac_amd.synthetic_cohort import SHAPE, run_cohort, stage_times
+    from ukbb_cardiac_amd.weights import synthetic_params
+    arch = MODELS['FCN_sa']
+    dev = torch.device('cuda', dev_index)
+    eng, err = None, None
+    try:
+        eng = Engine(arch, synthetic_params(arch, 1234), device=dev_index)
+        warm = run_cohort(eng, range(4), rank=0, world=1)                    # allocations, plans, first touch of the pinned buffers
+        del warm
+        torch.cuda.synchronize(dev)
+    except Exception as e:
+        err = repr(e)[-300:]
+    if barrier:
+        barrier()
+    if err:
+        return {'error': err}
+    X, Y, Z, T = SHAPE
+    try:
+        free_before = torch.cuda.mem_get_info(dev)[0]
+        reserved_before = torch.cuda.memory_reserved(dev)
+        t0 = time.perf_counter()
+        rec = run_cohort(eng, range(n_subjects), rank=rank, world=world)
+        dt = time.perf_counter() - t0                                        # from the common start to THIS rank's last result
+        del rec['pipeline']
+        torch.cuda.synchronize(dev)
+        free_after = torch.cuda.mem_get_info(dev)[0]
+        stages = stage_times(eng) if rank == 0 else None
+    except Exception as e:
+        return {'error': repr(e)[-300:]}
+    finally:
+        eng.close()
+    out = {'workload': '%d synthetic subjects of %dx%dx%dx%d (%d slices each) generated on the device from seed = subject id '
+                       '(ukbb_fcn_synth_volume), subject i on rank i mod %d; per subject: select_kth (exact 1 / 99 percentiles) -> rescale_pack -> '
+                       'FCN_sa forward in 128-slice batches -> unpack_labels + per-frame class counts -> uint8 label volume to pinned host memory, '
+                       'ES frame from the counts; 2 subjects in flight on 3 streams (SubjectPipeline); host gzip / file I/O excluded'
+                       % (n_subjects, X, Y, Z, T, Z * T, world),
+           'subjects_this_rank': rec['subjects'], 'seconds_this_rank': round(dt, 4),
+           'device_free_bytes_before': int(free_before), 'device_free_bytes_after': int(free_after),
+           'device_memory_delta_mb': round((free_before - free_after) / 1e6, 2),
+           # the pipeline's device buffers are torch tensors: freed ones stay in torch's caching allocator (that, not a leak, is the
+           # constant ~1 GB "less free" tools/soak.py shows after its first subject-pipeline leg)
+           'torch_reserved_bytes_before': int(reserved_before), 'torch_reserved_bytes_after': int(torch.cuda.memory_reserved(dev))}
+    if stages:
+        tot = sum(stages.values())
+        out['stage_ms_one_subject_unoverlapped'] = stages
+        out['network_fraction_of_device_time'] = round(stages['network'] / tot, 4)
+        out['network_only_slices_per_s'] = round(Z * T / (stages['network'] * 1e-3), 1)
+    return out
+
+
+def drop_in_hipsession_probe(dev_index):
+    """The literal drop-in surface: INTEGRATION.md's `HipSession` stub (executed verbatim from the file, as
+    tests/test_deploy_gpu.py::test_integration_md_hipsession_snippet does), called the way common/deploy_network.py:103-116 calls
+    its session -- 50 x sess.run(['prob:0', 'pred:0'], {'image:0': pageable float32 [10,192,208,1]}) per subject -- through
+    ukbb_fcn_forward_host (H2D + forward + D2H of prob AND pred, synchronous)."""
+    import re
+    import tempfile
+    import numpy as np
+    from ukbb_cardiac_amd import _lib
+    from ukbb_cardiac_amd.arch import MODELS
+    from ukbb_cardiac_amd.phantom import uniform_slices
+    from ukbb_cardiac_amd.weights import save_blob, synthetic_params
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    stub = [b for b in re.findall(r'```python\n(.*?)```', text, re.S) if 'class HipSession' in b]
+    ns = {}
+    exec(compile(stub[0], 'INTEGRATION.md', 'exec'), ns)
+    arch = MODELS['FCN_sa']
+    with tempfile.TemporaryDirectory() as td:
+        mp = os.path.join(td, 'FCN_sa')
+        save_blob(mp + '.ukbbw', arch, synthetic_params(arch, 1234))
+        vol = uniform_slices(500, H, W, seed=1).reshape(50, 10, H, W, 1)                # one subject: 50 frames x 10 slices
+        with ns['HipSession'](mp, lib=_lib.LIB_PATH, device=dev_index) as sess:
+            for t in range(3):
+                sess.run(['prob:0', 'pred:0'], feed_dict={'image:0': vol[t], 'training:0': False})
+            t0 = time.perf_counter()
+            for t in range(50):
+                prob, pred = sess.run(['prob:0', 'pred:0'], feed_dict={'image:0': vol[t], 'training:0': False})
+            dt = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            for t in range(50):
+                pred = sess.run('pred:0', feed_dict={'image:0': vol[t], 'training:0': False})
+            dt_stub_pred = time.perf_counter() - t0
+    return {'workload': "INTEGRATION.md HipSession.run(['prob:0','pred:0']) 50 x N = 10 x 192x208 from pageable numpy (deploy_network.py:103-116 "
+                        "call pattern), ukbb_fcn_forward_host: H2D + forward + D2H of prob (6.4 MB) and pred (1.6 MB) per call, synchronous",
+            'value': round(500 / dt, 1), 'unit': 'slices/s', 'ms_per_call': round(dt / 50 * 1e3, 3),
+            'stub_asked_for_pred_only': {'value': round(500 / dt_stub_pred, 1), 'unit': 'slices/s',
+                                         'note': 'same stub, fetches = "pred:0": the stub still produces and copies prob (it always passes both buffers)'}}
 
 
 def f32x3_probe(eng, x, n, steps, head_index):
@@ -492,6 +620,9 @@ def main():
     ap.add_argument('--no-kernel-events', action='store_true',
                     help='do not bracket kernels with HIP events in the timed region (roofline becomes null)')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the config-5 (aortic U-Net fp32 / bf16) and N = 10 probes')
+    ap.add_argument('--cohort-subjects', type=int, default=1000,
+                    help='BASELINE configs[3]: synthetic 500-slice subjects run through the device subject pipeline after the timed region '
+                         '(other_configs.config4_cohort; every rank takes i mod G; 0 = skip)')
     ap.add_argument('--inflight-probe', action='store_true',
                     help='after the timed region also measure the same steps with two batches in flight on two streams '
                          '(extra field two_batches_in_flight; off by default so that a rocprofv3 trace of the default command '
@@ -662,6 +793,30 @@ def main():
             'per_kernel_effective_frac_reference_graph': {nm: round(tf(m, a) / PEAK_FP32_MFMA_TFLOPS, 3) for nm, m, a in zip(names, macs, avg)},
         }
 
+    # BASELINE configs[3] on every rank (subject i -> rank i mod G, no collective; a barrier lines the clocks up, the slowest rank's
+    # time from that barrier to its last result is the cohort's time)
+    cohort = None
+    if args.cohort_subjects > 0 and not args.no_other_configs:
+        mine_c = config4_cohort_probe(dev_index, rank, world, args.cohort_subjects, barrier if world > 1 else None)
+        allc = [mine_c]
+        if world > 1:
+            allc = [None] * world
+            dist.all_gather_object(allc, mine_c)
+        cohort = allc[0]
+        errs = [c['error'] for c in allc if 'error' in c]
+        if errs:
+            cohort = {'error': errs[0], 'ranks_failed': len(errs)}
+        else:
+            t_max = max(c['seconds_this_rank'] for c in allc)
+            n_sl = args.cohort_subjects * 500
+            cohort.update({'value': round(n_sl / t_max, 1), 'unit': 'slices/s', 'subjects_per_s': round(args.cohort_subjects / t_max, 2),
+                           'seconds_max_over_ranks': round(t_max, 4), 'n_gpus': world})
+            if world > 1:
+                cohort['scaling'] = 'strong (one fixed cohort split over the ranks)'
+                cohort['per_rank'] = [{k: c.get(k) for k in ('subjects_this_rank', 'seconds_this_rank', 'device_memory_delta_mb')} for c in allc]
+            elif 'network_only_slices_per_s' in cohort:
+                cohort['pipeline_efficiency_vs_network_only'] = round(cohort['value'] / cohort['network_only_slices_per_s'], 4)
+
     if rank == 0:
         slices = world * n * args.steps
         value = slices / elapsed_max
@@ -694,6 +849,12 @@ def main():
                 out['other_configs'] = other_configs_probe(dev)
             except Exception as e:                                    # never lose the headline line to a side probe
                 out['other_configs'] = {'error': repr(e)[-300:]}
+            try:
+                out['other_configs']['drop_in_hipsession'] = drop_in_hipsession_probe(dev_index)
+            except Exception as e:
+                out['other_configs']['drop_in_hipsession'] = {'error': repr(e)[-300:]}
+        if cohort is not None:
+            out.setdefault('other_configs', {})['config4_cohort'] = cohort
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         # last, and long enough for an outside sampler at a 5 s period to land inside it at least once

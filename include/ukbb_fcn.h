@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define UKBB_FCN_ABI_VERSION 6
+#define UKBB_FCN_ABI_VERSION 7
 #define UKBB_FCN_MAX_LEVEL 8
 
 #define UKBB_OK 0
@@ -92,8 +92,8 @@ void ukbb_fcn_destroy(ukbb_fcn_handle *h);
  * handle (round 3) every activation between layers is ALSO stored as bf16 in HBM (rounded once, after
  * bias + ReLU), every layer runs on the bf16 matrix instructions (16-channel layers zero-padded to the
  * 32-row shape), the first layer (fp32 arithmetic) is evaluated inside the second one's staging and
- * the logits conv + softmax / argmax inside the last conv's epilogue: 21 launches, 2.9x the fp32 rate
- * at N = 100 x 256x256.  On a UKBB_KIND_UNET_LSTM handle (round 5) the U-Net runs the same bf16-storage
+ * the logits conv + softmax / argmax inside the fused tail: 20 launches, 3.6-3.8x the fp32 rate
+ * at N = 100 x 256x256 (round 4-5 builds).  On a UKBB_KIND_UNET_LSTM handle (round 5) the U-Net runs the same bf16-storage
  * plan and the ConvLSTM runs as direct 3x3 convs on the bf16 matrix instruction with its features, the
  * hoisted x half of the gate pre-activations and the hidden maps as bf16 in HBM (accumulation and cell
  * state fp32): 8-9 ms instead of 19 per 100-frame cine, per-class Dice >= 0.98 against the fp32 cine.  On FCN handles only the operands are bf16 (fp32 activations in
@@ -150,7 +150,13 @@ int ukbb_fcn_forward_seq(ukbb_fcn_handle *h, const float *image, int n_seq, int 
  * gets prob = NaN (0/0) and pred 0; with n_frames < T a frame that occurs twice in one window receives only
  * its LAST occurrence (numpy's `a[idx] += b` does not accumulate duplicates).
  * Requires 2*weight_R - 1 == arch.fc, time_step >= 1 and n_frames >= (T-1)/2 (below that the reference itself
- * raises IndexError).  prob [n_frames][H][W][C], pred [n_frames][H][W]. */
+ * raises IndexError).  prob [n_frames][H][W][C], pred [n_frames][H][W].
+ * Device scratch the handle keeps for this call, besides the U-Net's activations (freed by destroy): with F = n_frames, Wn = windows
+ * (= ceil(F / time_step)), HW = H*W, T = arch.fc, e = 4 bytes (fp32) or 2 (UKBB_PREC_BF16):
+ *   every step's hidden maps 2*T*Wn*HW*16*e  +  hoisted gate pre-activations 2*F*HW*64*e  +  first-step hidden maps 2*F*HW*16*e
+ *   +  cell state (2*F + Wn)*HW*16*4.
+ * F = Wn = 100 frames of 256x256: 7.5 + 3.4 + 0.8 + 1.3 = 13.0 GB in fp32, 7.2 GB in bf16 -- several handles per GPU, or cines of
+ * hundreds of frames, reach UKBB_ENOMEM on that, not on the U-Net (0.9 GB). */
 int ukbb_fcn_forward_cine(ukbb_fcn_handle *h, const float *image, int n_frames, int height, int width,
                           int weight_R, double weight_r, int time_step, float *prob, int32_t *pred, void *stream);
 
@@ -234,7 +240,7 @@ int64_t ukbb_fcn_gzip_labels_mode(const uint8_t *labels, uint64_t n_voxels, int 
  * ukbb_fcn_gunzip inflates a whole .gz file image (every member, zero padding between / after members
  * skipped) from src into dst and returns the number of bytes written; each member's ISIZE and -- unless
  * verify_crc is 0 -- CRC-32 are checked.  Whole-buffer decoder (64-bit bit buffer, two-level tables, wide
- * match copies, carry-less-multiply CRC), 3-4x zlib 1.2.11 on MR image data.  Strict by design: returns
+ * match copies, carry-less-multiply CRC), 1.75-2.3x zlib 1.2.11 on MR image data.  Strict by design: returns
  * UKBB_ENOMEM when the content does not fit dst_cap and UKBB_EINVAL for anything else it does not accept
  * (truncated or invalid stream, header CRC flag, trailing bytes that are not a member, CRC / length
  * mismatch); the caller falls back to zlib, which raises -- or accepts -- as before.
@@ -286,6 +292,13 @@ int64_t ukbb_fcn_get_activation(ukbb_fcn_handle *h, const char *name, float *dst
  * counter (s_memrealtime); waits for that wave only.  Run it on a stream of its own while the measured work is queued on another:
  * a single extra wave does not disturb it.  *mhz = the shader clock in MHz.  No reference counterpart (measurement only). */
 int ukbb_fcn_clock_probe(int device, void *stream, int spin_us, double *mhz);
+
+/* Synthetic subject for BASELINE.json configs[3] ("1000 synthetic subjects x 500 slices, generated on
+ * device from seed = subject id"): d_out[i] = a * b / 2048 with (a, b) = the two low 12-bit fields of splitmix64's finaliser of
+ * seed * 0x9E3779B97F4A7C15 + i -- exact in float32, so ukbb_cardiac_amd/synthetic_cohort.py reproduces it bit for bit in numpy
+ * for the oracle.  Asynchronous on `stream`.  No reference counterpart (the reference reads sa.nii.gz, common/deploy_network.py:80-83);
+ * measurement and tests only. */
+int ukbb_fcn_synth_volume(uint64_t seed, size_t n, float *d_out, void *stream);
 
 #ifdef __cplusplus
 }

@@ -182,7 +182,7 @@ def test_bench_two_rank_launch_rehearsal():
     import json
     port = 29600 + os.getpid() % 300
     cmd = ['-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
-              os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2', '--no-cpu-baseline']
+              os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2', '--no-cpu-baseline', '--cohort-subjects', '24']
     import torch
     one_gpu = torch.cuda.device_count() < 2
     r = _run(cmd + (['--rehearsal'] if one_gpu else []))
@@ -193,6 +193,12 @@ def test_bench_two_rank_launch_rehearsal():
     assert j['n_gpus'] == 2 and j['steps'] == 4 and j['scaling'] == 'weak' and j['config']['slices_per_gpu_per_step'] == 64
     assert abs(j['value'] - 2 * 64 * 4 / (j['ms_per_step'] * 4e-3)) <= 0.01 * j['value']
     assert 'cpu_baseline' not in j                        # rank 0 at N = 1 only
+    # r06: BASELINE configs[3] rides along on every rank -- subject i on rank i mod 2, no collective, the slowest rank's time counts
+    c4 = j['other_configs']['config4_cohort']
+    assert 'error' not in c4, c4
+    assert c4['n_gpus'] == 2 and [q['subjects_this_rank'] for q in c4['per_rank']] == [12, 12]
+    assert abs(c4['value'] - 24 * 500 / c4['seconds_max_over_ranks']) <= 0.01 * c4['value']
+    assert c4['seconds_max_over_ranks'] == max(q['seconds_this_rank'] for q in c4['per_rank'])
     # r04: per-rank evidence -- every rank's device, bus id and own time; the headline time is the slowest rank's
     assert [q['rank'] for q in j['ranks']] == [0, 1] and len(j['per_rank_ms_per_step']) == 2
     assert all(q['device_name'] and q['visible_devices'] >= 1 and q['ms_per_step'] > 0 for q in j['ranks'])

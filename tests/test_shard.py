@@ -115,3 +115,149 @@ def test_shards_per_gpu_and_default_device(tmp_path, monkeypatch):
     monkeypatch.setenv('UKBB_SHARD_INDEX', '1'); monkeypatch.setenv('UKBB_NUM_SHARDS', '2')
     F, _ = DN.define_flags().parse(['--data_dir', 'x'])
     assert (F.device, F.shard_index, F.num_shards) == (0, 1, 2)
+
+
+# ---- work stealing on top of the static split (claim files) ------------------------------------------------------------------
+
+def test_claim_files_are_exclusive_and_stale_ones_are_swept(tmp_path, monkeypatch):
+    import subprocess
+    import time
+    from ukbb_cardiac_amd import nifti, shard
+    d = str(tmp_path)
+    assert shard.try_claim(d, 'seg_sa') and not shard.try_claim(d, 'seg_sa')          # O_EXCL: one winner (our own live claim is not stale)
+    assert shard.try_claim(d, 'seg_la_2ch')                                            # another sequence of the same subject is another claim
+    assert open(shard.claim_path(d, 'seg_sa')).read().split() == [nifti._host_tag(), str(os.getpid())]
+    shard.release_claim(d, 'seg_sa')
+    shard.release_claim(d, 'seg_sa')                                                   # idempotent
+    assert shard.try_claim(d, 'seg_sa')
+    shard.release_claim(d, 'seg_sa')
+    # a claim of a process that no longer exists, same host and pid namespace: swept at once
+    p = subprocess.Popen([sys.executable, '-c', 'pass'])
+    p.wait()
+    open(shard.claim_path(d, 'seg_sa'), 'w').write('%s %d\n' % (nifti._host_tag(), p.pid))
+    assert shard.try_claim(d, 'seg_sa')
+    shard.release_claim(d, 'seg_sa')
+    # a claim of a LIVE process is respected
+    open(shard.claim_path(d, 'seg_sa'), 'w').write('%s %d\n' % (nifti._host_tag(), os.getppid()))
+    assert not shard.try_claim(d, 'seg_sa')
+    # a claim written on another host (pid means nothing here): respected while young, swept by age
+    open(shard.claim_path(d, 'seg_sa'), 'w').write('hdeadbeef00 %d\n' % p.pid)
+    assert not shard.try_claim(d, 'seg_sa')
+    old = time.time() - shard.CLAIM_MAX_AGE_S - 10
+    os.utime(shard.claim_path(d, 'seg_sa'), (old, old))
+    assert shard.try_claim(d, 'seg_sa')
+    shard.release_claim(d, 'seg_sa')
+    # an empty claim (its writer died between create and write) only counts as abandoned after a minute
+    open(shard.claim_path(d, 'seg_sa'), 'w').close()
+    assert not shard.try_claim(d, 'seg_sa')
+    os.utime(shard.claim_path(d, 'seg_sa'), (time.time() - 120, time.time() - 120))
+    assert shard.try_claim(d, 'seg_sa')
+
+
+def test_stealing_order_and_cpu_sets():
+    from ukbb_cardiac_amd import shard
+    subs = ['s%02d' % i for i in range(10)]
+    for g in (2, 3, 8):
+        for r in range(g):
+            o = shard.stealing_order(subs, r, g)
+            own = subjects_for_shard(subs, r, g)
+            assert sorted(o) == subs and o[:len(own)] == own                           # whole list, own static share first and in order
+            nxt = subjects_for_shard(subs, (r + 1) % g, g)
+            assert o[len(own):len(own) + len(nxt)] == nxt[::-1]                        # then the neighbour's share from its tail
+    assert shard.split_cpus(range(8), 3) == [[0, 1, 2], [3, 4, 5], [6, 7]]
+    assert shard.split_cpus([5, 3, 9], 4) == [[3, 5, 9]] * 4                           # fewer CPUs than workers: everyone gets all of them
+    assert sum(shard.split_cpus(range(256), 8), []) == list(range(256))
+    assert 1 <= shard.io_threads_for(32, 8) <= 16 and shard.io_threads_for(1, 8) == 1
+    q = shard.ClaimQueue('/nonexistent', subs, 1, 2, 'seg_sa', stealing=False)
+    assert list(q) == subjects_for_shard(subs, 1, 2) and q.take('s01') and not q.held  # static mode: no files touched
+
+
+def _stealing_worker(rank, world, data_dir, port):
+    import time
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from test_host_pipeline import stub_forward
+    from ukbb_cardiac_amd import deploy_network as DN
+    F, _ = DN.define_flags().parse(['--data_dir', data_dir, '--num_shards', str(world), '--shard_index', str(rank), '--output_csv',
+                                    os.path.join(os.path.dirname(data_dir), 'sa.csv')])
+    assert F.work_stealing
+
+    def forward(batch):                                        # rank 0 drew the large subjects AND is slow: the case static i mod G loses on
+        if rank == 0:
+            time.sleep(0.02 * batch.shape[0])
+        return stub_forward(batch)
+    dist.barrier()
+    done = DN.run(F, forward, log=lambda *_: None)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, done)                    # bookkeeping only; no data-path collective
+    if rank == 0:
+        subs = sorted(os.listdir(data_dir))
+        assert sorted(sum(gathered, [])) == subs, gathered     # complete ...
+        assert not set(gathered[0]) & set(gathered[1])         # ... and disjoint
+        static1 = subjects_for_shard(subs, 1, 2)
+        assert set(static1) <= set(gathered[1]) and len(gathered[1]) > len(static1), gathered     # the fast worker took over part of the slow one's share
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_deploy_with_unequal_subjects_steals_work(tmp_path):
+    from test_host_pipeline import _write_subject
+    from ukbb_cardiac_amd import measures, nifti
+    data = tmp_path / 'data'
+    data.mkdir()
+    for i in range(12):                                        # even indices (rank 0's share): 24 frames; odd: 3
+        _write_subject(data, 'subj%02d' % i, 'sa', (20, 28, 2, 24 if i % 2 == 0 else 3), 10 + i)
+    port = 29500 + (os.getpid() % 400) + 7
+    mp.spawn(_stealing_worker, args=(2, str(data), port), nprocs=2, join=True)
+    for i in range(12):
+        d = data / ('subj%02d' % i)
+        assert nifti.load(str(d / 'seg_sa.nii.gz')).data.shape == (20, 28, 2, 24 if i % 2 == 0 else 3)
+        assert not [f for f in os.listdir(d) if f.startswith('.claim') or '.tmp.' in f]           # nothing left behind
+    # the two workers' CSV parts merge into one table with every subject exactly once, stolen or not
+    assert measures.merge_shard_csv(str(tmp_path / 'sa.csv'), 2)
+    rows = open(tmp_path / 'sa.csv').read().strip().split('\n')
+    assert [r.split(',')[0] for r in rows[1:]] == ['subj%02d' % i for i in range(12)]
+
+
+_DYING_WORKER = '''
+import os, sys, time
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, 'tests'))
+from test_host_pipeline import stub_forward
+from ukbb_cardiac_amd import deploy_network as DN
+rank = int(os.environ['UKBB_SHARD_INDEX'])
+F, _ = DN.define_flags().parse(['--data_dir', sys.argv[1]])
+assert (F.num_shards, F.shard_index, F.work_stealing) == (2, rank, True)
+calls = [0]
+def forward(batch):
+    calls[0] += 1
+    if rank == 0 and sys.argv[2] == 'die' and calls[0] == 4:
+        os._exit(9)                                            # mid-subject (its second), claim file left behind, no cleanup of any kind
+    if rank == 1:
+        time.sleep(0.05)                                       # still busy with its own share when worker 0 dies
+    return stub_forward(batch)
+DN.run(F, forward, log=lambda *_: None)
+'''
+
+
+def test_a_worker_that_dies_mid_cohort_loses_nothing_but_its_exit_status(tmp_path, capfd):
+    from test_host_pipeline import _write_subject
+    from ukbb_cardiac_amd import nifti, shard
+    data = tmp_path / 'data'
+    data.mkdir()
+    for i in range(8):
+        _write_subject(data, 'subj%02d' % i, 'sa', (20, 28, 2, 3), 40 + i)
+    script = tmp_path / 'w.py'
+    script.write_text(_DYING_WORKER.format(root=ROOT))
+    rc = shard.launch(2, [str(script), str(data), 'die'])
+    assert rc == 9 and 'shard 0 of 2' in capfd.readouterr().err                      # the launcher reports the dead worker ...
+    done = [i for i in range(8) if os.path.exists(data / ('subj%02d' % i) / 'seg_sa.nii.gz')]
+    assert done == list(range(8)), done                                              # ... and the survivor drained the whole list, the orphan included
+    for i in range(8):
+        assert not [f for f in os.listdir(data / ('subj%02d' % i)) if f.startswith('.claim') or '.tmp.' in f]
+        assert nifti.load(str(data / ('subj%02d' % i) / 'seg_sa.nii.gz')).data.shape == (20, 28, 2, 3)
+    before = {i: os.path.getmtime(data / ('subj%02d' % i) / 'seg_sa.nii.gz') for i in range(8)}
+    assert shard.launch(2, [str(script), str(data), 'ok']) == 0                       # the rerun is a no-op
+    assert before == {i: os.path.getmtime(data / ('subj%02d' % i) / 'seg_sa.nii.gz') for i in range(8)}

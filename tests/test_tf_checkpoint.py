@@ -153,3 +153,21 @@ def test_lstm_cell_scope_is_matched_not_assumed(tmp_path, cell):
     write_checkpoint(prefix, t, tensor_crc=False)
     with pytest.raises(tfc.CheckpointError, match='one cell scope'):
         tfc.checkpoint_to_params(prefix)
+
+
+def test_unidirectional_conv_lstm_checkpoint_is_refused_by_name(tmp_path):
+    """common/network_ao.py:214-252 Conv_LSTM (train_network_ao.py --bidirectional=False) keeps ONE cell directly under LSTM/
+    and its output conv as LSTM/conv2d: such a checkpoint must be refused with a message that says so, not fail on a
+    'missing' LSTM/forward variable."""
+    arch = MODELS['UNet-LSTM_ao']
+    params = synthetic_params(arch, 12)
+    t = _tf_tensors(arch, params, with_slots=False)
+    uni = {n: v for n, v in t.items() if not n.startswith('LSTM/')}
+    uni['LSTM/conv_lstm_cell/kernel'] = t['LSTM/forward/conv_lstm_cell/kernel']
+    uni['LSTM/conv_lstm_cell/biases'] = t['LSTM/forward/conv_lstm_cell/biases']
+    uni['LSTM/conv2d/kernel'] = t['LSTM/output/conv2d/kernel'][:, :, :16]                # [1,1,n_hidden,n_class]
+    uni['LSTM/conv2d/bias'] = t['LSTM/output/conv2d/bias']
+    prefix = str(tmp_path / 'UNet-LSTM_uni')
+    write_checkpoint(prefix, uni, tensor_crc=False)
+    with pytest.raises(tfc.CheckpointError, match='UNIDIRECTIONAL.*bidirectional=False'):
+        tfc.checkpoint_to_params(prefix)

@@ -59,9 +59,16 @@ def main(out):
     import json
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
-    lstm_mb = sum((2 * tot[k]['FETCH_SIZE'] / cnt[k]['FETCH_SIZE'] + tot[k]['WRITE_SIZE'] / cnt[k]['WRITE_SIZE']) * 1024 / 1e6 * (calls / n_trace)
-                  for k, (calls, us) in stats.items() if ('lstm' in k or 'ls' in k.lower() and 'wino24_pc_kernel' in k and k.rstrip('>').split(',')[3].strip() in ('1', '2'))
-                  and cnt[k].get('FETCH_SIZE') and cnt[k].get('WRITE_SIZE'))
+    # the ConvLSTM launches by NAME: lstm_* kernels (cell / output / tile, the bf16 walker form) and the fused gate-conv forms of the
+    # F(2x4) kernel, whose 4th template argument LS is 1 (x pass) or 2 (time step) -- wino24_pc_kernel<TBW, BF, WM, LS, ...>
+    import re
+    is_lstm = re.compile(r'(^|[^a-z])lstm_|wino24_pc_kernel<\s*\d+\s*,\s*\w+\s*,\s*\d+\s*,\s*[12]\s*[,>]|ws_main.*\bLS\b|lstm_ws')
+    picked = [k for k in stats if is_lstm.search(k)]
+    if not picked:
+        sys.exit('lstm_bytes: no ConvLSTM kernel matched among %s -- kernel or template argument renamed? refusing to write lstm_traffic.json' % sorted(stats))
+    lstm_mb = sum((2 * tot[k]['FETCH_SIZE'] / cnt[k]['FETCH_SIZE'] + tot[k]['WRITE_SIZE'] / cnt[k]['WRITE_SIZE']) * 1024 / 1e6 * (stats[k][0] / n_trace)
+                  for k in picked if cnt[k].get('FETCH_SIZE') and cnt[k].get('WRITE_SIZE'))
+    print('ConvLSTM kernels counted: %s' % '; '.join(k[:60] for k in picked))
     with open(os.path.join(out, 'lstm_traffic.json'), 'w') as f:
         json.dump({'kernel_source_sha': bench.kernel_source_sha(), 'hbm_bytes_per_cine': total_hbm * 1e6, 'hbm_bytes_per_cine_lstm_kernels': lstm_mb * 1e6,
                    'kernel_ms_per_cine': total_ms,

@@ -12,7 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('UKBB_FCN_LIB') or os.path.join(_HERE, 'libukbb_fcn.so')   # override: A/B builds of the kernels
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_LEVEL = 8
 
 # every symbol include/ukbb_fcn.h declares
@@ -26,6 +26,7 @@ EXPORTS = [
     'ukbb_fcn_roi_compact', 'ukbb_fcn_pairwise_sum', 'ukbb_fcn_zscore_pack',
     'ukbb_fcn_gzip_labels_bound', 'ukbb_fcn_gzip_labels', 'ukbb_fcn_gzip_labels_mode', 'ukbb_fcn_gunzip', 'ukbb_fcn_gzip_crc',
     'ukbb_fcn_forward_seq', 'ukbb_fcn_forward_cine', 'ukbb_fcn_clock_probe', 'ukbb_fcn_kernel_mfma_macs_issued',
+    'ukbb_fcn_synth_volume',
 ]
 
 
@@ -111,6 +112,7 @@ def _load():
     lib.ukbb_fcn_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int, C.c_int]
     lib.ukbb_fcn_get_activation.restype = C.c_int64
     lib.ukbb_fcn_get_activation.argtypes = [vp, C.c_char_p, f32p, C.c_int64]
+    lib.ukbb_fcn_synth_volume.argtypes = [C.c_uint64, C.c_size_t, vp, vp]
     lib.ukbb_fcn_clock_probe.argtypes = [C.c_int, vp, C.c_int, C.POINTER(C.c_double)]
     if lib.ukbb_fcn_abi_version() != ABI_VERSION:
         raise ImportError('libukbb_fcn.so ABI %d != binding ABI %d: rebuild' % (lib.ukbb_fcn_abi_version(), ABI_VERSION))

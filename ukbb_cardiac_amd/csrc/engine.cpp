@@ -135,6 +135,7 @@ struct ukbb_fcn_handle {
 
     // UNet-LSTM (kind 2)
     int feat_buf = -1;                        // activation index of net['conv0_up']
+    bool lstm_bf_wino = false;                // UKBB_LSTM_BF16_WINOGRAD at plan build: fp32 Winograd arithmetic on bf16 storage (A/B form)
     int lstm_tile_cols = 0;                   // region shape of the fused gate-conv / cell kernel (kernels_wino24.hip): 32 | 16
     // lstm_gx / lstm_c1 / lstm_h1: per direction and FRAME (the x pass); lstm_c: per window; lstm_hall: per direction, step and window
     DevBuf lstm_gx, lstm_c1, lstm_h1, lstm_c, lstm_hall, lstm_probw, lstm_aux;   // lstm_aux: int maps / orders / double weights (raw bytes)
@@ -845,13 +846,18 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
         } else {
             // ConvLSTM: region shape of the fused gate-conv / cell kernel, chosen once per plan (both shapes give identical bits);
             // packed filters: the x rows of both directions as ONE 128-channel conv (groups = directions), the h rows per direction
+            // (read per plan build, like UKBB_NO_FUSE_TAIL: the A/B knob can be toggled inside one process by re-planning)
+            h->lstm_bf_wino = getenv("UKBB_LSTM_BF16_WINOGRAD") != nullptr;
             const int cfg = choose_cfg("lstm_fw", 3, 1, a.n_filter[0], a.same_dim, 4 * a.same_dim, H, W, n_hint, false, false);
             ConvConfig c;
-            if (cfg < 0 || find_cfg(cfg, c) || !is_wino24(c) || c.wm != 4 || (c.tw != 32 && c.tw != 16)) {
+            const bool have24 = cfg >= 0 && !find_cfg(cfg, c) && is_wino24(c) && c.wm == 4 && (c.tw == 32 || c.tw == 16);
+            // the bf16 plan's time steps run on launch_lstm_ws (kernels_ws.hip) and never touch the F(2x4) kernel: only the fp32 plan and the
+            // bf16-storage Winograd A/B form need that tiling
+            if (!have24 && (bf16_mode(h) != 2 || h->lstm_bf_wino)) {
                 set_err("the ConvLSTM needs the Winograd F(2x4) kernel (unset UKBB_NO_WINOGRAD / UKBB_NO_WINOGRAD24 / UKBB_CONV_CFG overrides)");
                 return UKBB_EARCH;
             }
-            h->lstm_tile_cols = c.tw;
+            h->lstm_tile_cols = have24 ? c.tw : 32;
             if (const char *e = getenv("UKBB_LSTM_TILE_COLS")) { const int v = atoi(e); if (v == 16 || v == 32) h->lstm_tile_cols = v; }   // A/B knob (identical bits)
             if (!dev_ptr(h, "lstm/wx")) {
                 const size_t per = (size_t)24 * 16 * 64;
@@ -1305,16 +1311,18 @@ int run_bilstm(ukbb_fcn_handle *h, const float *feat, int NF, const int *d_map, 
     const int T = a.fc, NHID = a.same_dim, tc = h->lstm_tile_cols;
     const size_t HW = (size_t)H * W;
     // bf16 plan: the direct-conv bf16 form (kernels_ws.hip) unless UKBB_LSTM_BF16_WINOGRAD=1 asks for the fp32 Winograd arithmetic on bf16 storage (A/B)
-    static const bool bf_wino = getenv("UKBB_LSTM_BF16_WINOGRAD") != nullptr;
-    const bool wsf = h->plan_bfio && !bf_wino;
+    const bool wsf = h->plan_bfio && !h->lstm_bf_wino;
     const size_t gxf = wsf ? lstm_ws_gx_elems(H, W) : wino24_lstm_gx_floats(H, W, tc), cf = wsf ? lstm_ws_c_floats(H, W) : wino24_lstm_c_floats(H, W, tc);
-    HIP_TRY(h->lstm_gx.ensure(2 * (size_t)NF * gxf), UKBB_ENOMEM);
-    HIP_TRY(h->lstm_c1.ensure(2 * (size_t)NF * cf), UKBB_ENOMEM);
-    HIP_TRY(h->lstm_h1.ensure(2 * (size_t)NF * HW * NHID), UKBB_ENOMEM);
-    HIP_TRY(h->lstm_c.ensure((size_t)Wn * cf), UKBB_ENOMEM);
-    HIP_TRY(h->lstm_hall.ensure(2 * (size_t)T * Wn * HW * NHID), UKBB_ENOMEM);
     const bool bf = h->plan_bfio;                        // bf16 plan: features, gx and hidden maps are bf16 in HBM
     const size_t esz = bf ? 2 : 4;
+    // Scratch of one cine (include/ukbb_fcn.h, forward_cine): gx 2 NF gxf + h1 2 NF HW NHID + hall 2 T Wn HW NHID elements of esz bytes,
+    // cell state (2 NF + Wn) cf floats.  DevBuf counts 4-byte units: the bf16 maps take half as many.
+    auto units = [esz](size_t elems) { return (elems * esz + 3) / 4; };
+    HIP_TRY(h->lstm_gx.ensure(units(2 * (size_t)NF * gxf)), UKBB_ENOMEM);
+    HIP_TRY(h->lstm_c1.ensure(2 * (size_t)NF * cf), UKBB_ENOMEM);
+    HIP_TRY(h->lstm_h1.ensure(units(2 * (size_t)NF * HW * NHID)), UKBB_ENOMEM);
+    HIP_TRY(h->lstm_c.ensure((size_t)Wn * cf), UKBB_ENOMEM);
+    HIP_TRY(h->lstm_hall.ensure(units(2 * (size_t)T * Wn * HW * NHID)), UKBB_ENOMEM);
     auto at = [esz](float *p, size_t elems) { return reinterpret_cast<float *>(reinterpret_cast<char *>(p) + elems * esz); };
     ConvArgs base{};
     base.ls_bf16 = bf ? 1 : 0;

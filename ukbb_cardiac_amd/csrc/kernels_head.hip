@@ -43,9 +43,16 @@ __host__ __device__ __forceinline__ constexpr int rowmap(int r, int g) {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#ifdef UKBB_NO_PACKED_F32
+// A/B form (r06): pairs of scalar v_fma_f32 instead of v_pk_fma_f32 (build with -fno-slp-vectorize as well, or
+// hipcc packs the gather's scalar FMAs again); tools/ab_packed.sh
+__device__ __forceinline__ float s_fma(float a, float b, float c) { float r; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return f32x2{s_fma(a[0], b[0], c[0]), s_fma(a[1], b[1], c[1])}; }
+#else
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
     f32x2 r; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
 }
+#endif
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 __device__ __forceinline__ f32x4 ldg4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }

@@ -336,6 +336,32 @@ float pairwise_combine(const float *leaf, size_t &idx, unsigned long long n) {
     return l + r;
 }
 
+// ---- synthetic subjects generated on the device ("generated on device from seed = subject id") ----
+// Voxel i of subject `seed` = a * b / 2048 with a, b the low two 12-bit fields of splitmix64's finaliser applied to
+// seed * 0x9E3779B97F4A7C15 + i: the product of two uniform integers is exact in float32 (< 2^24), so numpy reproduces the
+// volume bit for bit from integer arithmetic alone (ukbb_cardiac_amd/synthetic_cohort.py), and its density -ln(x) has the
+// heavy right tail that makes the 1 / 99 percentile clip of common/image_utils.py:72-74 matter.  One 16-byte store per thread.
+__device__ __forceinline__ float synth_voxel(unsigned long long seed_mul, unsigned long long i) {
+    unsigned long long z = seed_mul + i;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const unsigned a = (unsigned)z & 0xFFFu, b = (unsigned)(z >> 12) & 0xFFFu;
+    return (float)(a * b) * (1.0f / 2048.0f);
+}
+__global__ __launch_bounds__(256) void synth_volume_kernel(unsigned long long seed_mul, unsigned long long n, float *__restrict__ out) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * 256ull * 4ull;
+    for (unsigned long long i = ((unsigned long long)blockIdx.x * 256ull + threadIdx.x) * 4ull; i < n; i += stride) {
+        if (i + 4 <= n) {
+            float4 v;
+            v.x = synth_voxel(seed_mul, i); v.y = synth_voxel(seed_mul, i + 1); v.z = synth_voxel(seed_mul, i + 2); v.w = synth_voxel(seed_mul, i + 3);
+            *reinterpret_cast<float4 *>(out + i) = v;
+        } else {
+            for (unsigned long long j = i; j < n; ++j) out[j] = synth_voxel(seed_mul, j);
+        }
+    }
+}
+
 SelState *sel_scratch() {
     static thread_local SelState *p[MAX_DEVICES] = {nullptr};
     int d = 0;
@@ -510,6 +536,18 @@ int ukbb_fcn_zscore_pack(const float *d_vol, int X, int Y, int Z, int T, int64_t
                        (long long)sz, (long long)st, mu, den, X2, Y2, x_pre, y_pre, d_batch);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("zscore_pack: launch failed: %s", hipGetErrorString(e)); return UKBB_EDEVICE; }
+    return UKBB_OK;
+}
+
+int ukbb_fcn_synth_volume(uint64_t seed, size_t n, float *d_out, void *stream) {
+    if (!d_out || n == 0 || (reinterpret_cast<uintptr_t>(d_out) & 15)) { set_error("synth_volume: bad argument (n > 0, 16-byte aligned output)"); return UKBB_EINVAL; }
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(synth_volume_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (unsigned long long)seed * 0x9E3779B97F4A7C15ull,
+                       (unsigned long long)n, d_out);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("synth_volume: launch failed: %s (there is no CPU fallback)", hipGetErrorString(e)); return UKBB_EDEVICE; }
     return UKBB_OK;
 }
 

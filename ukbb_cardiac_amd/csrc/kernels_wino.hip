@@ -55,12 +55,22 @@ __device__ __forceinline__ void st4(float *p, const f32x4 &v) { *reinterpret_cas
 // Packed fp32 add / subtract on register pairs.  hipcc scalarises the subtractions of the input
 // transform into v_sub_f32 (+ moves) when left to itself; every VALU instruction of a producer wave
 // costs an MFMA slot, so the packed forms are spelled out.
+#ifdef UKBB_NO_PACKED_F32
+// A/B form (r06): the same arithmetic as pairs of scalar VALU instructions -- the guide prices a packed f32 op
+// beside MFMAs above two scalar ones; tools/ab_packed.sh measures it next to the fp32 MFMA streams of these kernels.
+__device__ __forceinline__ float s_add(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float s_sub(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float s_fma(float a, float b, float c) { float r; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { return f32x2{s_add(a[0], b[0]), s_add(a[1], b[1])}; }
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) { return f32x2{s_sub(a[0], b[0]), s_sub(a[1], b[1])}; }
+#else
 __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
     f32x2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
 }
 __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
     f32x2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r;
 }
+#endif
 
 __device__ __forceinline__ float relu1(float x) {   // one v_max_i32 (fmaxf adds a canonicalising second instruction)
     const int b = __builtin_bit_cast(int, x);

@@ -92,10 +92,21 @@ __device__ __forceinline__ void st1_s(float *p, float v) {
 }
 __device__ __forceinline__ void st4(float *p, const f32x4 &v) { *reinterpret_cast<f32x4 *>(p) = v; }
 
+#ifdef UKBB_NO_PACKED_F32
+// A/B form (r06): the same arithmetic as pairs of scalar VALU instructions -- the guide prices a packed f32 op
+// beside MFMAs above two scalar ones; tools/ab_packed.sh measures it next to the fp32 MFMA streams of these kernels.
+__device__ __forceinline__ float s_add(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float s_sub(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float s_fma(float a, float b, float c) { float r; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { return f32x2{s_add(a[0], b[0]), s_add(a[1], b[1])}; }
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) { return f32x2{s_sub(a[0], b[0]), s_sub(a[1], b[1])}; }
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 s, f32x2 b) { return f32x2{s_fma(a[0], s[0], b[0]), s_fma(a[1], s[1], b[1])}; }
+#else
 __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // a * s + b with a scalar factor in both halves (v_pk_fma_f32; the factor is splat into a register pair by the caller)
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 s, f32x2 b) { f32x2 r; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(s), "v"(b)); return r; }
+#endif
 
 struct V4 { f32x2 lo, hi; };                           // four channels as two packed pairs
 __device__ __forceinline__ V4 operator+(const V4 &a, const V4 &b) { return V4{pk_add(a.lo, b.lo), pk_add(a.hi, b.hi)}; }

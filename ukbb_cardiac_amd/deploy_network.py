@@ -28,7 +28,7 @@ if __package__ in (None, ''):
 
 from ukbb_cardiac_amd import measures, nifti, pipeline             # noqa: E402
 from ukbb_cardiac_amd.flags import FlagError, FlagSet              # noqa: E402
-from ukbb_cardiac_amd.shard import default_device, shard_from_env, subjects_for_shard   # noqa: E402
+from ukbb_cardiac_amd.shard import ClaimQueue, apply_cpu_set_from_env, default_device, shard_from_env   # noqa: E402
 
 
 def define_flags():
@@ -49,7 +49,7 @@ def define_flags():
                       '(float32 sequences; results identical to the host path).')
     fs.DEFINE_boolean('numpy1_casting', False, 'Rescale intensities with the float32 arithmetic numpy 1.x used when the reference '
                       'was written (1 ulp from numpy 2; host pre-processing only; INTEGRATION.md section 5).')
-    fs.DEFINE_integer('io_threads', 8, 'Reader threads (gzip NIfTI -> pinned staging) and writer threads (float64 label volume, gzip) '
+    fs.DEFINE_integer('io_threads', int(os.environ.get('UKBB_IO_THREADS', 8)), 'Reader threads (gzip NIfTI -> pinned staging) and writer threads (float64 label volume, gzip) '
                       'around the GPU in sequence mode; 0 = strictly sequential subjects as in the reference.')
     fs.DEFINE_enum('precision', 'fp32', ['fp32', 'f32x3'], 'Arithmetic of the matrix products: fp32 MFMA (default) or fp32 results from three '
                    'bf16 pieces per operand (UKBB_PREC_F32X3, include/ukbb_fcn.h; same labels, faster head).')
@@ -60,6 +60,9 @@ def define_flags():
                      'seg_sa.nii.gz.  Subjects already segmented by an earlier run are measured from their files.')
     fs.DEFINE_integer('num_shards', env_cnt, 'Number of workers sharing data_dir.')
     fs.DEFINE_integer('shard_index', env_idx, 'This worker: subjects i with i % num_shards == shard_index.')
+    fs.DEFINE_boolean('work_stealing', True, 'With num_shards > 1: after its own share a worker takes subjects of the other shards that '
+                      'nobody has claimed yet (claim file <subject>/.claim.<seg>_<seq>, created with O_EXCL; claims of dead workers are swept). '
+                      '--nowork_stealing = the strict i % num_shards split.')
     return fs
 
 
@@ -79,7 +82,7 @@ def save_sequence_outputs(data_dir, pre, seq, affine, pixdim, pred, frames):
     nifti.save(pred, '{0}/{1}_{2}.nii.gz'.format(data_dir, pre, seq), affine, pixdim, as_dtype=np.float64)
 
 
-def run_pipelined(FLAGS, engine, data_list, log=print, csv_rows=None):
+def run_pipelined(FLAGS, engine, data_list, log=print, csv_rows=None, queue=None):
     """Sequence mode with subjects overlapped: reader threads decompress the next files into pinned staging buffers,
     the GPU thread (this one) keeps up to two subjects in flight on three streams (subject_pipeline.SubjectPipeline),
     writer threads expand the uint8 labels to the reference's float64 volume, gzip and save.  Same files, byte for byte,
@@ -90,18 +93,33 @@ def run_pipelined(FLAGS, engine, data_list, log=print, csv_rows=None):
     from ukbb_cardiac_amd.subject_pipeline import SubjectPipeline
     start_time = time.time()
     seq, pre = FLAGS.seq_name, seg_prefix(FLAGS)
-    todo = []
-    for data in data_list:
-        data_dir = os.path.join(FLAGS.data_dir, data)
-        if not os.path.isdir(data_dir) or os.path.exists('{0}/{1}_{2}.nii.gz'.format(data_dir, pre, seq)):
-            log(data)
-            continue
-        image_name = '{0}/{1}.nii.gz'.format(data_dir, seq)
-        if not os.path.exists(image_name):
-            log(data)
-            log('  Directory {0} does not contain an image with file name {1}. Skip.'.format(data_dir, os.path.basename(image_name)))
-            continue
-        todo.append((data, data_dir, image_name))
+    def candidates(names, second=False):
+        """(data, data_dir, image_name) of the subjects still to segment, in walk order, each claimed right before its read is
+        scheduled (with --work_stealing a worker so holds at most window + depth claims; the rest of the list stays open)."""
+        for data in names:
+            data_dir = os.path.join(FLAGS.data_dir, data)
+            if not os.path.isdir(data_dir) or os.path.exists('{0}/{1}_{2}.nii.gz'.format(data_dir, pre, seq)):
+                if not second:
+                    log(data)
+                continue
+            image_name = '{0}/{1}.nii.gz'.format(data_dir, seq)
+            if not os.path.exists(image_name):
+                if not second:
+                    log(data)
+                    log('  Directory {0} does not contain an image with file name {1}. Skip.'.format(data_dir, os.path.basename(image_name)))
+                continue
+            if queue is not None and not queue.take(data):
+                continue                                    # another worker is on it
+            yield (data, data_dir, image_name)
+
+    def todo_items():
+        yield from candidates(data_list)
+        if queue is not None:                               # subjects a live worker held when we passed: finished by now, or orphaned
+            yield from candidates(queue.second_chance(), second=True)
+
+    def release(data):
+        if queue is not None:
+            queue.done(data)
     nthr = max(1, int(FLAGS.io_threads))
     window = nthr + 1                                   # reads allowed to run ahead of the GPU thread
     depth = 3
@@ -162,28 +180,49 @@ def run_pipelined(FLAGS, engine, data_list, log=print, csv_rows=None):
             frames = {fr: (device_pipeline.clip_like_reference(res.image[:, :, :, k], res.clip), res.labels[:, :, :, k].astype(np.float64))
                       for fr, k in (('ED', k_ed), ('ES', k_es))}
             labels, affine, pixdim = res.labels, nim.affine, nim.header['pixdim']
-            writes.append(writers.submit(lambda: save_sequence_outputs(data_dir, pre, seq, affine, pixdim, labels, frames)))
+
+            def write_then_release():
+                try:
+                    save_sequence_outputs(data_dir, pre, seq, affine, pixdim, labels, frames)
+                finally:
+                    release(data)                           # the claim outlives the subject's last file (seg_{seq}.nii.gz, written last)
+            writes.append(writers.submit(write_then_release))
+        else:
+            release(data)
         res.done()
 
     try:
-        nxt = 0
-        for i, item in enumerate(todo):
-            while nxt < len(todo) and nxt < i + window:
-                futures[nxt] = readers.submit(read, todo[nxt])
-                nxt += 1
-            nim, _ = futures.pop(i).result()
+        from collections import deque
+        todo = todo_items()
+        ahead = deque()                                     # (item, future of its read), in walk order
+
+        def top_up():
+            while len(ahead) < window:
+                item = next(todo, None)
+                if item is None:
+                    return
+                ahead.append((item, readers.submit(read, item)))
+        top_up()
+        while ahead:
+            item, fut = ahead.popleft()
+            nim, _ = fut.result()
             image = nim.get_data()
             pipe = state['pipe']
             if image.ndim != 4 or image.dtype != np.float32 or pipe is None or image.size > pipe._in_cap:
                 while inflight:                             # odd subject: drain, then take the sequential path
                     finish(*inflight.pop(0))
                 log(item[0])
-                _sequence_subject(FLAGS, item, nim, None, engine, log, processed, table_time, csv_rows)
+                try:
+                    _sequence_subject(FLAGS, item, nim, None, engine, log, processed, table_time, csv_rows)
+                finally:
+                    release(item[0])
+                top_up()
                 continue
             if len(inflight) >= depth - 1:
                 finish(*inflight.pop(0))
             pipe.submit(image)
             inflight.append((item, nim, time.time()))
+            top_up()
         while inflight:
             finish(*inflight.pop(0))
         for w in writes:
@@ -191,6 +230,8 @@ def run_pipelined(FLAGS, engine, data_list, log=print, csv_rows=None):
     finally:
         readers.shutdown(wait=True)
         writers.shutdown(wait=True)
+        if queue is not None:
+            queue.release_all()                             # an exception above must not leave live-looking claims behind
     return processed, table_time, start_time
 
 
@@ -241,7 +282,9 @@ def write_measures_csv(FLAGS, subjects, csv_rows, log=print):
     come from the device counts; a subject segmented by an earlier run (skipped above) is measured from its files the way the
     evaluation script does.  Same inclusion rule (:35: image and segmentation both exist), same order (sorted directory names)."""
     rows = []
-    for data in subjects:
+    # with --work_stealing this worker may also have segmented subjects of other shards (their rows are in csv_rows), and another
+    # worker may have taken some of this one's: both then hold a row for it -- identical text -- and the merge keeps one
+    for data in sorted(set(subjects) | set(csv_rows)):
         data_dir = os.path.join(FLAGS.data_dir, data)
         image_name, seg_name = '{0}/sa.nii.gz'.format(data_dir), '{0}/seg_sa.nii.gz'.format(data_dir)
         if data in csv_rows:
@@ -258,41 +301,54 @@ def run(FLAGS, forward, log=print, engine=None):
     """The subject loop of deploy_network.py:52-225 with ``forward`` standing for sess.run.
     With ``engine`` (and --device_preproc) float32 sequences take the device pipeline."""
     start_time = time.time()
-    data_list = subjects_for_shard(sorted(os.listdir(FLAGS.data_dir)), FLAGS.shard_index, FLAGS.num_shards)
-    processed, table_time = [], []
     seq, pre = FLAGS.seq_name, seg_prefix(FLAGS)
+    # the static split (subject i -> shard i mod num_shards) and, on top of it, claim-file work stealing in sequence mode
+    queue = ClaimQueue(FLAGS.data_dir, sorted(os.listdir(FLAGS.data_dir)), FLAGS.shard_index, FLAGS.num_shards, '%s_%s' % (pre, seq),
+                       stealing=bool(getattr(FLAGS, 'work_stealing', False)) and FLAGS.process_seq)
+    data_list = list(queue)
+    processed, table_time = [], []
     csv_rows = None
     if getattr(FLAGS, 'output_csv', ''):
         if seq != 'sa' or not FLAGS.process_seq:
             raise ValueError('--output_csv writes the table of short_axis/eval_ventricular_volume.py: it needs --seq_name sa in sequence mode')
         csv_rows = {}
-    shard_subjects = list(data_list)
+    shard_subjects = list(queue.static)                 # whose earlier-run results this worker measures for --output_csv
     if (FLAGS.process_seq and engine is not None and getattr(FLAGS, 'device_preproc', False) and getattr(FLAGS, 'io_threads', 0) > 0
             and not getattr(FLAGS, 'numpy1_casting', False)):
-        processed, table_time, _ = run_pipelined(FLAGS, engine, data_list, log, csv_rows)
+        processed, table_time, _ = run_pipelined(FLAGS, engine, data_list, log, csv_rows, queue)
         data_list = []
-    for data in data_list:
-        log(data)
+    def one_subject(data, second):
+        """One entry of the walk; ``second``: a subject another worker held when this one first came by (--work_stealing)."""
         data_dir = os.path.join(FLAGS.data_dir, data)
+        if not second:
+            log(data)
         if not os.path.isdir(data_dir):
-            continue
+            return
         if os.path.exists('{0}/{1}_{2}.nii.gz'.format(data_dir, pre, seq)):
-            continue                                   # already segmented: idempotent / resumable (:62-67)
+            return                                   # already segmented: idempotent / resumable (:62-67)
         if FLAGS.process_seq:
             image_name = '{0}/{1}.nii.gz'.format(data_dir, seq)
             if not os.path.exists(image_name):
-                log('  Directory {0} does not contain an image with file name {1}. Skip.'.format(
-                    data_dir, os.path.basename(image_name)))
-                continue
-            log('  Reading {} ...'.format(image_name))
-            nim = nifti.load(image_name)
-            _sequence_subject(FLAGS, (data, data_dir, image_name), nim, forward, engine, log, processed, table_time, csv_rows)
+                if not second:
+                    log('  Directory {0} does not contain an image with file name {1}. Skip.'.format(
+                        data_dir, os.path.basename(image_name)))
+                return
+            if not queue.take(data):
+                return                               # claimed by another worker (--work_stealing)
+            try:
+                if second:
+                    log(data)
+                log('  Reading {} ...'.format(image_name))
+                nim = nifti.load(image_name)
+                _sequence_subject(FLAGS, (data, data_dir, image_name), nim, forward, engine, log, processed, table_time, csv_rows)
+            finally:
+                queue.done(data)
         else:
             names = {fr: '{0}/{1}_{2}.nii.gz'.format(data_dir, seq, fr) for fr in ('ED', 'ES')}
             if not all(os.path.exists(p) for p in names.values()):
                 log('  Directory {0} does not contain an image with file name {1} or {2}. Skip.'.format(
                     data_dir, os.path.basename(names['ED']), os.path.basename(names['ES'])))
-                continue
+                return
             for fr in ('ED', 'ES'):
                 log('  Reading {} ...'.format(names[fr]))
                 nim = nifti.load(names[fr])
@@ -308,6 +364,10 @@ def run(FLAGS, forward, log=print, engine=None):
                     log('  Saving segmentation ...')
                     nifti.save(pred, '{0}/{1}_{2}_{3}.nii.gz'.format(data_dir, pre, seq, fr), nim.affine,
                                nim.header['pixdim'])
+    for data in data_list:
+        one_subject(data, False)
+    for data in queue.second_chance():                  # finished by its owner meanwhile (skip-if-exists), or orphaned (stale claim)
+        one_subject(data, True)
     if csv_rows is not None:
         write_measures_csv(FLAGS, shard_subjects, csv_rows, log)
     if table_time:
@@ -328,6 +388,7 @@ def main(argv=None):
         sys.exit('FATAL Flags parsing error: %s\n%s' % (e, fs.usage()))
     if 'CUDA_VISIBLE_DEVICES' in os.environ and 'HIP_VISIBLE_DEVICES' not in os.environ:
         os.environ['HIP_VISIBLE_DEVICES'] = os.environ['CUDA_VISIBLE_DEVICES']   # demo_pipeline.py:25,63
+    apply_cpu_set_from_env()                             # shard.launch's per-worker CPU set, before the first GPU call starts threads
     from ukbb_cardiac_amd.engine import Session          # raises if the HIP library is missing
     with Session(FLAGS.model_path, device=FLAGS.device) as sess:
         if FLAGS.precision != 'fp32':

@@ -43,7 +43,7 @@ def define_flags():
     fs.DEFINE_integer('device', default_device(), 'HIP device ordinal (after HIP_VISIBLE_DEVICES); defaults to '
                       'LOCAL_RANK under torch.distributed.run.')
     fs.DEFINE_integer('batch_slices', 64, 'Slices per forward call.')
-    fs.DEFINE_integer('io_threads', 2, 'Sequence mode: threads that read (inflate) the next cines ahead of the GPU and threads that '
+    fs.DEFINE_integer('io_threads', min(2, int(os.environ.get('UKBB_IO_THREADS', 2))), 'Sequence mode: threads that read (inflate) the next cines ahead of the GPU and threads that '
                       'write finished segmentations behind it; 0 = strictly sequential subjects as in the reference.')
     fs.DEFINE_boolean('device_preproc', True, 'Sequences: z-score, padding, transposes and the argmax on the GPU '
                       '(bit-identical to the host path; --nodevice_preproc restores it).')
@@ -247,6 +247,8 @@ def main(argv=None):
         os.environ['HIP_VISIBLE_DEVICES'] = os.environ['CUDA_VISIBLE_DEVICES']
     if FLAGS.model == 'Temporal-UNet':
         sys.exit("Error: --model Temporal-UNet is not available on the HIP engine (see DESIGN.md section 7).")
+    from ukbb_cardiac_amd.shard import apply_cpu_set_from_env
+    apply_cpu_set_from_env()                             # shard.launch's per-worker CPU set, before the first GPU call starts threads
     from ukbb_cardiac_amd.arch import KIND_UNET_LSTM
     from ukbb_cardiac_amd.engine import Session
     nifti.set_label_gzip(FLAGS.label_gzip)

@@ -148,6 +148,9 @@ def merge_shard_csv(path, num_shards, remove=True):
     if header is None:
         return False
     rows.sort(key=lambda r: r[0])
+    # one row per subject: with work stealing the worker that segmented a subject and the static owner of its index may both
+    # have measured it (same counts, same text); the first one stays
+    rows = [r for i, r in enumerate(rows) if i == 0 or r[0] != rows[i - 1][0]]
     tmp = '%s.tmp.%d' % (path, os.getpid())
     with open(tmp, 'w', newline='') as f:
         wr = csv.writer(f, lineterminator='\n')

@@ -69,18 +69,24 @@ class _GzWriter:
 
 
 def _host_tag():
-    """Short tag of this host *instance* (hostname + boot id): a pid only means something inside the namespace that issued it."""
+    """Short tag of this host *instance* (hostname + boot id + pid namespace): a pid only means something inside the namespace
+    that issued it.  Two containers of one node share the boot id -- and, with host networking / a shared UTS namespace, the
+    hostname -- but not the pid namespace, so its identity (the inode in ``/proc/self/ns/pid``) is part of the tag."""
     global _HOST_TAG
     if _HOST_TAG is None:
         import hashlib
         import socket
-        boot = ''
+        boot, pidns = '', ''
         try:
             with open('/proc/sys/kernel/random/boot_id') as f:
                 boot = f.read().strip()
         except OSError:
             pass
-        _HOST_TAG = 'h' + hashlib.sha1((socket.gethostname() + '|' + boot).encode()).hexdigest()[:10]
+        try:
+            pidns = os.readlink('/proc/self/ns/pid')        # 'pid:[4026531836]'
+        except OSError:
+            pass
+        _HOST_TAG = 'h' + hashlib.sha1((socket.gethostname() + '|' + boot + '|' + pidns).encode()).hexdigest()[:10]
     return _HOST_TAG
 
 

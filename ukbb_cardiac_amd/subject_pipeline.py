@@ -40,9 +40,11 @@ class Staged:
 class SubjectPipeline:
     HEADROOM = 4096                                         # bytes of writable pinned memory in front of every staged array
 
-    def __init__(self, engine, max_shape, batch_slices=128, depth=3, thres=(1, 99), extra_inputs=2):
+    def __init__(self, engine, max_shape, batch_slices=128, depth=3, thres=(1, 99), extra_inputs=2, pinned_inputs=True):
         """max_shape: largest (X, Y, Z, T) expected (buffers are sized for it; larger volumes re-allocate).
-        extra_inputs: pinned input buffers beyond ``depth`` (one per reader thread that may hold one)."""
+        extra_inputs: pinned input buffers beyond ``depth`` (one per reader thread that may hold one).
+        pinned_inputs=False: no pinned input pool at all -- for cohorts whose volumes are produced on the device
+        (``submit_generated``; ``stage`` / ``submit`` of host arrays then block forever and must not be used)."""
         import torch
         self.torch = torch
         self.engine = engine
@@ -58,7 +60,7 @@ class SubjectPipeline:
         self._inflight = []                                   # slots in submission order
         self._in_cap = int(np.prod(max_shape))
         self._in_free = queue.Queue()
-        for _ in range(self.depth + int(extra_inputs)):
+        for _ in range(self.depth + int(extra_inputs) if pinned_inputs else 0):
             # HEADROOM bytes in front of every buffer: nifti.load's whole-file decoder writes the 352-byte NIfTI header there and the
             # voxels straight behind it, i.e. into the array stage() hands out (the view keeps the whole allocation alive)
             self._in_free.put(torch.empty(self._in_cap + self.HEADROOM // 4, dtype=torch.float32, pin_memory=True)[self.HEADROOM // 4:])
@@ -138,20 +140,35 @@ class SubjectPipeline:
                 with self._lock:
                     self._staged.pop(id(st.array), None)
                 st.array[...] = image
-        image = st.array
-        X, Y, Z, T = image.shape
-        slot = self._acquire(image.shape)
+        self._enqueue(st.array.shape, st, None)
+
+    def submit_generated(self, shape, fill):
+        """Enqueue one (X,Y,Z,T) float32 volume that is PRODUCED ON THE DEVICE: ``fill(d_ptr, n, stream)`` enqueues, on the copy-in
+        stream it is given, whatever writes the n voxels (x fastest, like the file) to device address d_ptr -- it takes the place
+        of the H2D copy; everything behind it (percentiles, pack, forward, unpack, labels to pinned host memory) is the same code.
+        The Result of such a subject has no ``image``."""
+        if len(shape) != 4:
+            raise ValueError('expected an (X,Y,Z,T) shape, got %s' % (shape,))
+        self._enqueue(tuple(int(v) for v in shape), None, fill)
+
+    def _enqueue(self, shape, st, fill):
+        torch = self.torch
+        X, Y, Z, T = shape
+        slot = self._acquire(shape)
         n = X * Y * Z * T
-        pin_in = st.buf
         slot.busy = True
-        slot.shape = image.shape
+        slot.shape = shape
         slot.staged = st
         self._next = (self._next + 1) % self.depth
         n_class = self.engine.arch.n_class
         X2, Y2, x_pre, _, y_pre, _ = pad_amounts(X, Y)
         nsl = T * Z
         with torch.cuda.stream(self.s_in):
-            slot.d_vol[:n].copy_(pin_in[:n], non_blocking=True)
+            if st is not None:
+                slot.d_vol[:n].copy_(st.buf[:n], non_blocking=True)
+            else:
+                # the slot's previous subject was collected (its pack kernel, the last reader of d_vol, has finished long ago)
+                fill(slot.d_vol.data_ptr(), n, self.s_in.cuda_stream)
             # exact np.percentile(volume, (1, 99)): two neighbouring order statistics per percentile from the device
             # (4-pass radix select; synchronises the copy-in stream only), numpy's own interpolation on the host
             ranks, gammas = [], []
@@ -191,15 +208,19 @@ class SubjectPipeline:
     def pending(self):
         return len(self._inflight)
 
-    def collect(self):
+    def collect(self, copy=True):
         """Oldest submitted subject -> Result (labels uint8 (X,Y,Z,T), counts int64 [T, n_class], clip (lo, hi), image =
-        the staged input volume).  Call ``Result.done()`` when the image is no longer needed."""
+        the staged input volume).  Call ``Result.done()`` when the image is no longer needed.
+        copy=False: ``labels`` is a view of the slot's pinned buffer, valid only until ``depth`` more subjects have been submitted
+        (for callers that consume or drop it at once)."""
         slot = self._inflight.pop(0)
         slot.ev_out.synchronize()
         X, Y, Z, T = slot.shape
         n = X * Y * Z * T
         n_class = self.engine.arch.n_class
-        lab = slot.pin_lab.numpy()[:n].reshape(slot.shape, order='F').copy(order='F')
+        lab = slot.pin_lab.numpy()[:n].reshape(slot.shape, order='F')
+        if copy:
+            lab = lab.copy(order='F')
         cnt = slot.pin_cnt.numpy()[:T * n_class].reshape(T, n_class).copy()
         st, slot.staged = slot.staged, None
         slot.busy = False
@@ -231,8 +252,9 @@ class Result:
 
     @property
     def image(self):
-        """The input volume as staged (NOT clipped; the reference's saved frames are, see device_pipeline.clip_like_reference)."""
-        return self._staged.array
+        """The input volume as staged (NOT clipped; the reference's saved frames are, see device_pipeline.clip_like_reference);
+        None for a subject generated on the device."""
+        return None if self._staged is None else self._staged.array
 
     def done(self):
         if self._staged is not None:

@@ -401,6 +401,14 @@ def infer_arch(reader: CheckpointReader) -> ModelArch:
             n_block.append(k)
             l += 1
         lstm = any(_LSTM_VAR.match(n) for n in names)
+        # the single-direction head Conv_LSTM (network_ao.py:214-252; train_network_ao.py --bidirectional=False) keeps its cell directly
+        # under LSTM/ -- LSTM/<cell>/{kernel,biases} + LSTM/conv2d -- with no forward / backward / output scopes: refuse it by name
+        # instead of failing later on a "missing" LSTM/forward variable
+        uni = sorted(n for n in names if n.startswith('LSTM/') and not n.startswith(('LSTM/forward/', 'LSTM/backward/', 'LSTM/output/')))
+        if uni and not lstm:
+            raise CheckpointError('this is a UNet-LSTM checkpoint with the UNIDIRECTIONAL ConvLSTM head (common/network_ao.py:214-252 Conv_LSTM, '
+                                  'trained with --bidirectional=False; variables %s ...): only the bidirectional BiConv_LSTM head of the released '
+                                  'model (network_ao.py:255-319, LSTM/forward + LSTM/backward + LSTM/output) is built' % ', '.join(uni[:3]))
         if not n_filter or (not lstm and 'UNet/conv_out/conv2d/kernel' not in names):
             raise CheckpointError('UNet checkpoint without the expected UNet/conv{l}/conv2d variables')
         if lstm:
