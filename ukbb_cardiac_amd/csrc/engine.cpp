@@ -143,7 +143,9 @@ struct ukbb_fcn_handle {
 
     // image-slice streams (experiment UKBB_SPLIT, run_plan): consecutive conv ops run as S independent image ranges on S streams
     // side stream for kernels that only feed the head (sqg_l): fork after level l, join before the head
-    hipStream_t side = nullptr;
+    hipStream_t side = nullptr, side2 = nullptr;
+    hipEvent_t ev_split_fork = nullptr, ev_split_join = nullptr;
+    int split_first = -1, split_last = -2;      // op range run as two half-batch chains (UKBB_SPLIT_FROM at plan build)
     std::vector<hipEvent_t> ev_fork, ev_join;
     bool use_side = false;
 
@@ -157,6 +159,9 @@ struct ukbb_fcn_handle {
 
     ~ukbb_fcn_handle() {
         for (auto e : ev) (void)hipEventDestroy(e);
+        if (ev_split_fork) (void)hipEventDestroy(ev_split_fork);
+        if (ev_split_join) (void)hipEventDestroy(ev_split_join);
+        if (side2) (void)hipStreamDestroy(side2);
         for (auto e : ev_fork) (void)hipEventDestroy(e);
         for (auto e : ev_join) (void)hipEventDestroy(e);
         if (side) (void)hipStreamDestroy(side);
@@ -897,6 +902,21 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
     }
     h->plan_h = H; h->plan_w = W; h->plan_small = n_hint <= SMALL_BATCH; h->plan_n = n_hint;
     h->plan_bfio = bf16_mode(h) == 2;
+    // experiment (r06, config 5): UKBB_SPLIT_FROM=k runs the U-Net's levels >= k (conv{k}_0 .. up{k}_1) as two half-batch chains (run_plan)
+    h->split_first = -1; h->split_last = -2;
+    if (const char *e = getenv("UKBB_SPLIT_FROM")) {
+        const int k = atoi(e);
+        if (k >= 1 && k < a.n_level) {
+            // U-Net: conv{k}_0 .. up{k}_1; FCN (no decoder): conv{k}_0 .. the last encoder conv (the squeeze launches and the head follow unsplit)
+            const std::string c0 = "conv" + std::to_string(k) + "_0";
+            const std::string u0 = a.kind == UKBB_KIND_FCN ? "conv" + std::to_string(a.n_level - 1) + "_" : "up" + std::to_string(k) + "_";
+            for (size_t i = 0; i < h->ops.size(); ++i) {
+                if (h->split_first < 0 && h->ops[i].name.compare(0, c0.size(), c0) == 0) h->split_first = (int)i;
+                if (h->ops[i].name.compare(0, u0.size(), u0) == 0 && h->ops[i].kind != OP_TAIL) h->split_last = (int)i;
+            }
+            if (h->split_first < 0 || h->split_last < h->split_first) { h->split_first = -1; h->split_last = -2; }
+        }
+    }
     // events
     for (auto e : h->ev) (void)hipEventDestroy(e);
     h->ev.clear();
@@ -972,9 +992,166 @@ int run_plan(ukbb_fcn_handle *h, const float *image, int n, float *logits, float
     }
     hipStream_t s_main = s;
     bool forked = false;
+    // One launch of op i over images [n0, n0 + n) of the batch on stream s (the whole batch everywhere except inside a split range, below).
+    const size_t act_esz = h->plan_bfio ? 2 : 4;             // bytes per stored activation element
+    auto launch_one = [&](size_t i, int n0, int n, hipStream_t s, hipError_t &e) -> int {
+        const Op &op = h->ops[i];
+        auto actp = [&](int id) -> float * {
+            return reinterpret_cast<float *>(reinterpret_cast<char *>(h->act[id]->p) + (size_t)n0 * h->act_per_image[id] * act_esz);
+        };
+        e = hipSuccess;
+        switch (op.kind) {
+            case OP_FIRST: {
+                const HostLayer &L = h->layers[op.layer];
+                FirstArgs fa{image, dev_ptr(h, L.name + "/w"), dev_ptr(h, L.name + "/bias"), actp(op.out),
+                             n, op.H, op.W, L.cout, h->plan_bfio ? 1 : 0};
+                e = launch_first(fa, s);
+                break;
+            }
+            case OP_CONV: {
+                const HostLayer &L = h->layers[op.layer];
+                ConvConfig c;
+                find_cfg(op.cfg, c);
+                ConvArgs ca{};
+                ca.in0 = op.fused_first ? image : actp(op.in0);
+                if (op.fused_first) { ca.first_w = dev_ptr(h, "conv0_0/w"); ca.first_b = dev_ptr(h, "conv0_0/bias"); }
+                ca.in1 = op.in1 >= 0 ? actp(op.in1) : nullptr;
+                ca.C1 = op.in1 >= 0 ? (int)(h->act_per_image[op.in1] / ((size_t)op.H * op.W)) : 0;
+                ca.C0 = L.cin - ca.C1;
+                ca.wpk = op.wpk; ca.bias = op.bias; ca.out = actp(op.out);
+                ca.N = n; ca.H = op.H; ca.W = op.W; ca.Ho = op.Ho; ca.Wo = op.Wo; ca.Cout = L.cout;
+                if (c.pc == 5 || c.pc == 6) { ca.Cout = round_up(L.cout, 32); ca.cout_store = L.cout; }
+                if (op.fused_logits) {
+                    ca.lg_w = dev_ptr(h, "logits/w"); ca.lg_b = dev_ptr(h, "logits/bias");
+                    ca.lg_logits = logits; ca.lg_prob = prob; ca.lg_pred = pred; ca.lg_ncls = a.n_class;
+                }
+                ca.pad_y = op.pad_y; ca.pad_x = op.pad_x;
+                ca.tiles_y = (op.Ho + c.th - 1) / c.th; ca.tiles_x = (op.Wo + c.tw - 1) / c.tw;
+                ca.relu = L.relu ? 1 : 0;
+                e = launch_conv(op.cfg, ca, s);
+                break;
+            }
+            case OP_SQG: {
+                const HostLayer &L = h->layers[op.layer];
+                const std::string ls = std::to_string(op.stride);
+                SqgArgs sa{};
+                sa.x = actp(op.in0);
+                sa.w_s = dev_ptr(h, "sqg" + ls + "/w_s"); sa.b_s = dev_ptr(h, L.name + "/bias");
+                sa.w_g = dev_ptr(h, "sqg" + ls + "/w_g");
+                sa.out = actp(op.out);
+                sa.npix = (long long)n * op.H * op.W; sa.cin = L.cin;
+                e = launch_sqg(sa, s);
+                break;
+            }
+            case OP_SQG_MULTI: {
+                SqgArgs sa[4];
+                for (int j = 0; j < 4; ++j) {
+                    sa[j] = SqgArgs{};
+                    sa[j].cin = 32 << j;
+                    if (op.mlayer[j] < 0) continue;              // level handled by a launch of its own: npix = 0 -> no blocks
+                    const HostLayer &L = h->layers[op.mlayer[j]];
+                    const std::string ls = std::to_string(j + 1);
+                    sa[j].x = actp(op.min_[j]);
+                    sa[j].w_s = dev_ptr(h, "sqg" + ls + "/w_s"); sa[j].b_s = dev_ptr(h, L.name + "/bias");
+                    sa[j].w_g = dev_ptr(h, "sqg" + ls + "/w_g");
+                    sa[j].out = actp(op.mout[j]);
+                    sa[j].npix = (long long)n * op.mh[j] * op.mw[j]; sa[j].cin = L.cin;
+                }
+                e = launch_sqg_multi(sa, s);
+                break;
+            }
+            case OP_HEAD: {
+                HeadArgs ha{};
+                ha.conv0 = actp(op.in0);
+                for (int l = 0; l < 4; ++l) ha.G[l] = actp(op.sq[l]);
+                ha.w_s0 = dev_ptr(h, "head/w_s0"); ha.b_s0 = dev_ptr(h, "same_dim0/bias");
+                ha.w_o0 = dev_ptr(h, "head/w_o0"); ha.b_o0 = dev_ptr(h, "out0/bias");
+                ha.w_o1 = dev_ptr(h, "head/w_o1"); ha.b_o1 = dev_ptr(h, "out1/bias");
+                ha.w_o1x3 = dev_ptr(h, "head/w_o1x3"); ha.w_o0x3 = dev_ptr(h, "head/w_o0x3");
+                ha.w_lg = dev_ptr(h, "head/w_lg"); ha.b_lg = dev_ptr(h, "logits/bias");
+                ha.logits = logits; ha.prob = prob; ha.pred = pred;
+                ha.N = n; ha.H = op.H; ha.W = op.W; ha.n_class = a.n_class;
+                ha.x3 = h->precision == UKBB_PREC_F32X3;
+                e = launch_head(ha, s);
+                break;
+            }
+            case OP_TCONV: {
+                const HostLayer &L = h->layers[op.layer];
+                ConvConfig c;
+                find_cfg(op.cfg, c);
+                ConvArgs ca{};
+                ca.in0 = actp(op.in0); ca.in1 = nullptr; ca.C0 = L.cin; ca.C1 = 0;
+                ca.wpk = op.wpk; ca.bias = op.bias; ca.out = actp(op.out);
+                ca.N = n; ca.H = op.H; ca.W = op.W; ca.Ho = op.Ho; ca.Wo = op.Wo; ca.Cout = 4 * L.cout;
+                ca.pad_y = 1; ca.pad_x = 1;
+                ca.tiles_y = (op.Ho + c.th - 1) / c.th; ca.tiles_x = (op.Wo + c.tw - 1) / c.tw;
+                ca.relu = 1; ca.up2 = L.cout;
+                e = launch_conv(op.cfg, ca, s);
+                break;
+            }
+            case OP_STEM: {
+                StemArgs sa{};
+                sa.image = image; sa.wA0 = dev_ptr(h, "stem/wA0"); sa.wA1 = dev_ptr(h, "stem/wA1");
+                sa.b0 = dev_ptr(h, "conv0_0/bias"); sa.b1 = dev_ptr(h, "conv0_1/bias");
+                sa.out = actp(op.out); sa.N = n; sa.H = op.H; sa.W = op.W;
+                e = launch_unet_stem(sa, s);
+                break;
+            }
+            case OP_TAIL: {
+                TailArgs ta{};
+                ta.in0 = actp(op.in0); ta.in1 = actp(op.in1);
+                ta.wA0 = dev_ptr(h, "tail/wA0"); ta.wA1 = dev_ptr(h, "tail/wA1");
+                ta.b0 = dev_ptr(h, "up0_0/bias"); ta.b1 = dev_ptr(h, "up0_1/bias");
+                ta.lg_w = dev_ptr(h, "logits/w"); ta.lg_b = dev_ptr(h, "logits/bias");
+                ta.logits = logits; ta.prob = prob; ta.pred = pred;
+                ta.N = n; ta.H = op.H; ta.W = op.W; ta.ncls = a.n_class;
+                e = launch_unet_tail(ta, s);
+                break;
+            }
+            case OP_LOGITS: {
+                const HostLayer &L = h->layers[op.layer];
+                LogitsArgs la{};
+                la.in = actp(op.in0); la.w = dev_ptr(h, "logits/w"); la.bias = dev_ptr(h, "logits/bias");
+                la.logits = logits; la.prob = prob; la.pred = pred;
+                la.npix = (int64_t)n * op.H * op.W; la.C = L.cin; la.n_class = a.n_class;
+                la.in_bf16 = h->plan_bfio ? 1 : 0;
+                e = launch_logits(la, s);
+                break;
+            }
+            default:
+                set_err("op kind %d not implemented", (int)op.kind);
+                return UKBB_EARCH;
+        }
+        return UKBB_OK;
+    };
+    // UKBB_SPLIT_FROM (plan build): the ops of levels >= k -- conv{k}_0 .. up{k}_1, the launches whose fill / drain and serial chains
+    // are the largest part of their time -- run as TWO half-batch chains on two streams, enqueued interleaved, joined before the next op
+    const int sp0 = h->split_first, sp1 = h->split_last;
     for (size_t i = 0; i < h->ops.size(); ++i) {
         const Op &op = h->ops[i];
         s = s_main;
+        if ((int)i == sp0 && sp1 >= sp0 && n >= 2 && !h->timing) {
+            if (!h->side2) {
+                HIP_TRY(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking), UKBB_EDEVICE);
+                HIP_TRY(hipEventCreateWithFlags(&h->ev_split_fork, hipEventDisableTiming), UKBB_EDEVICE);
+                HIP_TRY(hipEventCreateWithFlags(&h->ev_split_join, hipEventDisableTiming), UKBB_EDEVICE);
+            }
+            HIP_TRY(hipEventRecord(h->ev_split_fork, s_main), UKBB_EDEVICE);
+            HIP_TRY(hipStreamWaitEvent(h->side2, h->ev_split_fork, 0), UKBB_EDEVICE);
+            const int nA = (n + 1) / 2;
+            for (int j = sp0; j <= sp1; ++j) {
+                hipError_t e;
+                int rc = launch_one(j, 0, nA, s_main, e);
+                if (rc) return rc;
+                if (e == hipSuccess) rc = launch_one(j, nA, n - nA, h->side2, e);
+                if (rc) return rc;
+                if (e != hipSuccess) { set_err("launch of %s (split) failed: %s", h->ops[j].name.c_str(), hipGetErrorString(e)); return UKBB_EDEVICE; }
+            }
+            HIP_TRY(hipEventRecord(h->ev_split_join, h->side2), UKBB_EDEVICE);
+            HIP_TRY(hipStreamWaitEvent(s_main, h->ev_split_join, 0), UKBB_EDEVICE);
+            i = (size_t)sp1;
+            continue;
+        }
         if (op.on_side) {                              // fork: side stream waits for everything issued so far
             if (!h->side) {
                 HIP_TRY(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking), UKBB_EDEVICE);
@@ -995,127 +1172,9 @@ int run_plan(ukbb_fcn_handle *h, const float *image, int n, float *logits, float
         const bool timed = h->timing && (h->timing_only < 0 || h->timing_only == (int)i);
         if (timed) HIP_TRY(hipEventRecord(h->ev[2 * i], s), UKBB_EDEVICE);
         hipError_t e = hipSuccess;
-        switch (op.kind) {
-            case OP_FIRST: {
-                const HostLayer &L = h->layers[op.layer];
-                FirstArgs fa{image, dev_ptr(h, L.name + "/w"), dev_ptr(h, L.name + "/bias"), h->act[op.out]->p,
-                             n, op.H, op.W, L.cout, h->plan_bfio ? 1 : 0};
-                e = launch_first(fa, s);
-                break;
-            }
-            case OP_CONV: {
-                const HostLayer &L = h->layers[op.layer];
-                ConvConfig c;
-                find_cfg(op.cfg, c);
-                ConvArgs ca{};
-                ca.in0 = op.fused_first ? image : h->act[op.in0]->p;
-                if (op.fused_first) { ca.first_w = dev_ptr(h, "conv0_0/w"); ca.first_b = dev_ptr(h, "conv0_0/bias"); }
-                ca.in1 = op.in1 >= 0 ? h->act[op.in1]->p : nullptr;
-                ca.C1 = op.in1 >= 0 ? (int)(h->act_per_image[op.in1] / ((size_t)op.H * op.W)) : 0;
-                ca.C0 = L.cin - ca.C1;
-                ca.wpk = op.wpk; ca.bias = op.bias; ca.out = h->act[op.out]->p;
-                ca.N = n; ca.H = op.H; ca.W = op.W; ca.Ho = op.Ho; ca.Wo = op.Wo; ca.Cout = L.cout;
-                if (c.pc == 5 || c.pc == 6) { ca.Cout = round_up(L.cout, 32); ca.cout_store = L.cout; }
-                if (op.fused_logits) {
-                    ca.lg_w = dev_ptr(h, "logits/w"); ca.lg_b = dev_ptr(h, "logits/bias");
-                    ca.lg_logits = logits; ca.lg_prob = prob; ca.lg_pred = pred; ca.lg_ncls = a.n_class;
-                }
-                ca.pad_y = op.pad_y; ca.pad_x = op.pad_x;
-                ca.tiles_y = (op.Ho + c.th - 1) / c.th; ca.tiles_x = (op.Wo + c.tw - 1) / c.tw;
-                ca.relu = L.relu ? 1 : 0;
-                e = launch_conv(op.cfg, ca, s);
-                break;
-            }
-            case OP_SQG: {
-                const HostLayer &L = h->layers[op.layer];
-                const std::string ls = std::to_string(op.stride);
-                SqgArgs sa{};
-                sa.x = h->act[op.in0]->p;
-                sa.w_s = dev_ptr(h, "sqg" + ls + "/w_s"); sa.b_s = dev_ptr(h, L.name + "/bias");
-                sa.w_g = dev_ptr(h, "sqg" + ls + "/w_g");
-                sa.out = h->act[op.out]->p;
-                sa.npix = (long long)n * op.H * op.W; sa.cin = L.cin;
-                e = launch_sqg(sa, s);
-                break;
-            }
-            case OP_SQG_MULTI: {
-                SqgArgs sa[4];
-                for (int j = 0; j < 4; ++j) {
-                    sa[j] = SqgArgs{};
-                    sa[j].cin = 32 << j;
-                    if (op.mlayer[j] < 0) continue;              // level handled by a launch of its own: npix = 0 -> no blocks
-                    const HostLayer &L = h->layers[op.mlayer[j]];
-                    const std::string ls = std::to_string(j + 1);
-                    sa[j].x = h->act[op.min_[j]]->p;
-                    sa[j].w_s = dev_ptr(h, "sqg" + ls + "/w_s"); sa[j].b_s = dev_ptr(h, L.name + "/bias");
-                    sa[j].w_g = dev_ptr(h, "sqg" + ls + "/w_g");
-                    sa[j].out = h->act[op.mout[j]]->p;
-                    sa[j].npix = (long long)n * op.mh[j] * op.mw[j]; sa[j].cin = L.cin;
-                }
-                e = launch_sqg_multi(sa, s);
-                break;
-            }
-            case OP_HEAD: {
-                HeadArgs ha{};
-                ha.conv0 = h->act[op.in0]->p;
-                for (int l = 0; l < 4; ++l) ha.G[l] = h->act[op.sq[l]]->p;
-                ha.w_s0 = dev_ptr(h, "head/w_s0"); ha.b_s0 = dev_ptr(h, "same_dim0/bias");
-                ha.w_o0 = dev_ptr(h, "head/w_o0"); ha.b_o0 = dev_ptr(h, "out0/bias");
-                ha.w_o1 = dev_ptr(h, "head/w_o1"); ha.b_o1 = dev_ptr(h, "out1/bias");
-                ha.w_o1x3 = dev_ptr(h, "head/w_o1x3"); ha.w_o0x3 = dev_ptr(h, "head/w_o0x3");
-                ha.w_lg = dev_ptr(h, "head/w_lg"); ha.b_lg = dev_ptr(h, "logits/bias");
-                ha.logits = logits; ha.prob = prob; ha.pred = pred;
-                ha.N = n; ha.H = op.H; ha.W = op.W; ha.n_class = a.n_class;
-                ha.x3 = h->precision == UKBB_PREC_F32X3;
-                e = launch_head(ha, s);
-                break;
-            }
-            case OP_TCONV: {
-                const HostLayer &L = h->layers[op.layer];
-                ConvConfig c;
-                find_cfg(op.cfg, c);
-                ConvArgs ca{};
-                ca.in0 = h->act[op.in0]->p; ca.in1 = nullptr; ca.C0 = L.cin; ca.C1 = 0;
-                ca.wpk = op.wpk; ca.bias = op.bias; ca.out = h->act[op.out]->p;
-                ca.N = n; ca.H = op.H; ca.W = op.W; ca.Ho = op.Ho; ca.Wo = op.Wo; ca.Cout = 4 * L.cout;
-                ca.pad_y = 1; ca.pad_x = 1;
-                ca.tiles_y = (op.Ho + c.th - 1) / c.th; ca.tiles_x = (op.Wo + c.tw - 1) / c.tw;
-                ca.relu = 1; ca.up2 = L.cout;
-                e = launch_conv(op.cfg, ca, s);
-                break;
-            }
-            case OP_STEM: {
-                StemArgs sa{};
-                sa.image = image; sa.wA0 = dev_ptr(h, "stem/wA0"); sa.wA1 = dev_ptr(h, "stem/wA1");
-                sa.b0 = dev_ptr(h, "conv0_0/bias"); sa.b1 = dev_ptr(h, "conv0_1/bias");
-                sa.out = h->act[op.out]->p; sa.N = n; sa.H = op.H; sa.W = op.W;
-                e = launch_unet_stem(sa, s);
-                break;
-            }
-            case OP_TAIL: {
-                TailArgs ta{};
-                ta.in0 = h->act[op.in0]->p; ta.in1 = h->act[op.in1]->p;
-                ta.wA0 = dev_ptr(h, "tail/wA0"); ta.wA1 = dev_ptr(h, "tail/wA1");
-                ta.b0 = dev_ptr(h, "up0_0/bias"); ta.b1 = dev_ptr(h, "up0_1/bias");
-                ta.lg_w = dev_ptr(h, "logits/w"); ta.lg_b = dev_ptr(h, "logits/bias");
-                ta.logits = logits; ta.prob = prob; ta.pred = pred;
-                ta.N = n; ta.H = op.H; ta.W = op.W; ta.ncls = a.n_class;
-                e = launch_unet_tail(ta, s);
-                break;
-            }
-            case OP_LOGITS: {
-                const HostLayer &L = h->layers[op.layer];
-                LogitsArgs la{};
-                la.in = h->act[op.in0]->p; la.w = dev_ptr(h, "logits/w"); la.bias = dev_ptr(h, "logits/bias");
-                la.logits = logits; la.prob = prob; la.pred = pred;
-                la.npix = (int64_t)n * op.H * op.W; la.C = L.cin; la.n_class = a.n_class;
-                la.in_bf16 = h->plan_bfio ? 1 : 0;
-                e = launch_logits(la, s);
-                break;
-            }
-            default:
-                set_err("op kind %d not implemented", (int)op.kind);
-                return UKBB_EARCH;
+        {
+            const int rc = launch_one(i, 0, n, s, e);
+            if (rc) return rc;
         }
         if (e != hipSuccess) { set_err("launch of %s failed: %s", op.name.c_str(), hipGetErrorString(e)); return UKBB_EDEVICE; }
         if (timed) HIP_TRY(hipEventRecord(h->ev[2 * i + 1], s), UKBB_EDEVICE);

@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256, conv_min_waves(KS, STRIDE, MB, TH, TW, KC, WM,
 // pixel directly from the 1-channel image (9 taps x KC channels on the vector ALU, same fma
 // order as conv_first_kernel) and write the KC-channel tile to LDS, so that layer's output
 // never exists in HBM.  Halo pixels outside the image are this conv's zero padding.
-template <int KS, int STRIDE, int MB, int TH, int TW, int KC, int WM, int WN, int CB, bool FIRST = false>
+template <int KS, int STRIDE, int MB, int TH, int TW, int KC, int WM, int WN, int CB, bool FIRST = false, bool DI = false>
 __global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
     using M = Mfma<MB>;
     using Acc = typename M::Acc;
@@ -552,6 +552,16 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
     constexpr int BUF = HP * XS + NCBL * SLAB;
     constexpr int RH = IH + 2, RW = IW + 2, RP = RH * RW, NRAW = (RP + 255) / 256;   // FIRST: raw image tile
     static_assert(WM * WN == 4, "4 consumer waves");
+    // r06: stride-2 halo rows are staged DE-INTERLEAVED -- even halo columns first (TW + 1 of them), then the odd ones -- so that the
+    // consumers' B fragment of tap (kh, kw), whose 32 lanes are consecutive OUTPUT pixels, reads consecutive LDS slots (80 bytes
+    // apart: the eight lanes of a ds_read_b128 group cover all 32 banks) instead of every second one (160 bytes apart: four bank
+    // quads, a 2-way conflict on every fragment read; profiles/r02_notes.md section 2).  UKBB_CONV_S2_INTERLEAVED=1 (environment, read per launch) keeps the old layout (A/B).
+    // Measured at N = 64 (r06, tools/ab_libs.sh, three alternating rounds on one box): conv2_0 66.7 -> 65.0 us, conv3_0 62.8 -> 61.1, conv4_0
+    // 59.3 -> 58.0, but conv1_0 (ONE 16-channel chunk per item: the producers' LDS writes, which now alternate between the two halves
+    // of a row, are its critical path, not the consumers' reads) 69.3 -> 71.0: the launcher picks DI for layers of more than one chunk.
+    constexpr bool DEINT = DI && STRIDE == 2 && KS == 3 && !FIRST;
+    constexpr int NEVEN = (IW + 1) / 2;                  // even halo columns 0, 2, .., IW - 1 (IW = 2 TW + 1)
+    auto slot_x = [](int px) { return DEINT ? ((px & 1) ? NEVEN + (px >> 1) : (px >> 1)) : px; };   // column of the staged row a halo column goes to
 
     extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 x BUF
 
@@ -826,11 +836,19 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
             };
             float *const xs_w = lds + pix0 * XS + 4 * c4;
             float *const ws_w = lds + HP * XS + 4 * tid;
+            int xs_de[DEINT ? NIT : 1];                 // de-interleaved rows: the staged slot of each of this thread's halo pixels
+            if constexpr (DEINT) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) xs_de[it] = (hy[it] * IW + slot_x(hx[it])) * XS + 4 * c4;
+            }
             auto store = [&](auto setc, int b) {        // register set SET -> LDS buffer b
                 constexpr int SET = decltype(setc)::value;
 #pragma unroll
                 for (int it = 0; it < NIT; ++it)
-                    if (pix0 + it * PSTEP < HP) *reinterpret_cast<u32x4 *>(xs_w + b * BUF + it * PSTEP * XS) = xq[SET][it];
+                    if (pix0 + it * PSTEP < HP) {
+                        if constexpr (DEINT) *reinterpret_cast<u32x4 *>(lds + b * BUF + xs_de[it]) = xq[SET][it];
+                        else *reinterpret_cast<u32x4 *>(xs_w + b * BUF + it * PSTEP * XS) = xq[SET][it];
+                    }
                 if (wfresh[SET]) {
 #pragma unroll
                     for (int it = 0; it < NWT; ++it)
@@ -877,7 +895,7 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
                     if (f < MAIN_F4) { const int pp = f / C4; cq = f - pp * C4; py = pp / (IW - 1); px = pp - py * (IW - 1); ok = true; }
                     else if (f >= MAIN_PAD && f - MAIN_PAD < LAST_F4) { const int q = f - MAIN_PAD; py = q / C4; cq = q - py * C4; px = IW - 1; ok = true; }
                     gofs[it] = ok ? (unsigned)((py * a.W + px) * a.C0 + 4 * cq) * 4u : 0x80000000u;
-                    lptr[it] = reinterpret_cast<char *>(lds) + (ok ? ((py * IW + px) * XS + 4 * cq) * 4 : KC * 4);   // idle lanes: the pad of halo pixel 0
+                    lptr[it] = reinterpret_cast<char *>(lds) + (ok ? ((py * IW + slot_x(px)) * XS + 4 * cq) * 4 : KC * 4);   // idle lanes: the pad of halo pixel 0
                     lastseg[it] = it * 256 + wave_f0 >= MAIN_PAD;                                         // wave-uniform
                 }
                 u32x4 yq[2][NIT2];
@@ -1002,7 +1020,7 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
             int q = (wn + pb * WN) * PB + pl;
             ooff[pb] = q < NPIX ? (unsigned)(((q / TW) * a.Wo + (q % TW)) * a.Cout + 4 * g) * 4u : 0x80000000u;   // out of range: dropped
             if (q >= NPIX) q = 0;
-            lbase[pb] = (((q / TW) * STRIDE) * IW + (q % TW) * STRIDE) * XS + KSTEPS * g;
+            lbase[pb] = (((q / TW) * STRIDE) * IW + (q % TW) * (DEINT ? 1 : STRIDE)) * XS + KSTEPS * g;
         }
         int s = 0;
         if constexpr (FIRST) __syncthreads();          // matches the producers' raw-tile barrier
@@ -1054,7 +1072,7 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(const ConvArgs a) {
                     _Pragma("unroll") for (int cb = 0; cb < CB; ++cb)                              \
                         VecLoad<KSTEPS>::ld(wbase + (cb * KS2 + (T)) * 64 * KSTEPS, av[SET][cb]);  \
                     _Pragma("unroll") for (int pb = 0; pb < PBW; ++pb)                             \
-                        VecLoad<KSTEPS>::ld(xs + lbase[pb] + (kh_ * IW + kw_) * XS, bv[SET][pb]);  \
+                        VecLoad<KSTEPS>::ld(xs + lbase[pb] + (kh_ * IW + (DEINT ? ((kw_ & 1) ? NEVEN : kw_ / 2) : kw_)) * XS, bv[SET][pb]);  \
                 }
 #ifdef UKBB_DIAG
                 if (a.diag & 2) {                       // ablation: no LDS reads / MFMAs, barriers only
@@ -1368,6 +1386,7 @@ hipError_t launch_conv(int cfg_id, const ConvArgs &a_in, hipStream_t s) {
     for (int i = 0; i < num_ws_configs(); ++i)
         if (ws_config(i).id == cfg_id) return launch_conv_ws(cfg_id, a_in, s);
     ConvArgs a = a_in;
+    const bool s2_interleaved = getenv("UKBB_CONV_S2_INTERLEAVED") != nullptr;     // A/B knob of the stride-2 halo layout (conv_pc_kernel DI)
 #ifdef UKBB_DIAG
     { const char *e = getenv("UKBB_CONV_DIAG"); a.diag = e ? atoi(e) : 0; }
     static unsigned long long *d_stamps = nullptr;
@@ -1443,6 +1462,7 @@ hipError_t launch_conv(int cfg_id, const ConvArgs &a_in, hipStream_t s) {
 #define UKBB_PC_CASE(ID, KS, S, MB, TH, TW, KC, WM, WN, CB)                                     \
     case ID: {                                                                                  \
         auto k = conv_pc_kernel<KS, S, MB, TH, TW, KC, WM, WN, CB>;                             \
+        if (S == 2 && KS == 3 && a.C0 + a.C1 > KC && !s2_interleaved) k = conv_pc_kernel<KS, S, MB, TH, TW, KC, WM, WN, CB, false, true>;   \
         static OncePerDevice lds_ok;                                                            \
         {                                                                                       \
             hipError_t e = allow_dynamic_lds(lds_ok, reinterpret_cast<const void *>(k), c->lds_bytes); \
