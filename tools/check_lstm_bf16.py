@@ -38,7 +38,7 @@ if __name__ == '__main__':
     import tempfile
     d = tempfile.mkdtemp()
     outs = {}
-    for tag, env in (('direct', {}), ('winograd', {'UKBB_LSTM_BF16_WINOGRAD': '1'})):
+    for tag, env in (('direct', {}), ('winograd', {'UKBB_LSTM_BF16_WINOGRAD': '1'}), ('unhoisted', {'UKBB_LSTM_BF16_UNHOIST': '1'})):
         e = dict(os.environ, **env)
         subprocess.check_call([sys.executable, os.path.abspath(__file__), os.path.join(d, tag + '.npz')], env=e)
         outs[tag] = np.load(os.path.join(d, tag + '.npz'))
@@ -50,9 +50,14 @@ if __name__ == '__main__':
         ok = np.isfinite(a) | ~np.isfinite(b)
         dmax = float(np.nanmax(np.abs(a - b)))
         agree = float((np.argmax(np.nan_to_num(a), -1) == np.argmax(np.nan_to_num(b), -1)).mean())
-        fine = same and ok.all() and dmax < 0.25 and agree > 0.99
+        # r06 experiment (UKBB_LSTM_BF16_UNHOIST=1): steps that re-multiply x (fp32 gates) against the default, which adds a gx rounded to bf16
+        c = outs['unhoisted'][k]
+        same_h = bool(outs['unhoisted'][k + '_same'][0])
+        dmax_h = float(np.nanmax(np.abs(a - c)))
+        agree_h = float((np.argmax(np.nan_to_num(a), -1) == np.argmax(np.nan_to_num(c), -1)).mean())
+        fine = same and same_h and ok.all() and dmax < 0.25 and agree > 0.99 and dmax_h < 0.25 and agree_h > 0.99
         bad += not fine
-        print('%3d frames %3dx%3d time_step %d: two runs identical %s; vs Winograd form: max |dprob| %.4f, labels equal %.4f  %s' % (
-            F, H, W, ts, same, dmax, agree, 'ok' if fine else 'FAIL'))
+        print('%3d frames %3dx%3d time_step %d: two runs identical %s; vs Winograd form: max |dprob| %.4f, labels equal %.4f; vs the un-hoisted form (UKBB_LSTM_BF16_UNHOIST=1): max |dprob| %.4f, '
+              'labels equal %.4f  %s' % (F, H, W, ts, same and same_h, dmax, agree, dmax_h, agree_h, 'ok' if fine else 'FAIL'))
     print('FAIL' if bad else 'OK')
     sys.exit(1 if bad else 0)

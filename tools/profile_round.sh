@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs --inflight-probe > "$OUT/bench_inflight.json" 2> "$OUT/bench.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-f32x3-probe --no-other-configs > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.log"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-f32x3-probe --no-other-configs > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.log"
 find "$OUT/trace" -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} "$OUT/kernel_stats.csv"
 find "$OUT/trace" -name '*kernel_trace.csv' -size +20M -delete
 cd "$ROOT" && bash tools/run_pmc.sh "gpurun_out/$TAG/pmc"

@@ -10,7 +10,7 @@ mkdir -p "$OUT/pmc"
 cd /tmp && export TMPDIR=/tmp
 python3 "$ROOT/tools/bench_unet.py" 100 > "$OUT/unet.txt" 2> "$OUT/unet.err"
 python3 "$ROOT/tools/unet_kernels.py" 100 bf16 > "$OUT/kernels_bf16.txt" 2>> "$OUT/unet.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/tools/bench_unet.py" 100 bf16 20 > "$OUT/under_rocprof.txt" 2> "$OUT/trace.log"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/tools/bench_unet.py" 100 bf16 20 > "$OUT/under_rocprof.txt" 2> "$OUT/trace.log"
 find "$OUT/trace" -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} "$OUT/kernel_stats.csv"
 find "$OUT/trace" -name '*kernel_trace.csv' -size +20M -delete
 i=0
@@ -20,7 +20,7 @@ for set in \
   "FETCH_SIZE GRBM_GUI_ACTIVE" \
   "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" ; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d "$OUT/pmc/pass$i" -- python3 "$ROOT/tools/bench_unet.py" 100 bf16 3 > "$OUT/pmc/pass$i.log" 2>&1
+  timeout 600 rocprofv3 --pmc $set --output-format csv -d "$OUT/pmc/pass$i" -- python3 "$ROOT/tools/bench_unet.py" 100 bf16 3 > "$OUT/pmc/pass$i.log" 2>&1
 done
 python3 "$ROOT/tools/pmc_summary.py" "$OUT/pmc" > "$OUT/pmc/summary.csv"
 find "$OUT/pmc" -name '*counter_collection.csv' -size +20M -delete

@@ -15,7 +15,7 @@ for set in \
   "FETCH_SIZE GRBM_GUI_ACTIVE" \
   "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" ; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d "$ROOT/$OUT/pass$i" -- python3 "$ROOT/bench.py" $ARGS > "$ROOT/$OUT/pass$i.log" 2>&1
+  timeout 600 rocprofv3 --pmc $set --output-format csv -d "$ROOT/$OUT/pass$i" -- python3 "$ROOT/bench.py" $ARGS > "$ROOT/$OUT/pass$i.log" 2>&1
 done
 python3 "$ROOT/tools/pmc_summary.py" "$ROOT/$OUT" > "$ROOT/$OUT/summary.csv"
 find "$ROOT/$OUT" -name '*counter_collection.csv' -size +20M -delete

@@ -135,6 +135,7 @@ struct ukbb_fcn_handle {
 
     // UNet-LSTM (kind 2)
     int feat_buf = -1;                        // activation index of net['conv0_up']
+    bool lstm_bf_hoist = true;                // bf16 time steps read the hoisted gx (r05; default) -- false (UKBB_LSTM_BF16_UNHOIST at plan build): they re-multiply x (r06 experiment)
     bool lstm_bf_wino = false;                // UKBB_LSTM_BF16_WINOGRAD at plan build: fp32 Winograd arithmetic on bf16 storage (A/B form)
     int lstm_tile_cols = 0;                   // region shape of the fused gate-conv / cell kernel (kernels_wino24.hip): 32 | 16
     // lstm_gx / lstm_c1 / lstm_h1: per direction and FRAME (the x pass); lstm_c: per window; lstm_hall: per direction, step and window
@@ -853,6 +854,11 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
             // packed filters: the x rows of both directions as ONE 128-channel conv (groups = directions), the h rows per direction
             // (read per plan build, like UKBB_NO_FUSE_TAIL: the A/B knob can be toggled inside one process by re-planning)
             h->lstm_bf_wino = getenv("UKBB_LSTM_BF16_WINOGRAD") != nullptr;
+            // r06 experiment, measured and NOT the default: UKBB_LSTM_BF16_UNHOIST=1 makes the bf16 time steps re-multiply x instead of reading the hoisted gx
+            // (320 -> 224 bytes per pixel and step).  100-frame 256x256 cine, three alternating rounds + rocprofv3 (profiles/r06_ab_lstm_unhoist.txt): step
+            // 354.8 -> 372.1 us, x pass 754 -> 636 us, cine 8.17 -> 8.31 ms: the step is not bound by its bytes alone -- the second chunk's staging and MFMAs
+            // cost more issue time than the gx loads they replace.  The hoisted form (r05) stays.
+            h->lstm_bf_hoist = getenv("UKBB_LSTM_BF16_UNHOIST") == nullptr;
             const int cfg = choose_cfg("lstm_fw", 3, 1, a.n_filter[0], a.same_dim, 4 * a.same_dim, H, W, n_hint, false, false);
             ConvConfig c;
             const bool have24 = cfg >= 0 && !find_cfg(cfg, c) && is_wino24(c) && c.wm == 4 && (c.tw == 32 || c.tw == 16);
@@ -891,6 +897,10 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
                     pack_lstm_gate_weights_bf16(L.w.data(), L.cin, a.n_filter[0], nullptr, whb.data(), nullptr);
                     rc = upload(h, std::string(nm2) + "/wh_bf16", whb);
                     if (rc) return rc;
+                    std::vector<float> wxhb(2 * perb);               // r06: both halves as one two-chunk filter (un-hoisted time steps, ls_mode 3)
+                    pack_lstm_gate_weights_bf16_xh(L.w.data(), nullptr, wxhb.data(), nullptr);
+                    rc = upload(h, std::string(nm2) + "/wxh_bf16", wxhb);
+                    if (rc) return rc;
                     ++d;
                 }
                 rc = upload(h, "lstm/wx_bf16", wxb);
@@ -902,10 +912,15 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
     }
     h->plan_h = H; h->plan_w = W; h->plan_small = n_hint <= SMALL_BATCH; h->plan_n = n_hint;
     h->plan_bfio = bf16_mode(h) == 2;
-    // experiment (r06, config 5): UKBB_SPLIT_FROM=k runs the U-Net's levels >= k (conv{k}_0 .. up{k}_1) as two half-batch chains (run_plan)
+    // r06: the U-Net's levels >= k (conv{k}_0 .. up{k}_1) run as two half-batch chains on two streams (run_plan): the launches of the deep
+    // levels are short, and one half's fill / drain / serial chains hide under the other half's body.  Measured at N = 100 x 256x256 with
+    // k = 1 (profiles/r06_split_levels.txt): fp32 4.06 -> 3.90 ms per forward (+4 %), bf16 1.076-1.092 -> 1.068-1.071 (+1-2 %), labels
+    // bit-identical; on the FCN (persistent 512-thread kernels that hold a CU's whole LDS) it is 0.5-1 % SLOWER, as r03 found for image
+    // ranges: U-Net plans take k = 1 by default, FCN plans none.  UKBB_SPLIT_FROM=k overrides (0 = off).
     h->split_first = -1; h->split_last = -2;
-    if (const char *e = getenv("UKBB_SPLIT_FROM")) {
-        const int k = atoi(e);
+    {
+        const char *e = getenv("UKBB_SPLIT_FROM");
+        const int k = e ? atoi(e) : (a.kind == UKBB_KIND_FCN ? 0 : 1);
         if (k >= 1 && k < a.n_level) {
             // U-Net: conv{k}_0 .. up{k}_1; FCN (no decoder): conv{k}_0 .. the last encoder conv (the squeeze launches and the head follow unsplit)
             const std::string c0 = "conv" + std::to_string(k) + "_0";
@@ -1130,7 +1145,7 @@ int run_plan(ukbb_fcn_handle *h, const float *image, int n, float *logits, float
     for (size_t i = 0; i < h->ops.size(); ++i) {
         const Op &op = h->ops[i];
         s = s_main;
-        if ((int)i == sp0 && sp1 >= sp0 && n >= 2 && !h->timing) {
+        if ((int)i == sp0 && sp1 >= sp0 && n >= 8 && !h->timing) {      // per-kernel timing (set_timing) measures whole-batch launches
             if (!h->side2) {
                 HIP_TRY(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking), UKBB_EDEVICE);
                 HIP_TRY(hipEventCreateWithFlags(&h->ev_split_fork, hipEventDisableTiming), UKBB_EDEVICE);
@@ -1371,13 +1386,16 @@ int run_bilstm(ukbb_fcn_handle *h, const float *feat, int NF, const int *d_map, 
     const size_t HW = (size_t)H * W;
     // bf16 plan: the direct-conv bf16 form (kernels_ws.hip) unless UKBB_LSTM_BF16_WINOGRAD=1 asks for the fp32 Winograd arithmetic on bf16 storage (A/B)
     const bool wsf = h->plan_bfio && !h->lstm_bf_wino;
+    // r06 experiment (UKBB_LSTM_BF16_UNHOIST=1): the direct-conv bf16 steps read the feature frame (32 bytes per pixel) and multiply it again
+    // instead of reading gx (128 bytes per pixel); no gx buffer exists in that form.  Slower by 5 % per step (see build_plan), so not the default.
+    const bool unhoist = wsf && !h->lstm_bf_hoist;
     const size_t gxf = wsf ? lstm_ws_gx_elems(H, W) : wino24_lstm_gx_floats(H, W, tc), cf = wsf ? lstm_ws_c_floats(H, W) : wino24_lstm_c_floats(H, W, tc);
     const bool bf = h->plan_bfio;                        // bf16 plan: features, gx and hidden maps are bf16 in HBM
     const size_t esz = bf ? 2 : 4;
     // Scratch of one cine (include/ukbb_fcn.h, forward_cine): gx 2 NF gxf + h1 2 NF HW NHID + hall 2 T Wn HW NHID elements of esz bytes,
     // cell state (2 NF + Wn) cf floats.  DevBuf counts 4-byte units: the bf16 maps take half as many.
     auto units = [esz](size_t elems) { return (elems * esz + 3) / 4; };
-    HIP_TRY(h->lstm_gx.ensure(units(2 * (size_t)NF * gxf)), UKBB_ENOMEM);
+    if (!unhoist) HIP_TRY(h->lstm_gx.ensure(units(2 * (size_t)NF * gxf)), UKBB_ENOMEM);
     HIP_TRY(h->lstm_c1.ensure(2 * (size_t)NF * cf), UKBB_ENOMEM);
     HIP_TRY(h->lstm_h1.ensure(units(2 * (size_t)NF * HW * NHID)), UKBB_ENOMEM);
     HIP_TRY(h->lstm_c.ensure((size_t)Wn * cf), UKBB_ENOMEM);
@@ -1395,7 +1413,7 @@ int run_bilstm(ukbb_fcn_handle *h, const float *feat, int NF, const int *d_map, 
         ConvArgs ca = base;
         ca.in0 = feat; ca.N = NF; ca.Cout = 2 * 4 * NHID;
         ca.wpk = dev_ptr(h, wsf ? "lstm/wx_bf16" : "lstm/wx"); ca.bias = dev_ptr(h, wsf ? "lstm/bx_bf16" : "lstm/bx");
-        ca.ls_mode = 1; ca.ls_gx = h->lstm_gx.p; ca.ls_c_out = h->lstm_c1.p; ca.out = h->lstm_h1.p;
+        ca.ls_mode = 1; ca.ls_gx = unhoist ? nullptr : h->lstm_gx.p; ca.ls_c_out = h->lstm_c1.p; ca.out = h->lstm_h1.p;
         ca.ls_gx_dir = (long long)NF * gxf; ca.ls_c_dir = (long long)NF * cf; ca.ls_h_dir = (long long)NF * HW * NHID;
         hipError_t e = wsf ? launch_lstm_ws(ca, s) : launch_wino24_lstm(ca, tc, s);
         if (e != hipSuccess) { set_err("ConvLSTM x-pass launch failed: %s", hipGetErrorString(e)); return UKBB_EDEVICE; }
@@ -1409,13 +1427,21 @@ int run_bilstm(ukbb_fcn_handle *h, const float *feat, int NF, const int *d_map, 
             ca.N = Wn; ca.Cout = 4 * NHID;
             ca.wpk = dev_ptr(h, wsf ? (dir ? "lstm_bw/wh_bf16" : "lstm_fw/wh_bf16") : (dir ? "lstm_bw/wh" : "lstm_fw/wh")); ca.bias = nullptr;
             ca.ls_mode = 2;
-            ca.ls_gx = at(h->lstm_gx.p, (size_t)dir * NF * gxf); ca.ls_gx_map = d_map + (size_t)k * Wn;
+            ca.ls_gx = unhoist ? nullptr : at(h->lstm_gx.p, (size_t)dir * NF * gxf); ca.ls_gx_map = d_map + (size_t)k * Wn;
+            const float *hprev; const int *hmap;
             if (step == 1) {                                // previous state = the x pass's per-frame first step
-                ca.in0 = at(h->lstm_h1.p, (size_t)dir * NF * HW * NHID); ca.in0_map = d_map + (size_t)kprev * Wn;
+                hprev = at(h->lstm_h1.p, (size_t)dir * NF * HW * NHID); hmap = d_map + (size_t)kprev * Wn;
                 ca.ls_c_in = h->lstm_c1.p + (size_t)dir * NF * cf;
             } else {
-                ca.in0 = at(hall, (size_t)kprev * kst); ca.in0_map = nullptr;
+                hprev = at(hall, (size_t)kprev * kst); hmap = nullptr;
                 ca.ls_c_in = h->lstm_c.p;
+            }
+            ca.in0 = hprev; ca.in0_map = hmap;
+            if (unhoist) {                                  // ls_mode 3: source 0 = the step's feature frames (through ls_gx_map), source 1 = the previous hidden maps (through in0_map)
+                ca.ls_mode = 3;
+                ca.in0 = feat; ca.in1 = hprev; ca.C1 = NHID;
+                ca.wpk = dev_ptr(h, dir ? "lstm_bw/wxh_bf16" : "lstm_fw/wxh_bf16");
+                ca.bias = dev_ptr(h, "lstm/bx_bf16") + dir * 64;
             }
             ca.ls_c_out = h->lstm_c.p;
             ca.out = at(hall, (size_t)k * kst);

@@ -193,6 +193,9 @@ hipError_t launch_lstm_ws(const ConvArgs &a, hipStream_t s);
 size_t lstm_ws_gx_elems(int H, int W);      // bf16 values of gx per image (frame)
 size_t lstm_ws_c_floats(int H, int W);      // fp32 values of the cell state per image
 size_t pack_lstm_gate_weights_bf16(const float *w, int cin_total, int c_first, const float *bias, float *dst /*9 * 16 * 64 / 2 dwords*/, float *bias_perm);
+// r06, ls_mode 3 (a time step with the x half NOT hoisted: in0 = feature frames through ls_gx_map, in1 = previous hidden maps through in0_map, bias = the
+// permuted gate bias, no gx): the whole [3][3][32][64] gate kernel as one two-chunk filter
+size_t pack_lstm_gate_weights_bf16_xh(const float *w /*[3][3][32][64]*/, const float *bias, float *dst /*9 * 32 * 64 / 2 dwords*/, float *bias_perm);
 
 // ---------------------------------------------------------------------------
 // First layer: conv3x3, C_in = 1 (network.py:186 with l = 0), direct stencil.
@@ -273,6 +276,7 @@ struct TailArgs {
     int32_t *pred;              // optional [N,H,W]
     int N, H, W, ncls;
     unsigned long long *stamps;  // diagnostic builds only (-DUKBB_DIAG, env UKBB_TAIL_STAMPS): per-wave phase cycle sums
+    int seg_tiles;               // strip mode (set by the launcher): tile rows per segment of a column strip; 0 = whole strips
 };
 hipError_t launch_unet_tail(const TailArgs &a, hipStream_t s);
 void pack_tail_weights(const float *w0 /*[3][3][32][16] folded*/, const float *w1 /*[3][3][16][16] folded*/, float *dst0 /*9*64*4*/, float *dst1 /*5*64*4*/);

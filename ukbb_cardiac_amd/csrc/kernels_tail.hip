@@ -71,7 +71,11 @@ __host__ __device__ constexpr int tl_lds_bytes(int r, int nw, int nb) { return n
 
 // NC: classes (compile time: the epilogue is straight-line code for exactly this count); FULL: also store logits / probabilities
 // (the hot path of the deploy loop asks for the label map only)
-template <int R, int NW, int NB, int NC, bool FULL>
+// STRIP (r06): the tiles of a worker run DOWN a column strip (image, tile column) in segments of a.seg_tiles tiles, and the HR0 - R = 4 halo
+// rows two vertically adjacent tiles share stay in LDS: after the first tile of a segment only the R new halo rows are requested from memory
+// (8 of 12: a third of the tail's input bytes, the largest single stream of the bf16 forward), the shared rows are moved from the bottom of the
+// wave's stage to its top by an LDS -> LDS copy before the new rows are parked.  Every fragment address stays an immediate.
+template <int R, int NW, int NB, int NC, bool FULL, bool STRIP = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void unet_tail_kernel(const TailArgs a) {
     constexpr int TL_TW = tl_tw(NB), TL_MW = tl_mw(NB), TL_IW = tl_iw(NB);
     constexpr int R1 = R + 2, HR0 = R + 4, HP0 = tl_hp(R, NB), NLD = tl_nld(R, NB), STAGE = tl_stage(R, NB), MPLANE = tl_mplane(R, NB);
@@ -96,7 +100,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void unet_tail_kernel(const TailAr
     const int chunk = (nwalk % 8 == 0) ? xcd * per_xcd + slot : walker;
     const int worker = chunk * NW + wave, nworkers = nwalk * NW;
 #endif
-    const int my = worker < ntiles ? (ntiles - worker + nworkers - 1) / nworkers : 0;
+    // STRIP: unit u = segment u % segs of strip u / segs; strip = (image, tile column); a segment = seg consecutive tile rows
+    const int seg = STRIP ? (a.seg_tiles > 0 ? a.seg_tiles : tiles_y) : 1;
+    const int segs = (tiles_y + seg - 1) / seg, nunits = a.N * tiles_x * segs;
+    int my = 0;
+    if constexpr (STRIP) {
+        for (int u = worker; u < nunits; u += nworkers) { const int j = u % segs; my += (j + 1) * seg <= tiles_y ? seg : tiles_y - j * seg; }
+    } else {
+        my = worker < ntiles ? (ntiles - worker + nworkers - 1) / nworkers : 0;
+    }
     if (my == 0) return;                                // no barrier anywhere: a wave may simply leave
 
     // ---- A fragments and biases into registers, once ----
@@ -147,16 +159,33 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void unet_tail_kernel(const TailAr
 
     // ---- tile cursors: (image, tile row, tile column) advanced by the worker stride with carries -- scalar adds and compares instead
     //      of two integer divisions per tile ----
-    struct Cur { int n, ty, tx; };
+    struct Cur { int n, ty, tx, unit, ty_end; bool first; };      // first: first tile of its segment (STRIP): the whole halo comes from memory
     const int st_n = nworkers / tiles, st_y = (nworkers % tiles) / tiles_x, st_x = (nworkers % tiles) % tiles_x;
+    auto open_unit = [&](Cur &c, int u) {               // STRIP: two integer divisions per SEGMENT
+        c.unit = u;
+        const int strip = u / segs, j = u - strip * segs;
+        c.n = strip / tiles_x; c.tx = strip - c.n * tiles_x;
+        c.ty = j * seg; c.ty_end = c.ty + seg < tiles_y ? c.ty + seg : tiles_y;
+        c.first = true;
+    };
     auto advance = [&](Cur &c) {
-        c.tx += st_x; const int cx = c.tx >= tiles_x ? 1 : 0; c.tx -= cx * tiles_x;
-        c.ty += st_y + cx; const int cy = c.ty >= tiles_y ? 1 : 0; c.ty -= cy * tiles_y;
-        c.n += st_n + cy;
+        if constexpr (STRIP) {
+            c.first = false;
+            if (++c.ty == c.ty_end) open_unit(c, c.unit + nworkers);     // past the last unit: coordinates of no tile; request(false) ignores them
+        } else {
+            c.tx += st_x; const int cx = c.tx >= tiles_x ? 1 : 0; c.tx -= cx * tiles_x;
+            c.ty += st_y + cx; const int cy = c.ty >= tiles_y ? 1 : 0; c.ty -= cy * tiles_y;
+            c.n += st_n + cy;
+        }
     };
     Cur cl, cc;                                         // load cursor (one tile ahead) and compute cursor
-    cl.n = worker / tiles; cl.ty = (worker % tiles) / tiles_x; cl.tx = (worker % tiles) % tiles_x;
+    if constexpr (STRIP) open_unit(cl, worker);
+    else { cl.n = worker / tiles; cl.ty = (worker % tiles) / tiles_x; cl.tx = (worker % tiles) % tiles_x; cl.unit = 0; cl.ty_end = 0; cl.first = true; }
     cc = cl;
+    // STRIP: pieces of the halo rows a tile shares with the one above it (rows 0 .. HR0 - R - 1 = the first SH_PIECES pieces of a stage)
+    constexpr int SH_ROWS = HR0 - R, SH_PIECES = 2 * SH_ROWS * TL_IW, SH_NI = (SH_PIECES + 63) / 64, SH_FULL = SH_PIECES / 64;
+    constexpr int SH_SRC = R * TL_IW * 32;              // byte offset of halo row R (the first shared row as the tile above saw it)
+    static_assert(!STRIP || SH_SRC >= SH_PIECES * 16, "strip mode: the shared rows' old and new places must not overlap");
     u32x4 xq[2][NLD];
     auto request = [&](bool valid) {                    // both inputs' halos of the load cursor's tile -> registers (past the last tile: zeros)
         const int oy0 = cl.ty * R, ox0 = cl.tx * TL_TW;
@@ -177,17 +206,49 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void unet_tail_kernel(const TailAr
                 vo[i] = ok ? pbase[i] + (unsigned)toff : OOB;
             }
         }
+        // STRIP, not the first tile of its segment: the shared rows are in LDS already -- whole instructions of them are not issued, the
+        // one instruction that straddles the boundary fetches its shared pieces out of range (no memory traffic; their LDS slots are
+        // overwritten by the copy)
+        const bool fresh = !STRIP || cl.first;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
+            if (STRIP && i < SH_FULL && !fresh) continue;
+            if (STRIP && i == SH_FULL && SH_FULL < SH_NI && !fresh && lane + 64 * i < SH_PIECES) vo[i] = OOB;
             xq[0][i] = __builtin_amdgcn_raw_buffer_load_b128(rs0, vo[i], 0, 0);
             xq[1][i] = __builtin_amdgcn_raw_buffer_load_b128(rs1, vo[i], 0, 0);
         }
     };
-    auto park = [&]() {
+    auto park = [&](bool fresh) {                       // fresh: the whole halo was requested (always, unless STRIP)
+        [[maybe_unused]] u32x4 sh[2][STRIP ? SH_NI : 1];
+        if constexpr (STRIP) {
+            if (!fresh) {                                // the rows shared with the tile above: read at their old place before anything is stored
+#pragma unroll
+                for (int i = 0; i < SH_NI; ++i) {
+                    sh[0][i] = *reinterpret_cast<const u32x4 *>(wl + SH_SRC + lane * 16 + i * 1024);
+                    sh[1][i] = *reinterpret_cast<const u32x4 *>(wl + STAGE + SH_SRC + lane * 16 + i * 1024);
+                }
+            }
+            // The stores below hit, through OTHER lanes, the bytes just read: per thread the two address sets (same lane term, different
+            // constants) never alias, so hipcc may sink the reads behind the stores -- the first build did, and the shared rows came out as
+            // the NEW tile's rows.  The LDS executes a wave's instructions in order; the compiler has to keep them in order.
+            asm volatile("" ::: "memory");
+        }
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
+            if (STRIP && i < SH_FULL && !fresh) continue;     // never requested (request())
             *reinterpret_cast<u32x4 *>(wl + lane * 16 + i * 1024) = xq[0][i];
             *reinterpret_cast<u32x4 *>(wl + STAGE + lane * 16 + i * 1024) = xq[1][i];
+        }
+        if constexpr (STRIP) {
+            if (!fresh) {
+#pragma unroll
+                for (int i = 0; i < SH_NI; ++i) {
+                    if (i < SH_FULL || lane + 64 * i < SH_PIECES) {
+                        *reinterpret_cast<u32x4 *>(wl + lane * 16 + i * 1024) = sh[0][i];
+                        *reinterpret_cast<u32x4 *>(wl + STAGE + lane * 16 + i * 1024) = sh[1][i];
+                    }
+                }
+            }
         }
     };
 
@@ -340,7 +401,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void unet_tail_kernel(const TailAr
     request(true);
 #pragma unroll 1
     for (int k = 0; k < my; ++k) {
-        park();                                         // tile k: registers -> LDS (waits for its loads)
+        park(cl.first);                                 // tile k: registers -> LDS (waits for its loads)
         UKBB_TL_STAMP(0)
         advance(cl);
         request(k + 1 < my);                            // tile k + 1 in flight during everything below
@@ -403,6 +464,26 @@ hipError_t launch_unet_tail(const TailArgs &a_in, hipStream_t s) {
     constexpr int bytes = tl_lds_bytes(R, NW, NB);
     static_assert(bytes <= 160 * 1024, "LDS");
     const bool full = a.logits || a.prob;
+    // strip mode (r06 experiment, UKBB_TAIL_STRIPS=1; default: the row-major walk of r04 / r05): segments per strip chosen so that the busiest
+    // worker has the fewest tiles -- ceil(units / workers) * seg -- and among equals the longest segments (each segment re-reads 4 halo rows).
+    // Measured at N = 100 x 256x256 (profiles/r06_ab_tail.txt): a third fewer input bytes requested, identical bits, tail 158.5 vs 162.8 us under
+    // rocprofv3 (minima 151.2 / 150.2), forward +0.75 %: the tail is not bound by its bytes, so the simpler walk stays the default.
+    const char *es = getenv("UKBB_TAIL_STRIPS");
+    const bool strips = es && atoi(es) != 0;
+    a.seg_tiles = 0;
+    if (strips) {
+        const int tiles_y = (a.H + R - 1) / R, tiles_x = (a.W + TL_TW - 1) / TL_TW;
+        const long long nstrips = (long long)a.N * tiles_x, workers = (long long)grid * NW;
+        long long best = -1; int best_seg = tiles_y;
+        for (int segs = 1; segs <= tiles_y; ++segs) {
+            const int seg = (tiles_y + segs - 1) / segs;
+            if ((tiles_y + seg - 1) / seg != segs) continue;                   // not a distinct split
+            const long long units = nstrips * segs, cost = (units + workers - 1) / workers * seg;
+            if (best < 0 || cost < best) { best = cost; best_seg = seg; }
+        }
+        if (const char *e = getenv("UKBB_TAIL_SEG")) { const int v = atoi(e); if (v >= 1) best_seg = v; }
+        a.seg_tiles = best_seg;
+    }
 #ifdef UKBB_DIAG
     static unsigned long long *d_st = nullptr;
     const bool stamp = getenv("UKBB_TAIL_STAMPS") != nullptr;
@@ -437,6 +518,8 @@ hipError_t launch_unet_tail(const TailArgs &a_in, hipStream_t s) {
 #define UKBB_TAIL_CASE(NC)                                                                         \
     case NC: {                                                                                     \
         static OncePerDevice ok_full, ok_pred;                                                     \
+        static OncePerDevice ok_full_s, ok_pred_s;                                                 \
+        if (strips) return full ? go(unet_tail_kernel<R, NW, NB, NC, true, true>, ok_full_s) : go(unet_tail_kernel<R, NW, NB, NC, false, true>, ok_pred_s); \
         return full ? go(unet_tail_kernel<R, NW, NB, NC, true>, ok_full) : go(unet_tail_kernel<R, NW, NB, NC, false>, ok_pred); \
     }
     switch (a.ncls) {

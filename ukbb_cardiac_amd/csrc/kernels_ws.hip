@@ -107,10 +107,15 @@ __host__ __device__ constexpr bool wst_first(int tm, int blk, int a, int b) {
 //     ([image][tile][row][16-byte piece][lane]: every load / store instruction is one contiguous KB), h is written as bf16 NHWC (lane half g = channels 8 g ..:
 //     32 pixels x 32 bytes = one contiguous KB per row).  Eight independent waves per workgroup and two per SIMD hide the epilogue's loads and its
 //     transcendental chains behind each other's MFMAs -- what the fp32 Winograd form (kernels_wino24.hip) cannot do with its 192 accumulators per wave.
+//     LS 3 (r06): a time step with the x half of the gate convolution NOT hoisted -- two chunks, source 0 = the feature frame of window n at this step
+//     (in0 through ls_gx_map), source 1 = the previous hidden map (in1 through in0_map), bias as the C operand, no gx anywhere.  The bf16 step is bound by
+//     its bytes, not its MFMAs: reading x (32 bytes per pixel) and multiplying again costs 9 more MFMAs per 32 x 32 block and saves the 128 bytes per pixel
+//     of gx (320 -> 224 bytes per pixel and step).
 template <int KIND, int R, int CB, int NW, int NCH, bool TWO, int TM, bool LG = false, int LS = 0>
 __device__ __forceinline__ void ws_main(const ConvArgs &a, const int grp, const int walker, const int nwalk) {
     static_assert(!LG || (KIND == 0 && CB == 1), "fused logits: 3x3 conv with one Cout block");
-    static_assert(LS == 0 || (KIND == 0 && CB == 2 && NCH == 1 && !TWO && !LG), "ConvLSTM epilogue: 16 channels in, the 64 gate channels of one direction per workgroup");
+    static_assert(LS == 0 || (KIND == 0 && CB == 2 && !LG && ((LS != 3 && NCH == 1 && !TWO) || (LS == 3 && NCH == 2 && TWO))),
+                  "ConvLSTM epilogue: 16 channels in (LS 3: x 16 + h 16), the 64 gate channels of one direction per workgroup");
     constexpr int WS_IW = ws_iw(KIND), HR = ws_hr(KIND, R), TAPS = ws_taps(KIND);
     constexpr int HP = HR * WS_IW, NLD = ws_nld(KIND, R), STAGE = ws_stage_bytes(KIND, R), PLANE = ws_plane_bytes(KIND, R);
     constexpr int WSLAB = NCH * CB * TAPS * 1024;       // bytes: [chunk][cb][tap][lane][16]
@@ -201,10 +206,13 @@ __device__ __forceinline__ void ws_main(const ConvArgs &a, const int grp, const 
     auto load_setup = [&](int k) {
         int n, oy0, ox0;
         const bool valid = tile_coords(k, n, oy0, ox0);
+        int n1 = n;                                          // image of source 1
         if constexpr (LS == 2) { if (a.in0_map) n = map0[n]; }   // image n reads frame in0_map[n]
+        if constexpr (LS == 3) { if (a.in0_map) n1 = map0[n]; n = mapg[n]; }   // source 0 = the feature frame of window n at this step, source 1 = its previous hidden map
+        else n1 = n;
         // range = the image's planes of that source: a chunk's plane is selected by the scalar offset of the load
         rs0 = __builtin_amdgcn_make_buffer_rsrc((void *)(in0 + (size_t)n * nb0 * plane_bytes), 0, nb0 * plane_bytes, 0x00020000);
-        rs1 = __builtin_amdgcn_make_buffer_rsrc((void *)((TWO ? in1 : in0) + (size_t)n * (TWO ? nb1 : nb0) * plane_bytes), 0, (TWO ? nb1 : nb0) * plane_bytes, 0x00020000);
+        rs1 = __builtin_amdgcn_make_buffer_rsrc((void *)((TWO ? in1 : in0) + (size_t)n1 * (TWO ? nb1 : nb0) * plane_bytes), 0, (TWO ? nb1 : nb0) * plane_bytes, 0x00020000);
         const int toff = ((oy0 - 1) * a.W + (ox0 - 1)) * 32;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
@@ -271,20 +279,22 @@ __device__ __forceinline__ void ws_main(const ConvArgs &a, const int grp, const 
     // ---- LS 2: the tile's gx (bf16, four 16-byte pieces per row = one gate of the lane's eight hidden channels each) and cell state (fp32, two pieces per row)
     //      requested at the START of the tile's matrix phase: they return under its MFMAs and the other waves' work
     [[maybe_unused]] u32x4 gxq[LS == 2 ? R : 1][4];
-    [[maybe_unused]] f32x4 cq[LS == 2 ? R : 1][2];
+    [[maybe_unused]] f32x4 cq[LS >= 2 ? R : 1][2];
     [[maybe_unused]] auto ls_prefetch = [&](int k) {
-        if constexpr (LS == 2) {
+        if constexpr (LS >= 2) {
             int n, oy0, ox0;
             const bool valid = tile_coords(k, n, oy0, ox0);
             const int rtile = (oy0 / R) * a.tiles_x + ox0 / WS_TW;
-            const int fm = mapg[n];
             const int ci = a.in0_map ? map0[n] : n;
-            const unsigned char *gp = reinterpret_cast<const unsigned char *>(a.ls_gx) + ((size_t)fm * tiles + rtile) * (R * 4096) + lane * 16;
             const unsigned char *cp = reinterpret_cast<const unsigned char *>(a.ls_c_in) + ((size_t)ci * tiles + rtile) * (R * 2048) + lane * 16;
+            [[maybe_unused]] const unsigned char *gp = nullptr;
+            if constexpr (LS == 2) gp = reinterpret_cast<const unsigned char *>(a.ls_gx) + ((size_t)mapg[n] * tiles + rtile) * (R * 4096) + lane * 16;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
+                if constexpr (LS == 2) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) gxq[r][q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(gp + (r * 4 + q) * 1024));
+                    for (int q = 0; q < 4; ++q) gxq[r][q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(gp + (r * 4 + q) * 1024));
+                }
 #pragma unroll
                 for (int q = 0; q < 2; ++q) cq[r][q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(cp + (r * 2 + q) * 1024));
             }
@@ -404,11 +414,16 @@ __device__ __forceinline__ void ws_main(const ConvArgs &a, const int grp, const 
                         gi += wide(wi); gj += wide(wj); gf += wide(wf); go += wide(wo);
                         const float cold = cq[r][m >> 2][m & 3];
                         c = cold;
-                    } else {                                // the time steps add the ROUNDED gx: the x pass's own first step uses the same values
+                    } else if constexpr (LS == 3) {         // gates = W_x x + W_h h + b straight from the accumulator (fp32, nothing rounded)
+                        const float cold = cq[r][m >> 2][m & 3];
+                        c = cold;
+                    } else if (a.ls_gx) {                   // the time steps add the ROUNDED gx: the x pass's own first step uses the same values
                         auto rnd = [&](float v) { f32x2 t; t.x = v; t.y = 0.f; return __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2)) & 0xffffu; };
                         gh[0][m] = rnd(gi); gh[1][m] = rnd(gj); gh[2][m] = rnd(gf); gh[3][m] = rnd(go);
                         gi = __builtin_bit_cast(float, gh[0][m] << 16); gj = __builtin_bit_cast(float, gh[1][m] << 16);
                         gf = __builtin_bit_cast(float, gh[2][m] << 16); go = __builtin_bit_cast(float, gh[3][m] << 16);
+                    } else {                                // x pass of the un-hoisted form (LS 3 steps follow): no gx is kept, the first step uses the fp32 gates
+                        gh[0][m] = gh[1][m] = gh[2][m] = gh[3][m] = 0u;
                     }
                     const float sgf = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((gf + fb) * -1.44269504f));
                     const float sgi = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(gi * -1.44269504f));
@@ -428,7 +443,7 @@ __device__ __forceinline__ void ws_main(const ConvArgs &a, const int grp, const 
                     __builtin_amdgcn_raw_buffer_store_b128(v, rc_, lvo, (r * 2 + q) * 1024, 0);
                 }
                 if constexpr (LS == 1) {
-                    const __amdgpu_buffer_rsrc_t rg_ = __builtin_amdgcn_make_buffer_rsrc((void *)gw, 0, valid ? R * 4096 : 0, 0x00020000);
+                    const __amdgpu_buffer_rsrc_t rg_ = __builtin_amdgcn_make_buffer_rsrc((void *)gw, 0, (valid && a.ls_gx) ? R * 4096 : 0, 0x00020000);   // no gx asked for: range 0, stores dropped
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {           // piece q = gate q (i, j, f, o): halfwords m = 0..7
                         const u32x4 v = {gh[q][0] | (gh[q][1] << 16), gh[q][2] | (gh[q][3] << 16), gh[q][4] | (gh[q][5] << 16), gh[q][6] | (gh[q][7] << 16)};
@@ -582,7 +597,7 @@ __device__ __forceinline__ void ws_main(const ConvArgs &a, const int grp, const 
             constexpr int SETN = (Q + 1) & 1;           // register set / stage of position Q + 1
             if constexpr (SETN == 0) { park(S0); request(S0, std::integral_constant<int, (Q + 3) % U>{}); }
             else                     { park(S1); request(S1, std::integral_constant<int, (Q + 3) % U>{}); }
-            if constexpr (LS == 2) ls_prefetch(bi * TPB + Q / NCH);
+            if constexpr (LS >= 2 && Q % NCH == 0) ls_prefetch(bi * TPB + Q / NCH);
             compute(qc);
             if constexpr (Q % NCH == NCH - 1) { epilogue(bi * TPB + Q / NCH); UKBB_WS_STAMP(3 + bi * TPB + Q / NCH) }
         });
@@ -877,7 +892,8 @@ template <int R, int NW, int LS>
 __global__ __launch_bounds__(NW * 64, NW / 4) void lstm_ws_kernel(const ConvArgs a) {
     int grp, walker, nwalk;
     ws_place(a.Cout / 64, grp, walker, nwalk);
-    ws_main<0, R, 2, NW, 1, false, 0, false, LS>(a, grp, walker, nwalk);
+    if constexpr (LS == 3) ws_main<0, R, 2, NW, 2, true, 0, false, 3>(a, grp, walker, nwalk);
+    else ws_main<0, R, 2, NW, 1, false, 0, false, LS>(a, grp, walker, nwalk);
 }
 
 }  // namespace
@@ -1006,8 +1022,12 @@ size_t lstm_ws_c_floats(int H, int W) { return lstm_ws_tiles(H, W) * LSW_R * 512
 
 hipError_t launch_lstm_ws(const ConvArgs &a_in, hipStream_t s) {
     ConvArgs a = a_in;
-    if ((a.ls_mode != 1 && a.ls_mode != 2) || !a.ls_bf16 || a.C0 != 16 || a.C1 || a.in1 || a.up2 || a.H != a.Ho || a.W != a.Wo || a.pad_y != 1 || a.pad_x != 1) return hipErrorInvalidValue;
-    if (a.ls_mode == 1 ? (a.Cout != 64 && a.Cout != 128) || a.in0_map || !a.bias || !a.ls_gx || !a.ls_c_out : a.Cout != 64 || !a.ls_gx || !a.ls_gx_map || !a.ls_c_in || !a.ls_c_out)
+    if (a.ls_mode < 1 || a.ls_mode > 3 || !a.ls_bf16 || a.C0 != 16 || a.up2 || a.H != a.Ho || a.W != a.Wo || a.pad_y != 1 || a.pad_x != 1) return hipErrorInvalidValue;
+    if (a.ls_mode == 3 ? (a.C1 != 16 || !a.in1) : (a.C1 || a.in1)) return hipErrorInvalidValue;
+    // mode 1: gx optional (nullptr = the un-hoisted form follows, nothing is kept); mode 2: gx + its frame map; mode 3: the frame map (of in0) and the bias
+    if (a.ls_mode == 1 ? (a.Cout != 64 && a.Cout != 128) || a.in0_map || !a.bias || !a.ls_c_out
+        : a.ls_mode == 2 ? a.Cout != 64 || !a.ls_gx || !a.ls_gx_map || !a.ls_c_in || !a.ls_c_out
+                         : a.Cout != 64 || !a.bias || !a.ls_gx_map || !a.ls_c_in || !a.ls_c_out)
         return hipErrorInvalidValue;
     if ((long long)a.H * a.W * 32 >= 0x7fffffffll) return hipErrorInvalidValue;
     a.tiles_y = (a.Ho + LSW_R - 1) / LSW_R; a.tiles_x = (a.Wo + WS_TW - 1) / WS_TW;
@@ -1022,11 +1042,26 @@ hipError_t launch_lstm_ws(const ConvArgs &a_in, hipStream_t s) {
     int grid = cus >= 8 * nG ? cus / (8 * nG) * (8 * nG) : cus / nG * nG;
     if (grid < nG) grid = nG;
     if (want < grid) grid = (int)((want + nG - 1) / nG * nG);
-    constexpr int bytes = ws_lds_bytes(0, LSW_R, 2, LSW_NW, 1);
-    static_assert(bytes <= 160 * 1024, "LDS");
-    static OncePerDevice ok1, ok2;
+    constexpr int bytes = ws_lds_bytes(0, LSW_R, 2, LSW_NW, 1), bytes3 = ws_lds_bytes(0, LSW_R, 2, LSW_NW, 2);
+    static_assert(bytes <= 160 * 1024 && 2 * bytes3 <= 160 * 1024, "LDS (two workgroups per CU)");
+    static OncePerDevice ok1, ok2, ok3;
     if (a.ls_mode == 1) return launch_ws_kernel(lstm_ws_kernel<LSW_R, LSW_NW, 1>, bytes, LSW_NW * 64, a, grid, s, ok1);
+    if (a.ls_mode == 3) return launch_ws_kernel(lstm_ws_kernel<LSW_R, LSW_NW, 3>, bytes3, LSW_NW * 64, a, grid, s, ok3);
     return launch_ws_kernel(lstm_ws_kernel<LSW_R, LSW_NW, 2>, bytes, LSW_NW * 64, a, grid, s, ok2);
+}
+
+size_t pack_lstm_gate_weights_bf16_xh(const float *w, const float *bias, float *dst, float *bias_perm) {
+    // both 16-channel halves of the gate kernel [3][3][16 + 16][64] as the two chunks of ONE filter (chunk 0 = x rows, chunk 1 = h rows),
+    // output channels permuted as in pack_lstm_gate_weights_bf16: the resident filter of ws_main LS 3
+    std::vector<float> tmp((size_t)9 * 32 * 64);
+    for (int P = 0; P < 64; ++P) {
+        const int cb = P / 32, row = P % 32, j = row / 8, g = (row / 4) & 1, i = row % 4;
+        const int orig = (2 * cb + (j >> 1)) * 16 + 8 * g + 4 * (j & 1) + i;
+        if (bias_perm) bias_perm[P] = bias ? bias[orig] : 0.f;
+        for (int t = 0; t < 9; ++t)
+            for (int ci = 0; ci < 32; ++ci) tmp[((size_t)t * 32 + ci) * 64 + P] = w[((size_t)t * 32 + ci) * 64 + orig];
+    }
+    return pack_conv_weights_bf16(tmp.data(), 3, 32, 64, 2, dst);
 }
 
 size_t pack_lstm_gate_weights_bf16(const float *w, int cin_total, int c_first, const float *bias, float *dst, float *bias_perm) {
