@@ -526,8 +526,8 @@ def config4_cohort_probe(dev_index, rank, world, n_subjects, barrier=None):
            'subjects_this_rank': rec['subjects'], 'seconds_this_rank': round(dt, 4),
            'device_free_bytes_before': int(free_before), 'device_free_bytes_after': int(free_after),
            'device_memory_delta_mb': round((free_before - free_after) / 1e6, 2),
-           # the pipeline's device buffers are torch tensors: freed ones stay in torch's caching allocator (that, not a leak, is the
-           # constant ~1 GB "less free" tools/soak.py shows after its first subject-pipeline leg)
+           # the pipeline's device buffers are torch tensors: freed ones stay in torch's caching allocator, so the HIP-level free memory is
+           # compared with the pipeline alive on both sides and torch's reserved pool is reported beside it
            'torch_reserved_bytes_before': int(reserved_before), 'torch_reserved_bytes_after': int(torch.cuda.memory_reserved(dev))}
     if stages:
         tot = sum(stages.values())

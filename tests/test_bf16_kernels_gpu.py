@@ -66,9 +66,9 @@ def test_winograd_f2x4_matches_f2x2_and_its_two_region_shapes_agree_bit_for_bit(
 
 
 def test_tail_on_column_strips_gives_the_bits_of_the_row_major_walk():
-    """r06 experiment kept behind UKBB_TAIL_STRIPS=1 (kernels_tail.hip STRIP: tiles walked down column strips, the four halo rows two vertically adjacent
+    """r06, the default walk of the fused tail (kernels_tail.hip STRIP; UKBB_TAIL_STRIPS=0 = the row-major walk of r04 / r05: tiles walked down column strips, the four halo rows two vertically adjacent
     tiles share moved inside LDS instead of re-fetched): every output identical bits to the default walk for whole strips, segment lengths 1, 2, 3, 5
-    and ragged / tiny maps, pred-only and full-output kernels (tools/check_tail_strips.py; the first build failed exactly this test: hipcc sank the
+    and ragged / tiny maps, pred-only and full-output kernels against the row-major walk (tools/check_tail_strips.py; the first build failed exactly this test: hipcc sank the
     copy's LDS reads behind stores that alias them through other lanes)."""
     _tool('check_tail_strips.py', 2, 64, 96, 3, 256, 256, 1, 48, 80, 2, 16, 16, 1, 32, 272, 5, 112, 48)
 

@@ -64,7 +64,12 @@ if __name__ == '__main__':
         n += 1
     print('%d subjects through the subject pipeline in %.2f s (%.1f ms each), mismatching label volumes: %d' %
           (n, time.time() - t0, (time.time() - t0) / n * 1e3, bad), flush=True)
-    del pipe
+    # r06: the last Result of the loop keeps the pipeline (and its 3 slots x 260 MB of device buffers) alive through its back reference --
+    # r04 / r05 printed "1010.8 MB less free memory" here because `res` outlived `del pipe`, not because anything leaked
+    # (bench.py's 1000-subject cohort: HIP-level free memory moves by 2 MB, torch's reserved pool is constant)
+    del res, pipe
+    import gc
+    gc.collect()
     eng.close()
     del x, pred, ref
     torch.cuda.empty_cache()

@@ -464,12 +464,13 @@ hipError_t launch_unet_tail(const TailArgs &a_in, hipStream_t s) {
     constexpr int bytes = tl_lds_bytes(R, NW, NB);
     static_assert(bytes <= 160 * 1024, "LDS");
     const bool full = a.logits || a.prob;
-    // strip mode (r06 experiment, UKBB_TAIL_STRIPS=1; default: the row-major walk of r04 / r05): segments per strip chosen so that the busiest
-    // worker has the fewest tiles -- ceil(units / workers) * seg -- and among equals the longest segments (each segment re-reads 4 halo rows).
-    // Measured at N = 100 x 256x256 (profiles/r06_ab_tail.txt): a third fewer input bytes requested, identical bits, tail 158.5 vs 162.8 us under
-    // rocprofv3 (minima 151.2 / 150.2), forward +0.75 %: the tail is not bound by its bytes, so the simpler walk stays the default.
+    // strip mode (r06; UKBB_TAIL_STRIPS=0 = the row-major walk of r04 / r05): segments per strip chosen so that the busiest worker has the
+    // fewest tiles -- ceil(units / workers) * seg -- and among equals the longest segments (each segment re-reads 4 halo rows).
+    // Measured at N = 100 x 256x256 (profiles/r06_ab_tail.txt): identical bits; HBM traffic of the launch 674 -> 513 MB (counters: 2 x FETCH_SIZE +
+    // WRITE_SIZE; L2 hit rate 0.30 -> 0.40), the forward's 4128 -> 3966 MB; time unchanged (158.5 vs 162.8 us under rocprofv3, minima 151.2 / 150.2;
+    // forward +0.75 %): the tail is not bound by its bytes, the strips are the default for the traffic they save.
     const char *es = getenv("UKBB_TAIL_STRIPS");
-    const bool strips = es && atoi(es) != 0;
+    const bool strips = !es || atoi(es) != 0;
     a.seg_tiles = 0;
     if (strips) {
         const int tiles_y = (a.H + R - 1) / R, tiles_x = (a.W + TL_TW - 1) / TL_TW;
