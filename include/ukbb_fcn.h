@@ -98,7 +98,12 @@ void ukbb_fcn_destroy(ukbb_fcn_handle *h);
  * hoisted x half of the gate pre-activations and the hidden maps as bf16 in HBM (accumulation and cell
  * state fp32): 8-9 ms instead of 19 per 100-frame cine, per-class Dice >= 0.98 against the fp32 cine.  On FCN handles only the operands are bf16 (fp32 activations in
  * HBM; layers without such a tiling stay fp32).  Not bit-compatible with the reference; meant to be
- * judged by Dice against the fp32 result (common/image_utils.py:171-175): 0.993 / 0.992 measured. */
+ * judged by Dice against the fp32 result (common/image_utils.py:171-175): 0.993 / 0.992 measured.
+ * KNOWN LIMITATION (found in round 6, mechanism open): a UKBB_KIND_UNET handle in UKBB_PREC_BF16 must not run while kernels of ANOTHER stream
+ * of the same process are running (another handle's forward, any other GPU work): its weight-stationary launches then produce sporadic
+ * wrong tiles (tools/two_stream_check.py with PREC=bf16; profiles/r06_notes.md section 10).  One stream per process -- the way the drop-in
+ * scripts, the cohort pipeline's network stage and bench.py drive it -- is unaffected, as are fp32 / f32x3 handles and the FCN in every
+ * combination tried (tests/test_concurrency_gpu.py). */
 #define UKBB_PREC_FP32 0
 #define UKBB_PREC_BF16 1
 /* UKBB_PREC_F32X3 (round 2, FCN head only so far): fp32 results from bf16 matrix instructions.  Every fp32 operand x is

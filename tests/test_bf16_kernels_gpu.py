@@ -71,39 +71,3 @@ def test_tail_on_column_strips_gives_the_bits_of_the_row_major_walk():
     and ragged / tiny maps, pred-only and full-output kernels against the row-major walk (tools/check_tail_strips.py; the first build failed exactly this test: hipcc sank the
     copy's LDS reads behind stores that alias them through other lanes)."""
     _tool('check_tail_strips.py', 2, 64, 96, 3, 256, 256, 1, 48, 80, 2, 16, 16, 1, 32, 272, 5, 112, 48)
-
-
-def test_half_batch_chains_of_the_deep_levels_change_no_bit():
-    """r06: U-Net plans run levels >= 1 as two half-batch chains on two streams (engine.cpp run_plan, UKBB_SPLIT_FROM): labels, probabilities and
-    logits of the split plan (default) against the unsplit one (UKBB_SPLIT_FROM=0), fp32 and bf16, odd and even batches, batches below the split threshold."""
-    import numpy as np
-    sys.path.insert(0, ROOT)
-    from ukbb_cardiac_amd.arch import MODELS
-    from ukbb_cardiac_amd.engine import Engine
-    from ukbb_cardiac_amd.phantom import cine_phantom
-    from ukbb_cardiac_amd.weights import synthetic_params
-    arch = MODELS['UNet_ao']
-    params = synthetic_params(arch, 77)
-    old = os.environ.pop('UKBB_SPLIT_FROM', None)
-    try:
-        for n, H, W in ((9, 64, 96), (16, 128, 128), (3, 48, 80)):
-            img = ((cine_phantom(n, H, W, seed=n)[..., :1] - 0.3) / 0.25).astype(np.float32)
-            outs = {}
-            for tag, env in (('split', None), ('whole', '0'), ('from2', '2')):
-                if env is None:
-                    os.environ.pop('UKBB_SPLIT_FROM', None)
-                else:
-                    os.environ['UKBB_SPLIT_FROM'] = env
-                with Engine(arch, params) as eng:
-                    a = eng.run(img, want_logits=True, want_prob=True)
-                    eng.set_precision('bf16')
-                    b = eng.run(img, want_logits=True, want_prob=True)
-                outs[tag] = (a, b)
-            for tag in ('whole', 'from2'):
-                for i in (0, 1):
-                    for k in ('logits', 'prob', 'pred'):
-                        assert np.array_equal(outs['split'][i][k], outs[tag][i][k]), (n, H, W, tag, i, k)
-    finally:
-        os.environ.pop('UKBB_SPLIT_FROM', None)
-        if old is not None:
-            os.environ['UKBB_SPLIT_FROM'] = old

@@ -19,6 +19,9 @@
 
 using namespace ukbb;
 
+extern "C" int ukbb_fcn_debug_poison_lds(uint32_t pattern, void *stream);     // kernels_prep.hip (debugging aid, not in the public header)
+extern "C" int ukbb_fcn_debug_fence_kernel(void *stream);                       // kernels_prep.hip (debugging aid)
+
 namespace {
 
 thread_local std::string g_err;
@@ -146,6 +149,7 @@ struct ukbb_fcn_handle {
     // side stream for kernels that only feed the head (sqg_l): fork after level l, join before the head
     hipStream_t side = nullptr, side2 = nullptr;
     hipEvent_t ev_split_fork = nullptr, ev_split_join = nullptr;
+    int debug_first_op = 0, debug_last_op = 1 << 30;   // UKBB_DEBUG_OPS="first,last" at plan build: run_plan launches only these ops
     int split_first = -1, split_last = -2;      // op range run as two half-batch chains (UKBB_SPLIT_FROM at plan build)
     std::vector<hipEvent_t> ev_fork, ev_join;
     bool use_side = false;
@@ -912,15 +916,18 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
     }
     h->plan_h = H; h->plan_w = W; h->plan_small = n_hint <= SMALL_BATCH; h->plan_n = n_hint;
     h->plan_bfio = bf16_mode(h) == 2;
-    // r06: the U-Net's levels >= k (conv{k}_0 .. up{k}_1) run as two half-batch chains on two streams (run_plan): the launches of the deep
-    // levels are short, and one half's fill / drain / serial chains hide under the other half's body.  Measured at N = 100 x 256x256 with
-    // k = 1 (profiles/r06_split_levels.txt): fp32 4.06 -> 3.90 ms per forward (+4 %), bf16 1.076-1.092 -> 1.068-1.071 (+1-2 %), labels
-    // bit-identical; on the FCN (persistent 512-thread kernels that hold a CU's whole LDS) it is 0.5-1 % SLOWER, as r03 found for image
-    // ranges: U-Net plans take k = 1 by default, FCN plans none.  UKBB_SPLIT_FROM=k overrides (0 = off).
+    // r06 experiment, OFF by default: UKBB_SPLIT_FROM=k runs the levels >= k of a plan (U-Net: conv{k}_0 .. up{k}_1) as two half-batch chains on two
+    // streams (run_plan), so that one half's fill / drain / serial chains hide under the other half's body.  Measured at N = 100 x 256x256 with k = 1
+    // (profiles/r06_split_levels.txt): fp32 U-Net 4.06 -> 3.90 ms per forward (+4 %), bf16 1.076-1.092 -> 1.068-1.071 (+1-2 %), FCN 0.5-1 % slower.
+    // NOT the default because of what the 300-case bf16 sweep found with it (profiles/r06_notes.md section 10): the bf16-storage U-Net plan
+    // produces sporadic wrong tiles whenever kernels of ANOTHER stream of the same process run beside its weight-stationary launches
+    // (kernels_ws.hip) -- two engines on two streams show it too, the half-batch chains only brought it into one forward.  Every launch alone is
+    // right beside a disturbing stream, fp32 plans and the FCN are right in every combination tried; the mechanism is not understood, so nothing
+    // in the engine runs two launches at once unless asked to.
     h->split_first = -1; h->split_last = -2;
     {
         const char *e = getenv("UKBB_SPLIT_FROM");
-        const int k = e ? atoi(e) : (a.kind == UKBB_KIND_FCN ? 0 : 1);
+        const int k = e ? atoi(e) : 0;
         if (k >= 1 && k < a.n_level) {
             // U-Net: conv{k}_0 .. up{k}_1; FCN (no decoder): conv{k}_0 .. the last encoder conv (the squeeze launches and the head follow unsplit)
             const std::string c0 = "conv" + std::to_string(k) + "_0";
@@ -930,6 +937,12 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
                 if (h->ops[i].name.compare(0, u0.size(), u0) == 0 && h->ops[i].kind != OP_TAIL) h->split_last = (int)i;
             }
             if (h->split_first < 0 || h->split_last < h->split_first) { h->split_first = -1; h->split_last = -2; }
+        }
+        h->debug_first_op = 0; h->debug_last_op = 1 << 30;
+        if (const char *o = getenv("UKBB_DEBUG_OPS")) { int f = 0, l = 1 << 30; if (sscanf(o, "%d,%d", &f, &l) >= 1) { h->debug_first_op = f; h->debug_last_op = l; } }
+        if (const char *o = getenv("UKBB_SPLIT_OP")) {     // debugging: ONLY op i runs as two half-batch launches on two streams
+            const int i = atoi(o);
+            if (i >= 0 && i < (int)h->ops.size()) { h->split_first = i; h->split_last = i; }
         }
     }
     // events
@@ -1142,9 +1155,17 @@ int run_plan(ukbb_fcn_handle *h, const float *image, int n, float *logits, float
     // UKBB_SPLIT_FROM (plan build): the ops of levels >= k -- conv{k}_0 .. up{k}_1, the launches whose fill / drain and serial chains
     // are the largest part of their time -- run as TWO half-batch chains on two streams, enqueued interleaved, joined before the next op
     const int sp0 = h->split_first, sp1 = h->split_last;
+    // debugging aids (r06, tools/two_stream_bisect.py): run only the ops [first, last] of the plan (whatever they read was left by an earlier full forward)
+    const int dbg_first = h->debug_first_op, dbg_last = h->debug_last_op;
+    const char *poison_env = getenv("UKBB_DEBUG_POISON_LDS");            // hex pattern written to every CU's LDS in front of every launch
+    const bool poison_on = poison_env != nullptr;
+    const bool fence_on = getenv("UKBB_DEBUG_FENCE_KERNEL") != nullptr;
+    const bool sync_on = getenv("UKBB_DEBUG_SYNC_EVERY_OP") != nullptr;
+    const uint32_t poison_pat = poison_on ? (uint32_t)strtoul(poison_env, nullptr, 16) : 0u;
     for (size_t i = 0; i < h->ops.size(); ++i) {
         const Op &op = h->ops[i];
         s = s_main;
+        if ((int)i < dbg_first || (int)i > dbg_last) continue;
         if ((int)i == sp0 && sp1 >= sp0 && n >= 8 && !h->timing) {      // per-kernel timing (set_timing) measures whole-batch launches
             if (!h->side2) {
                 HIP_TRY(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking), UKBB_EDEVICE);
@@ -1187,11 +1208,14 @@ int run_plan(ukbb_fcn_handle *h, const float *image, int n, float *logits, float
         const bool timed = h->timing && (h->timing_only < 0 || h->timing_only == (int)i);
         if (timed) HIP_TRY(hipEventRecord(h->ev[2 * i], s), UKBB_EDEVICE);
         hipError_t e = hipSuccess;
+        if (poison_on) (void)ukbb_fcn_debug_poison_lds(poison_pat, s);      // debugging aid: a kernel that reads LDS it never wrote now reads this pattern
         {
             const int rc = launch_one(i, 0, n, s, e);
             if (rc) return rc;
         }
         if (e != hipSuccess) { set_err("launch of %s failed: %s", op.name.c_str(), hipGetErrorString(e)); return UKBB_EDEVICE; }
+        if (fence_on) (void)ukbb_fcn_debug_fence_kernel(s);                  // debugging aid: an explicit system-scope fence launch behind every op
+        if (sync_on) (void)hipStreamSynchronize(s);                           // debugging aid: the host waits for every op before it enqueues the next
         if (timed) HIP_TRY(hipEventRecord(h->ev[2 * i + 1], s), UKBB_EDEVICE);
         if (op.on_side) HIP_TRY(hipEventRecord(h->ev_join[op.stride], h->side), UKBB_EDEVICE);
     }
@@ -1206,6 +1230,13 @@ int run_plan(ukbb_fcn_handle *h, const float *image, int n, float *logits, float
 extern "C" {
 
 int ukbb_fcn_abi_version(void) { return UKBB_FCN_ABI_VERSION; }
+
+// debugging aid, not in the public header (tools/two_stream_bisect.py): forwards launch only the ops [first, last] of the plan from now on
+int ukbb_fcn_debug_set_ops(ukbb_fcn_handle *h, int first, int last) {
+    if (!h) return UKBB_EINVAL;
+    h->debug_first_op = first; h->debug_last_op = last;
+    return UKBB_OK;
+}
 
 const char *ukbb_fcn_last_error(void) { return g_err.c_str(); }
 

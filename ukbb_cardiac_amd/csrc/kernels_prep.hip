@@ -539,6 +539,45 @@ int ukbb_fcn_zscore_pack(const float *d_vol, int X, int Y, int Z, int T, int64_t
     return UKBB_OK;
 }
 
+// ---- debugging aid (r06): fill every CU's LDS with a bit pattern.  LDS is not cleared between workgroups; a kernel that reads LDS it never wrote
+//      normally sees the finite leftovers of the previous kernel of its own plan -- and NaN patterns when another stream's kernel ran there ----
+static __global__ __launch_bounds__(256) void poison_lds_kernel(unsigned pattern, int dwords, unsigned *sink) {
+    extern __shared__ unsigned pl_lds[];
+    for (int i = threadIdx.x; i < dwords; i += 256) pl_lds[i] = pattern;
+    __syncthreads();
+    if (sink && pl_lds[(threadIdx.x * 97) % dwords] != pattern) sink[0] = 1;     // keeps the stores alive
+}
+int ukbb_fcn_debug_poison_lds(uint32_t pattern, void *stream) {
+    constexpr int bytes = 160 * 1024;
+    static OncePerDevice ok;
+    if (allow_dynamic_lds(ok, reinterpret_cast<const void *>(poison_lds_kernel), bytes) != hipSuccess) { set_error("poison_lds: cannot get 160 KB of LDS"); return UKBB_EDEVICE; }
+    hipLaunchKernelGGL(poison_lds_kernel, dim3((unsigned)(device_cu_count() * 4)), dim3(256), bytes, (hipStream_t)stream, pattern, bytes / 4, (unsigned *)nullptr);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("poison_lds: launch failed: %s", hipGetErrorString(e)); return UKBB_EDEVICE; }
+    return UKBB_OK;
+}
+
+// ---- debugging aid (r06): a launch whose every workgroup does nothing but a system-scope release + acquire fence (L2 write-back and invalidate of
+//      the XCD it runs on): placed between two dependent launches it takes the place of whatever the runtime does, or does not do, at that boundary ----
+static __global__ __launch_bounds__(64) void fence_kernel(unsigned *sink) {
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);            // hipcc: system scope by default -> buffer_wbl2 sc0 sc1 + s_waitcnt + buffer_inv sc0 sc1
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "");       // system scope
+    if (sink && threadIdx.x == 12345) sink[0] = 1;
+}
+int ukbb_fcn_debug_fence_kernel(void *stream) {
+    hipLaunchKernelGGL(fence_kernel, dim3((unsigned)(device_cu_count() * 2)), dim3(64), 0, (hipStream_t)stream, (unsigned *)nullptr);
+    return hipGetLastError() == hipSuccess ? UKBB_OK : UKBB_EDEVICE;
+}
+
+// the same with a chosen LDS footprint per block (co-resident with other kernels' workgroups: a kernel that uses LDS beyond what it asked for reads this)
+int ukbb_fcn_debug_poison_lds_sized(uint32_t pattern, int bytes, int blocks, void *stream) {
+    if (bytes < 1024 || bytes > 160 * 1024 || blocks < 1) return UKBB_EINVAL;
+    static OncePerDevice ok;
+    if (allow_dynamic_lds(ok, reinterpret_cast<const void *>(poison_lds_kernel), 160 * 1024) != hipSuccess) return UKBB_EDEVICE;
+    hipLaunchKernelGGL(poison_lds_kernel, dim3((unsigned)blocks), dim3(256), bytes, (hipStream_t)stream, pattern, bytes / 4, (unsigned *)nullptr);
+    return hipGetLastError() == hipSuccess ? UKBB_OK : UKBB_EDEVICE;
+}
+
 int ukbb_fcn_synth_volume(uint64_t seed, size_t n, float *d_out, void *stream) {
     if (!d_out || n == 0 || (reinterpret_cast<uintptr_t>(d_out) & 15)) { set_error("synth_volume: bad argument (n > 0, 16-byte aligned output)"); return UKBB_EINVAL; }
     size_t blocks = (n / 4 + 255) / 256;
