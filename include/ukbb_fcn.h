@@ -99,11 +99,11 @@ void ukbb_fcn_destroy(ukbb_fcn_handle *h);
  * state fp32): 8-9 ms instead of 19 per 100-frame cine, per-class Dice >= 0.98 against the fp32 cine.  On FCN handles only the operands are bf16 (fp32 activations in
  * HBM; layers without such a tiling stay fp32).  Not bit-compatible with the reference; meant to be
  * judged by Dice against the fp32 result (common/image_utils.py:171-175): 0.993 / 0.992 measured.
- * KNOWN LIMITATION (found in round 6, mechanism open): a UKBB_KIND_UNET handle in UKBB_PREC_BF16 must not run while kernels of ANOTHER stream
- * of the same process are running (another handle's forward, any other GPU work): its weight-stationary launches then produce sporadic
- * wrong tiles (tools/two_stream_check.py with PREC=bf16; profiles/r06_notes.md section 10).  One stream per process -- the way the drop-in
- * scripts, the cohort pipeline's network stage and bench.py drive it -- is unaffected, as are fp32 / f32x3 handles and the FCN in every
- * combination tried (tests/test_concurrency_gpu.py). */
+ * Concurrency (round 6): a handle of any kind and precision may run beside kernels of other streams of the process (one handle per stream,
+ * one thread per handle; tests/test_concurrency_gpu.py runs two engines on two streams with batches in flight on both).  Until round 6 a
+ * UKBB_KIND_UNET handle in UKBB_PREC_BF16 could not: 16-byte buffer stores of its weight-stationary kernels lacked a wait state that hipcc
+ * does not emit when the store's soffset is an SGPR, and lost their data under another queue's memory traffic (kernels_ws.hip
+ * store_b128_sofs, profiles/r06_notes.md section 10; tests/test_store_hazard.py guards the ISA of the whole library). */
 #define UKBB_PREC_FP32 0
 #define UKBB_PREC_BF16 1
 /* UKBB_PREC_F32X3 (round 2, FCN head only so far): fp32 results from bf16 matrix instructions.  Every fp32 operand x is

@@ -27,10 +27,7 @@ if __name__ == '__main__':
     ref = None
     for r in range(rounds):
         for k in (0, 4, 3, 2, 1):
-            if k:
-                os.environ['UKBB_SPLIT_FROM'] = str(k)
-            else:
-                os.environ.pop('UKBB_SPLIT_FROM', None)
+            os.environ['UKBB_SPLIT_FROM'] = str(k)                     # 0 = off (the fp32 U-Net's default is 1)
             eng = Engine(arch, params)
             eng.set_precision(prec)
             for _ in range(3):

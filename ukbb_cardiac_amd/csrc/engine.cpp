@@ -916,18 +916,17 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
     }
     h->plan_h = H; h->plan_w = W; h->plan_small = n_hint <= SMALL_BATCH; h->plan_n = n_hint;
     h->plan_bfio = bf16_mode(h) == 2;
-    // r06 experiment, OFF by default: UKBB_SPLIT_FROM=k runs the levels >= k of a plan (U-Net: conv{k}_0 .. up{k}_1) as two half-batch chains on two
-    // streams (run_plan), so that one half's fill / drain / serial chains hide under the other half's body.  Measured at N = 100 x 256x256 with k = 1
-    // (profiles/r06_split_levels.txt): fp32 U-Net 4.06 -> 3.90 ms per forward (+4 %), bf16 1.076-1.092 -> 1.068-1.071 (+1-2 %), FCN 0.5-1 % slower.
-    // NOT the default because of what the 300-case bf16 sweep found with it (profiles/r06_notes.md section 10): the bf16-storage U-Net plan
-    // produces sporadic wrong tiles whenever kernels of ANOTHER stream of the same process run beside its weight-stationary launches
-    // (kernels_ws.hip) -- two engines on two streams show it too, the half-batch chains only brought it into one forward.  Every launch alone is
-    // right beside a disturbing stream, fp32 plans and the FCN are right in every combination tried; the mechanism is not understood, so nothing
-    // in the engine runs two launches at once unless asked to.
+    // r06: the levels >= k of a plan (U-Net: conv{k}_0 .. up{k}_1) run as two half-batch chains on two streams (run_plan), so that one half's
+    // fill / drain / serial chains hide under the other half's body.  Measured at N = 100 x 256x256 (profiles/r06_split_levels.txt and
+    // r06_split_after_fix.txt), labels bit-identical to the unsplit plan in every run: fp32 U-Net 4.02 -> 3.86 ms per forward with k = 1
+    // (+4 %; k = 2: 3.88, k = 3: 3.92, k = 4: no change), bf16-storage U-Net 1.042 -> 1.042 (nothing to hide once the walkers fill the chip),
+    // FCN 0.5-1 % slower.  So: ON from level 1 for a UKBB_KIND_UNET plan in fp32, off everywhere else; UKBB_SPLIT_FROM=k overrides (0 = off).
+    // (While this was first tried the 300-case bf16 sweep met sporadic wrong tiles with it; that was the wide-store hazard of kernels_ws.hip,
+    // store_b128_sofs there and profiles/r06_notes.md section 10 -- fixed, and the sweep is clean with the split forced on.)
     h->split_first = -1; h->split_last = -2;
     {
         const char *e = getenv("UKBB_SPLIT_FROM");
-        const int k = e ? atoi(e) : 0;
+        const int k = e ? atoi(e) : (a.kind == UKBB_KIND_UNET && bf16_mode(h) == 0) ? 1 : 0;
         if (k >= 1 && k < a.n_level) {
             // U-Net: conv{k}_0 .. up{k}_1; FCN (no decoder): conv{k}_0 .. the last encoder conv (the squeeze launches and the head follow unsplit)
             const std::string c0 = "conv" + std::to_string(k) + "_0";

@@ -56,6 +56,33 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x16 mfma_bf16(const u32x4 &a, const u32x4 &b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+// 16-byte buffer store whose soffset is an SGPR, followed by pinned wait states.
+// gfx950, found r06 (profiles/r06_notes.md section 10): the vector-memory unit reads the data registers of a store wider than 8 bytes over
+// several cycles AFTER issue, and a VALU write to one of them in the next issue slots changes what is stored.  hipcc pads this hazard only
+// when the store's soffset is a constant (LLVM GCNHazardRecognizer::createsVALUHazard assumes an SGPR soffset makes it impossible);
+// with an SGPR soffset it emitted "buffer_store_dwordx4 v[128:131], ... s55 offen" directly followed by "v_cvt_pk_bf16_f32 v128, ..."
+// (the packed registers of the next store).  With the memory pipeline to itself the store drains before the overwrite lands; under
+// back-pressure from another queue's kernels it does not, and whole 16-byte pieces of a map carried the NEXT piece's values (logits
+// of 1e33 a few layers later).  s_nop 7 x 2 behind every such store measured 0 failures in 160 two-stream forwards against 85 %
+// without, at no cost in time; sched_barrier keeps both schedulers from moving anything across.  tests/test_store_hazard.py checks
+// the ISA of every code object for the pattern.
+__device__ __forceinline__ void store_b128_sofs(const u32x4 &v, __amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, soff, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#if !defined(UKBB_STORE_PAD) || UKBB_STORE_PAD == 4
+    asm volatile("s_waitcnt expcnt(0)\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+#elif UKBB_STORE_PAD == 1                                  // experiment builds (tools/ab_store_pad.sh): how little is enough
+    asm volatile("s_nop 0" ::: "memory");
+#elif UKBB_STORE_PAD == 2
+    asm volatile("s_waitcnt expcnt(0)" ::: "memory");
+#elif UKBB_STORE_PAD == 3
+    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+#elif UKBB_STORE_PAD == 5
+    asm volatile("s_nop 3" ::: "memory");
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
     const __bf16 l = (__bf16)lo, h = (__bf16)hi;       // RNE; v_cvt_pk_bf16_f32
     return (unsigned)__builtin_bit_cast(unsigned short, l) | ((unsigned)__builtin_bit_cast(unsigned short, h) << 16);
@@ -440,14 +467,14 @@ __device__ __forceinline__ void ws_main(const ConvArgs &a, const int grp, const 
                 for (int q = 0; q < 2; ++q) {
                     const u32x4 v = {__builtin_bit_cast(unsigned, cn[4 * q]), __builtin_bit_cast(unsigned, cn[4 * q + 1]),
                                      __builtin_bit_cast(unsigned, cn[4 * q + 2]), __builtin_bit_cast(unsigned, cn[4 * q + 3])};
-                    __builtin_amdgcn_raw_buffer_store_b128(v, rc_, lvo, (r * 2 + q) * 1024, 0);
+                    store_b128_sofs(v, rc_, lvo, (r * 2 + q) * 1024);   // an offset above 4095 is an SGPR, not an immediate
                 }
                 if constexpr (LS == 1) {
                     const __amdgpu_buffer_rsrc_t rg_ = __builtin_amdgcn_make_buffer_rsrc((void *)gw, 0, (valid && a.ls_gx) ? R * 4096 : 0, 0x00020000);   // no gx asked for: range 0, stores dropped
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {           // piece q = gate q (i, j, f, o): halfwords m = 0..7
                         const u32x4 v = {gh[q][0] | (gh[q][1] << 16), gh[q][2] | (gh[q][3] << 16), gh[q][4] | (gh[q][5] << 16), gh[q][6] | (gh[q][7] << 16)};
-                        __builtin_amdgcn_raw_buffer_store_b128(v, rg_, lvo, (r * 4 + q) * 1024, 0);
+                        store_b128_sofs(v, rg_, lvo, (r * 4 + q) * 1024);
                     }
                 }
                 u32x4 hvw;
@@ -457,7 +484,7 @@ __device__ __forceinline__ void ws_main(const ConvArgs &a, const int grp, const 
                     hvw[d] = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
                 }
                 const __amdgpu_buffer_rsrc_t rh_ = __builtin_amdgcn_make_buffer_rsrc((void *)hbase, 0, rowok ? himg_bytes : 0, 0x00020000);
-                __builtin_amdgcn_raw_buffer_store_b128(hvw, rh_, hvo, (oy * a.Wo + ox0) * 32, 0);
+                store_b128_sofs(hvw, rh_, hvo, (oy * a.Wo + ox0) * 32);
             });
             return;
         }
@@ -554,7 +581,7 @@ __device__ __forceinline__ void ws_main(const ConvArgs &a, const int grp, const 
                     const auto sx = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
                     const auto sy = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
                     const u32x4 v = {sx[0], sy[0], sx[1], sy[1]};
-                    __builtin_amdgcn_raw_buffer_store_b128(v, ro, vo[cb][jb / 2], srow, 0);
+                    store_b128_sofs(v, ro, vo[cb][jb / 2], srow);
                 });
             });
         });
@@ -813,7 +840,7 @@ __device__ __forceinline__ void wr_main(const ConvArgs &a, const int grp, const 
                     const auto sx = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
                     const auto sy = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
                     const u32x4 v = {sx[0], sy[0], sx[1], sy[1]};
-                    __builtin_amdgcn_raw_buffer_store_b128(v, ro, colok ? svoff[cb][jb / 2] : OOB, srow, 0);
+                    store_b128_sofs(v, ro, colok ? svoff[cb][jb / 2] : OOB, srow);
                 });
             });
         });
