@@ -62,7 +62,8 @@ def test_unet_lstm_cine_does_not_read_foreign_lds(monkeypatch):
 
 
 @pytest.mark.parametrize('model,prec,shape,split', [('FCN_sa', 'fp32', (32, 192, 208), None), ('UNet_ao', 'fp32', (10, 304, 272), None), ('UNet_ao', 'fp32', (10, 304, 272), '0'),
-                                                    ('UNet_ao', 'bf16', (10, 304, 272), None), ('UNet_ao', 'bf16', (24, 256, 256), '1'), ('FCN_sa', 'bf16', (32, 192, 208), None)])
+                                                    ('UNet_ao', 'bf16', (10, 304, 272), None), ('UNet_ao', 'bf16', (24, 256, 256), '1'), ('FCN_sa', 'bf16', (32, 192, 208), None),
+                                                    ('UNet-LSTM_ao', 'fp32', (12, 96, 128), None), ('UNet-LSTM_ao', 'bf16', (20, 128, 160), None)])
 def test_plans_are_right_beside_another_streams_work(model, prec, shape, split):
     import subprocess
     n, h, w = shape
@@ -70,7 +71,7 @@ def test_plans_are_right_beside_another_streams_work(model, prec, shape, split):
     env.pop('UKBB_SPLIT_FROM', None)
     if split is not None:
         env['UKBB_SPLIT_FROM'] = split
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'two_stream_check.py'), model, str(n), str(h), str(w), '120'], env=env,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'two_stream_check.py'), model, str(n), str(h), str(w), '40' if model.startswith('UNet-LSTM') else '120'], env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == 'OK', r.stdout[-2000:]
 

@@ -1,8 +1,9 @@
-"""Do kernels that use scratch (private-segment) memory survive running CONCURRENTLY from two HIP streams of one process?
-r06: the half-batch chains of the bf16 U-Net produced sporadic garbage exactly when `conv_wr_kernel<2,2,8>` (24 bytes of scratch: the
-only spilling kernel in the range) ran from two streams at once; with the scratch-free tiling of the same layer: never.  This tool runs TWO
-engines of one model on two streams, batches in flight on both, and compares every label map with the single-stream reference.
-    python tools/two_stream_check.py [model] [N H W] [iterations]        GPU box; prints OK / FAILED."""
+"""Is a forward right while kernels of ANOTHER stream of the same process run beside it?
+Two engines of one model on two streams, four batches in flight on each, every label map compared with the single-stream result.
+r06: this is the check that exposed (and now guards) the wide-store hazard of kernels_ws.hip -- the bf16-storage U-Net failed 85-98 % of
+its forwards here until its 16-byte buffer stores were padded (profiles/r06_notes.md section 10).  A 'UNet-LSTM...' model runs whole cines
+(N = frames) through ukbb_fcn_forward_cine.
+    PREC=fp32|bf16|f32x3 python tools/two_stream_check.py [model] [N H W] [iterations]        GPU box; prints OK / FAILED."""
 import os
 import sys
 
@@ -23,16 +24,24 @@ if __name__ == '__main__':
     arch = MODELS[model]
     params = synthetic_params(arch, 1234)
     dev = torch.device('cuda', 0)
-    xs = [torch.from_numpy(uniform_slices(n, h, w, seed=10 + i)).to(dev) for i in range(2)]
+    lstm = model.startswith('UNet-LSTM')                        # a cine of n frames per "forward" (ukbb_fcn_forward_cine), frames [n, h, w]
+    xs = [torch.from_numpy(uniform_slices(n, h, w, seed=10 + i)[..., 0].copy() if lstm else uniform_slices(n, h, w, seed=10 + i)).to(dev) for i in range(2)]
     engs = [Engine(arch, params) for _ in range(2)]
     for e in engs:
         if prec != 'fp32':
             e.set_precision(prec)
     streams = [torch.cuda.Stream(dev) for _ in range(2)]
+
+    def forward(i, pred, stream=0):
+        if lstm:
+            engs[i].run_cine_device(xs[i].data_ptr(), n, h, w, probs[i].data_ptr(), pred.data_ptr(), stream=stream)
+        else:
+            engs[i].run_device(xs[i].data_ptr(), n, h, w, pred_ptr=pred.data_ptr(), stream=stream)
+    probs = [torch.empty((n, h, w, arch.n_class), dtype=torch.float32, device=dev) for _ in range(2)] if lstm else None   # (one per stream: graded on the labels)
     refs = []
     for i in range(2):                                           # single-stream references
         p = torch.empty((n, h, w), dtype=torch.int32, device=dev)
-        engs[i].run_device(xs[i].data_ptr(), n, h, w, pred_ptr=p.data_ptr())
+        forward(i, p)
         torch.cuda.synchronize()
         refs.append(p.clone())
     preds = [[torch.empty((n, h, w), dtype=torch.int32, device=dev) for _ in range(4)] for _ in range(2)]
@@ -40,7 +49,7 @@ if __name__ == '__main__':
     for it in range(0, iters, 4):
         for k in range(4):                                       # 4 batches in flight per stream before anything is checked
             for i in range(2):
-                engs[i].run_device(xs[i].data_ptr(), n, h, w, pred_ptr=preds[i][k].data_ptr(), stream=streams[i].cuda_stream)
+                forward(i, preds[i][k], streams[i].cuda_stream)
         torch.cuda.synchronize()
         for i in range(2):
             for k in range(4):
