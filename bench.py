@@ -366,10 +366,11 @@ def other_configs_probe(device):
     x = torch.from_numpy(img).to(device)
     pred = torch.empty((n, 256, 256), dtype=torch.int32, device=device)
     with Engine(arch, synthetic_params(arch, 1234), device=device.index) as eng:
-        t32 = rate(eng, x, n, 256, 256, pred)
+        # timed regions of >= 50 ms: one host synchronisation costs 0.3-0.5 ms, which a 10-forward region of the bf16 path (10 ms) showed as +4 % (r06: 1.10 vs 1.05 ms)
+        t32 = rate(eng, x, n, 256, 256, pred, k=20)
         p32 = pred.cpu().numpy().copy()
         eng.set_precision('bf16')
-        t16 = rate(eng, x, n, 256, 256, pred)
+        t16 = rate(eng, x, n, 256, 256, pred, k=50)
         p16 = pred.cpu().numpy()
         launches = len(eng.kernel_names())
     from ukbb_cardiac_amd.arch import fcn_macs_per_slice
