@@ -53,7 +53,11 @@ extern "C" {
                                same_dim = ConvLSTM hidden channels (16), fc = unrolled time steps (9);
                                weights: the UNet layers without its conv_out, then per direction the gate
                                kernel [3,3,16+16,64] + bias[64] (forward, backward), then the output conv
-                               kernel [1,1,32,n_class] + bias.  Use forward_seq / forward_cine. */
+                               kernel [1,1,32,n_class] + bias.  Use forward_seq / forward_cine.
+                               The single-direction head Conv_LSTM (:214-252, bidirectional=False :349-352) is this
+                               kind with an all-zero backward gate kernel + bias and the output kernel [W; 0]: exact
+                               (that cell's hidden maps are 0 at every step), detected at create, its time steps are
+                               skipped (round 6; weights.embed_unidirectional_lstm does the embedding). */
 
 /* Hyper-parameters of build_FCN / UNet as bound in common/train_network.py:174-195
  * and common/train_network_ao.py:268,275-284. */

@@ -291,14 +291,30 @@ def biconv_lstm(features, params, n_hidden):
     return np.stack(outs, axis=1)
 
 
+def conv_lstm(features, params, n_hidden):
+    """Conv_LSTM, common/network_ao.py:214-252 (the single-direction head, UNet_LSTM_Model with bidirectional=False :349-352):
+    one cell from the zero state (:228) over t = 0..T-1, the 1x1 logits conv on every step's cell output (:244).
+    params['lstm'] = the cell's {'kernel' [3,3,C+h,4h], 'bias'}, params['lstm_conv'] = {'kernel' [1,1,h,n_class], 'bias'}."""
+    N, T, H, W, _ = features.shape
+    dt = features.dtype
+    h = c = np.zeros((N, H, W, n_hidden), dt)
+    po = params['lstm_conv']
+    outs = []
+    for t in range(T):
+        h, c = conv_lstm_cell(features[:, t], h, c, params['lstm'])
+        outs.append(conv2d_same(h, po['kernel'], 1) + po['bias'].astype(dt))
+    return np.stack(outs, axis=1)
+
+
 def unet_lstm(images, params, n_hidden=16, n_level=5, n_filter=(16, 32, 64, 128, 256), n_block=(2, 2, 2, 2, 2),
-              dtype=np.float64):
-    """UNet_LSTM_Model inference graph, common/network_ao.py:322-399 (bidirectional): images [N,T,H,W,1] ->
-    logits [N,T,H,W,n_class]; prob = softmax, pred = argmax (:396-397)."""
+              dtype=np.float64, bidirectional=True):
+    """UNet_LSTM_Model inference graph, common/network_ao.py:322-399: images [N,T,H,W,1] -> logits [N,T,H,W,n_class];
+    prob = softmax, pred = argmax (:396-397).  bidirectional (:349-352) picks BiConv_LSTM (the released model) or Conv_LSTM."""
     x = np.asarray(images, dtype=dtype)
     N, T, H, W, C = x.shape
     feats = unet_features(x.reshape(N * T, H, W, C), params, n_level, n_filter, n_block, dtype)
-    return biconv_lstm(feats.reshape(N, T, H, W, feats.shape[-1]), params, n_hidden)
+    head = biconv_lstm if bidirectional else conv_lstm
+    return head(feats.reshape(N, T, H, W, feats.shape[-1]), params, n_hidden)
 
 
 def aortic_lstm_prob_sequence(image, forward_seq, weight_R=5, weight_r=0.1, time_step=1, n_class=3):

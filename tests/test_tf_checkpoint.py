@@ -155,10 +155,10 @@ def test_lstm_cell_scope_is_matched_not_assumed(tmp_path, cell):
         tfc.checkpoint_to_params(prefix)
 
 
-def test_unidirectional_conv_lstm_checkpoint_is_refused_by_name(tmp_path):
+def test_unidirectional_conv_lstm_checkpoint_loads_as_a_zero_backward_cell(tmp_path):
     """common/network_ao.py:214-252 Conv_LSTM (train_network_ao.py --bidirectional=False) keeps ONE cell directly under LSTM/
-    and its output conv as LSTM/conv2d: such a checkpoint must be refused with a message that says so, not fail on a
-    'missing' LSTM/forward variable."""
+    and its output conv as LSTM/conv2d.  (r05 refused such a checkpoint by name; r06 serves it: the importer embeds it in the
+    bidirectional layer set with an all-zero backward cell, weights.embed_unidirectional_lstm -- exact, tests/test_unidirectional_lstm.py.)"""
     arch = MODELS['UNet-LSTM_ao']
     params = synthetic_params(arch, 12)
     t = _tf_tensors(arch, params, with_slots=False)
@@ -167,7 +167,24 @@ def test_unidirectional_conv_lstm_checkpoint_is_refused_by_name(tmp_path):
     uni['LSTM/conv_lstm_cell/biases'] = t['LSTM/forward/conv_lstm_cell/biases']
     uni['LSTM/conv2d/kernel'] = t['LSTM/output/conv2d/kernel'][:, :, :16]                # [1,1,n_hidden,n_class]
     uni['LSTM/conv2d/bias'] = t['LSTM/output/conv2d/bias']
+    uni['LSTM/conv_lstm_cell/kernel/Adam'] = np.zeros_like(uni['LSTM/conv_lstm_cell/kernel'])   # optimizer slots do not confuse it
     prefix = str(tmp_path / 'UNet-LSTM_uni')
     write_checkpoint(prefix, uni, tensor_crc=False)
-    with pytest.raises(tfc.CheckpointError, match='UNIDIRECTIONAL.*bidirectional=False'):
-        tfc.checkpoint_to_params(prefix)
+    arch2, params2 = tfc.checkpoint_to_params(prefix)
+    assert arch2 == arch
+    np.testing.assert_array_equal(params2['lstm_fw']['kernel'], params['lstm_fw']['kernel'])
+    np.testing.assert_array_equal(params2['lstm_fw']['bias'], params['lstm_fw']['bias'])
+    assert not params2['lstm_bw']['kernel'].any() and not params2['lstm_bw']['bias'].any()
+    np.testing.assert_array_equal(params2['lstm_out']['kernel'][:, :, :16], params['lstm_out']['kernel'][:, :, :16])
+    assert not params2['lstm_out']['kernel'][:, :, 16:].any()
+    np.testing.assert_array_equal(params2['lstm_out']['bias'], params['lstm_out']['bias'])
+    for name in params:
+        if not name.startswith('lstm'):
+            for k in params[name]:
+                np.testing.assert_array_equal(params2[name][k], params[name][k])
+    assert pack_flat(arch2, params2).size == arch.n_weight_floats()
+    # a checkpoint with BOTH the single cell and the directional scopes is the bidirectional model (the extra variables are ignored)
+    both = dict(t); both.update({k: v for k, v in uni.items() if k.startswith('LSTM/')})
+    write_checkpoint(prefix, both, tensor_crc=False)
+    _, params3 = tfc.checkpoint_to_params(prefix)
+    np.testing.assert_array_equal(pack_flat(arch, params3), pack_flat(arch, params))

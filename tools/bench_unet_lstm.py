@@ -16,7 +16,14 @@ if __name__ == '__main__':
     from ukbb_cardiac_amd.engine import Engine
     from ukbb_cardiac_amd.weights import synthetic_params
     arch = MODELS['UNet-LSTM_ao']
-    eng = Engine(arch, synthetic_params(arch, 1234))
+    params = synthetic_params(arch, 1234)
+    if os.environ.get('UNI'):                                          # the single-direction head (network_ao.py:214-252) through its zero-backward-cell embedding
+        from ukbb_cardiac_amd.weights import embed_unidirectional_lstm
+        uni = {k: v for k, v in params.items() if not k.startswith('lstm')}
+        uni['lstm'] = params['lstm_fw']
+        uni['lstm_conv'] = {'kernel': params['lstm_out']['kernel'][:, :, :arch.same_dim], 'bias': params['lstm_out']['bias']}
+        params = embed_unidirectional_lstm(uni, arch.same_dim)
+    eng = Engine(arch, params)
     F, H, W = 100, 256, 256
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 5                  # timed cines (profilers pass a small count)
     prec = sys.argv[2] if len(sys.argv) > 2 else 'fp32'

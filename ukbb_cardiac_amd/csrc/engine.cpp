@@ -140,6 +140,8 @@ struct ukbb_fcn_handle {
     int feat_buf = -1;                        // activation index of net['conv0_up']
     bool lstm_bf_hoist = true;                // bf16 time steps read the hoisted gx (r05; default) -- false (UKBB_LSTM_BF16_UNHOIST at plan build): they re-multiply x (r06 experiment)
     bool lstm_bf_wino = false;                // UKBB_LSTM_BF16_WINOGRAD at plan build: fp32 Winograd arithmetic on bf16 storage (A/B form)
+    bool lstm_bw_zero = false;                // the backward cell's kernel and bias are all zero (the single-direction head Conv_LSTM of network_ao.py:214-252 embedded by
+                                              // weights.embed_unidirectional_lstm): its hidden maps are exactly zero, run_bilstm clears them instead of running its time steps
     int lstm_tile_cols = 0;                   // region shape of the fused gate-conv / cell kernel (kernels_wino24.hip): 32 | 16
     // lstm_gx / lstm_c1 / lstm_h1: per direction and FRAME (the x pass); lstm_c: per window; lstm_hall: per direction, step and window
     DevBuf lstm_gx, lstm_c1, lstm_h1, lstm_c, lstm_hall, lstm_probw, lstm_aux;   // lstm_aux: int maps / orders / double weights (raw bytes)
@@ -874,6 +876,13 @@ int build_plan(ukbb_fcn_handle *h, int H, int W, int n_hint) {
             }
             h->lstm_tile_cols = have24 ? c.tw : 32;
             if (const char *e = getenv("UKBB_LSTM_TILE_COLS")) { const int v = atoi(e); if (v == 16 || v == 32) h->lstm_tile_cols = v; }   // A/B knob (identical bits)
+            {
+                const HostLayer &B = h->layers[h->layer_index.at("lstm_bw")];
+                bool z = getenv("UKBB_LSTM_RUN_ZERO_CELL") == nullptr;      // knob: run the zero cell anyway (tests compare both ways)
+                for (size_t i = 0; z && i < B.w.size(); ++i) z = B.w[i] == 0.f;
+                for (size_t i = 0; z && i < B.b.size(); ++i) z = B.b[i] == 0.f;
+                h->lstm_bw_zero = z;
+            }
             if (!dev_ptr(h, "lstm/wx")) {
                 const size_t per = (size_t)24 * 16 * 64;
                 std::vector<float> wx(2 * per), bx(2 * 64), wh(per);
@@ -1449,7 +1458,11 @@ int run_bilstm(ukbb_fcn_handle *h, const float *feat, int NF, const int *d_map, 
         if (e != hipSuccess) { set_err("ConvLSTM x-pass launch failed: %s", hipGetErrorString(e)); return UKBB_EDEVICE; }
     }
     const size_t kst = (size_t)Wn * HW * NHID;           // one step's hidden maps
-    for (int dir = 0; dir < 2; ++dir) {
+    // A zero backward cell (the single-direction head served through the bidirectional layer set): from the zero state i = o = 1/2, j = tanh(0) = 0,
+    // so c and h stay exactly 0 at every step -- the x pass above already produced zeros for its first step; the other T - 1 maps are cleared, not computed.
+    const int ndir = h->lstm_bw_zero ? 1 : 2;
+    if (h->lstm_bw_zero) HIP_TRY(hipMemsetAsync(at(h->lstm_hall.p, (size_t)T * kst), 0, (size_t)T * kst * esz, s), UKBB_EDEVICE);
+    for (int dir = 0; dir < ndir; ++dir) {
         float *const hall = at(h->lstm_hall.p, (size_t)dir * T * kst);
         for (int step = 1; step < T; ++step) {
             const int k = dir ? T - 1 - step : step, kprev = dir ? k + 1 : k - 1;

@@ -386,6 +386,23 @@ def variable_names(arch: ModelArch, available=None) -> "OrderedDict[str, Dict[st
     return out
 
 
+def unidirectional_lstm_variables(available) -> Optional[Dict[str, Dict[str, str]]]:
+    """Variable names of the single-direction head Conv_LSTM (network_ao.py:214-252: one Conv2DLSTMCell and the logits conv directly under
+    variable_scope('LSTM')), or None when the checkpoint has the bidirectional scopes (or no LSTM at all).
+    [TF-recall: LSTM/<cell scope>/{kernel,biases}, LSTM/conv2d/{kernel,bias}]"""
+    names = set(available)
+    if any(n.startswith(('LSTM/forward/', 'LSTM/backward/', 'LSTM/output/')) for n in names):
+        return None
+    cell_k = sorted(n for n in names if re.match(r'^LSTM/[^/]+/kernel$', n) and not n.startswith('LSTM/conv2d'))
+    if len(cell_k) != 1 or 'LSTM/conv2d/kernel' not in names:
+        return None
+    scope = cell_k[0][:-len('/kernel')]
+    bias = scope + '/biases' if scope + '/biases' in names else scope + '/bias'
+    if bias not in names or 'LSTM/conv2d/bias' not in names:
+        return None
+    return {'lstm': {'kernel': cell_k[0], 'bias': bias}, 'lstm_conv': {'kernel': 'LSTM/conv2d/kernel', 'bias': 'LSTM/conv2d/bias'}}
+
+
 def infer_arch(reader: CheckpointReader) -> ModelArch:
     """Hyper-parameters from the kernel shapes (the .meta graph is not parsed)."""
     names = set(reader.names())
@@ -402,13 +419,18 @@ def infer_arch(reader: CheckpointReader) -> ModelArch:
             l += 1
         lstm = any(_LSTM_VAR.match(n) for n in names)
         # the single-direction head Conv_LSTM (network_ao.py:214-252; train_network_ao.py --bidirectional=False) keeps its cell directly
-        # under LSTM/ -- LSTM/<cell>/{kernel,biases} + LSTM/conv2d -- with no forward / backward / output scopes: refuse it by name
-        # instead of failing later on a "missing" LSTM/forward variable
-        uni = sorted(n for n in names if n.startswith('LSTM/') and not n.startswith(('LSTM/forward/', 'LSTM/backward/', 'LSTM/output/')))
-        if uni and not lstm:
-            raise CheckpointError('this is a UNet-LSTM checkpoint with the UNIDIRECTIONAL ConvLSTM head (common/network_ao.py:214-252 Conv_LSTM, '
-                                  'trained with --bidirectional=False; variables %s ...): only the bidirectional BiConv_LSTM head of the released '
-                                  'model (network_ao.py:255-319, LSTM/forward + LSTM/backward + LSTM/output) is built' % ', '.join(uni[:3]))
+        # under LSTM/ -- LSTM/<cell>/{kernel,biases} + LSTM/conv2d -- with no forward / backward / output scopes.  It is served by the
+        # bidirectional engine with a zero backward cell (weights.embed_unidirectional_lstm: exact), see checkpoint_to_params
+        if unidirectional_lstm_variables(names) is not None:
+            uv = unidirectional_lstm_variables(names)
+            n_hidden = reader.shape(uv['lstm']['kernel'])[3] // 4
+            cand = ModelArch('UNet-LSTM_custom', KIND_UNET_LSTM, reader.shape(uv['lstm_conv']['kernel'])[3],
+                             n_level=len(n_filter), n_filter=tuple(n_filter), n_block=tuple(n_block), same_dim=n_hidden, fc=9)
+            for m in MODELS.values():
+                if (m.kind, m.n_class, m.n_level, tuple(m.n_filter), tuple(m.n_block), m.same_dim, m.fc) == \
+                   (cand.kind, cand.n_class, cand.n_level, tuple(cand.n_filter), tuple(cand.n_block), cand.same_dim, cand.fc):
+                    return m
+            return cand
         if not n_filter or (not lstm and 'UNet/conv_out/conv2d/kernel' not in names):
             raise CheckpointError('UNet checkpoint without the expected UNet/conv{l}/conv2d variables')
         if lstm:
@@ -460,15 +482,26 @@ def checkpoint_to_params(prefix: str, arch: Optional[ModelArch] = None, verify_c
         arch = infer_arch(reader)
     params = {}
     specs = {s.name: s for s in arch.layer_specs()}
-    for layer, names in variable_names(arch, reader.names()).items():
+    uni = unidirectional_lstm_variables(reader.names()) if arch.kind == KIND_UNET_LSTM else None
+    wanted = variable_names(arch, None if uni else reader.names())
+    if uni:                                                  # Conv_LSTM head: its two layers are read under their own names and embedded below
+        for layer in ('lstm_fw', 'lstm_bw', 'lstm_out'):
+            wanted.pop(layer)
+        wanted.update(uni)
+        nh = arch.same_dim
+        shapes = {'lstm': (3, 3, arch.n_filter[0] + nh, 4 * nh), 'lstm_conv': (1, 1, nh, arch.n_class)}
+    for layer, names in wanted.items():
         p = {}
         for key, tfname in names.items():
             t = reader.get_tensor(tfname, verify_crc).astype(np.float32)
             p[key] = t
-        want = tuple(specs[layer].kernel_shape)
+        want = tuple(specs[layer].kernel_shape) if layer in specs else shapes[layer]
         if tuple(p['kernel'].shape) != want:
             raise CheckpointError('%s (%s): kernel shape %s, expected %s' % (layer, names['kernel'], p['kernel'].shape, want))
         params[layer] = p
+    if uni:
+        from .weights import embed_unidirectional_lstm
+        params = embed_unidirectional_lstm(params, arch.same_dim)
     return arch, params
 
 

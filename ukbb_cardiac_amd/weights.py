@@ -60,6 +60,26 @@ def synthetic_params(arch: ModelArch, seed: int = 1234) -> Params:
     return params
 
 
+def embed_unidirectional_lstm(params: Params, n_hidden: int) -> Params:
+    """The single-direction ConvLSTM head (common/network_ao.py:214-252 Conv_LSTM; train_network_ao.py --bidirectional=False) expressed
+    in the bidirectional layer set the engine is built for (BiConv_LSTM :255-319): ``params`` holds the U-Net layers plus 'lstm' (the one
+    cell) and 'lstm_conv' (the 1x1 logits conv on its output); returned are the same U-Net layers plus 'lstm_fw' = that cell, 'lstm_bw' = a
+    cell of all-zero kernel and bias, 'lstm_out' = [W; 0] over concat([h_fw, h_bw]).
+    Exact, not approximate: from the zero state a zero cell gives i = o = 1/2, j = tanh(0) = 0, so c' = sigmoid(f + 1) * 0 + 1/2 * 0 = 0 and
+    h' = tanh(0) * 1/2 = 0 at every step, and the output conv adds 16 products 0 * 0 to the single-direction sum.
+    (tests/test_unidirectional_lstm.py: the oracle's Conv_LSTM against its BiConv_LSTM on the embedded set -- backward maps exactly zero,
+    logits equal to the rounding of the summation order -- and the engine on the embedded set against the oracle's Conv_LSTM.)"""
+    out = {k: v for k, v in params.items() if k not in ('lstm', 'lstm_conv')}
+    cell, conv = params['lstm'], params['lstm_conv']
+    out['lstm_fw'] = {'kernel': np.asarray(cell['kernel'], np.float32), 'bias': np.asarray(cell['bias'], np.float32)}
+    out['lstm_bw'] = {'kernel': np.zeros_like(out['lstm_fw']['kernel']), 'bias': np.zeros_like(out['lstm_fw']['bias'])}
+    k = np.asarray(conv['kernel'], np.float32)
+    if k.shape[:3] != (1, 1, n_hidden):
+        raise ValueError('lstm_conv kernel %s, expected (1, 1, %d, n_class)' % (k.shape, n_hidden))
+    out['lstm_out'] = {'kernel': np.concatenate([k, np.zeros_like(k)], axis=2), 'bias': np.asarray(conv['bias'], np.float32)}
+    return out
+
+
 def threshold_params(arch: ModelArch, thresholds=None, slope: float = 40.0) -> Params:
     """A parameter set whose label map is a smooth function of the image: label = number of `thresholds` below the intensity after
     two 3x3 means.  Random weights (synthetic_params) give noise-like label maps -- millions of runs per subject, which makes the label
