@@ -111,3 +111,36 @@ def test_clearing_the_zero_cells_maps_equals_running_it(prec, monkeypatch):
         assert np.array_equal(got['skip'][0][k], got['run'][0][k]), k
     for i in (0, 1):
         assert np.array_equal(got['skip'][1][i], got['run'][1][i]) and np.array_equal(got['skip'][1][i], got['skip2'][i])
+
+
+@pytest.mark.gpu
+def test_drop_in_script_on_a_single_direction_checkpoint(tmp_path):
+    """deploy_network_ao.py on a checkpoint-V2 triple of the Conv_LSTM model (variables LSTM/<cell>/{kernel,biases}, LSTM/conv2d/{kernel,bias}, written by
+    tests/tf_bundle_writer.py): seg_ao.nii.gz = argmax of the reference's window tiling (deploy_network_ao.py:129-183) of this model's sequence outputs."""
+    from tests.tf_bundle_writer import write_checkpoint
+    from test_tf_checkpoint import _tf_tensors
+    from ukbb_cardiac_amd import deploy_network_ao, nifti
+    from ukbb_cardiac_amd.engine import Engine
+    from ukbb_cardiac_amd.image_utils import normalise_intensity
+    arch, uni = _uni_params(33)
+    emb = embed_unidirectional_lstm(uni, arch.same_dim)
+    t = _tf_tensors(arch, emb, with_slots=False)
+    ck = {n: v for n, v in t.items() if not n.startswith('LSTM/')}
+    ck['LSTM/conv_lstm_cell/kernel'] = t['LSTM/forward/conv_lstm_cell/kernel']
+    ck['LSTM/conv_lstm_cell/biases'] = t['LSTM/forward/conv_lstm_cell/biases']
+    ck['LSTM/conv2d/kernel'] = uni['lstm_conv']['kernel']
+    ck['LSTM/conv2d/bias'] = uni['lstm_conv']['bias']
+    mp = str(tmp_path / 'UNet-LSTM_uni')
+    write_checkpoint(mp, ck, tensor_crc=False)
+    rng = np.random.default_rng(5)
+    vol = np.round(100 * rng.gamma(2.0, 1.0, size=(80, 96, 1, 12))).astype(np.float32)
+    d = tmp_path / 'data' / 'subj1'
+    d.mkdir(parents=True)
+    nifti.save(vol, str(d / 'ao.nii.gz'), np.diag([1.6, 1.6, 6.0, 1.0]), pixdim=[1, 1.6, 1.6, 6, 0.01, 0, 0, 0])
+    deploy_network_ao.main(['--seq_name', 'ao', '--data_dir', str(tmp_path / 'data'), '--model_path', mp])
+    seg = nifti.load(str(d / 'seg_ao.nii.gz')).get_data()
+    with Engine(arch, emb) as eng:
+        want = O.aortic_lstm_prob_sequence(normalise_intensity(vol.copy(), 10.0), lambda x: eng.run_seq(x)['prob'])
+    assert seg.dtype == np.int32 and seg.shape == vol.shape
+    np.testing.assert_array_equal(seg, np.argmax(want, -1).astype(np.int32))
+    assert len(np.unique(seg)) > 1
