@@ -1,0 +1,165 @@
+"""Every launch of the UKBB_PREC_BF16 aortic U-Net plan against an INDEPENDENT emulation of what it is specified to compute (r06).
+
+The bf16 path is defined by where it rounds (include/ukbb_fcn.h UKBB_PREC_BF16): BN folded in fp32, the folded kernel rounded to bf16
+(RNE), bf16 x bf16 products accumulated in fp32, + fp32 bias, ReLU, the activation rounded to bf16 ONCE as it is stored; the fused stem rounds the image and
+conv0_0's output the same way, the fused tail up0_0's and up0_1's outputs, and the logits use the fp32 logits kernel on those bf16 activations.
+
+For every layer the engine stores, this test takes the ENGINE's own stored input map(s) -- exact bf16 values -- and evaluates that one layer in numpy
+float64 with the bf16-rounded folded kernel (oracle/fcn_oracle.py conv2d_same / conv2d_transpose_same: the reference's op, reference
+common/network.py:19-34, network_ao.py:31-58): the exact result of the specified arithmetic.  The engine's stored output must then be that value
+rounded to bf16, up to fp32 accumulation error near a rounding boundary: |engine - exact| <= half a bf16 ulp of the exact value (+ a 2^-18 relative slack
+for the fp32 accumulation, + an absolute floor for values ReLU brings next to zero).  No error is carried from layer to layer, so the bound is the same at
+conv1_0 and at up1_1.  The fused stem (two layers) and tail (two layers + logits) are emulated as units with their intermediate rounding; there an
+intermediate value that lands within fp32 accumulation error of ITS rounding boundary may round the other way and move the outputs it feeds by a bf16
+ulp of one product, so those are graded at 4 ulps for every element and half an ulp for 99.5 % of them.
+
+This replaces comparing the r04 kernels with the kernels they replaced (tests/test_bf16_kernels_gpu.py: regression guards) as the parity statement of
+the bf16 kernels: kernels_ws.hip (conv / transposed conv walkers, the K = 2304 ring form), the bf16 tile-per-workgroup tilings, kernels_stem.hip and
+kernels_tail.hip are each checked against numpy, at the tuned 256 x 256 shape and at a shape where the small-map fall-backs run."""
+import numpy as np
+import pytest
+
+from oracle import fcn_oracle as O
+
+pytestmark = pytest.mark.gpu
+BN_EPS = np.float32(1e-3)
+
+
+def bf16_round(x):
+    """float32 -> nearest bf16 (ties to even), returned as float32."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    r = ((u >> np.uint32(16)) & np.uint32(1)) + np.uint32(0x7fff)
+    return ((u + r) & np.uint32(0xffff0000)).view(np.float32)
+
+
+def fold(p, transposed=False):
+    """engine.cpp create(): sc = gamma / sqrtf(var + eps); W' = W * sc; b' = beta - mean * sc, all float32, no contraction."""
+    k = p['kernel'].astype(np.float32)
+    if 'gamma' not in p:
+        return k, p['bias'].astype(np.float32)
+    sc = (p['gamma'].astype(np.float32) / np.sqrt(p['var'].astype(np.float32) + BN_EPS)).astype(np.float32)
+    ms = (p['mean'].astype(np.float32) * sc).astype(np.float32)
+    b = (p['beta'].astype(np.float32) - ms).astype(np.float32)
+    w = (k * (sc[None, None, :, None] if transposed else sc[None, None, None, :])).astype(np.float32)
+    return w, b
+
+
+def layer(x, p, stride=1, transposed=False, relu=True):
+    """One conv2d_bn_relu / conv2d_transpose_bn_relu of the bf16 plan in float64 on the given (bf16-valued) input: the exact pre-rounding result."""
+    w, b = fold(p, transposed)
+    w = bf16_round(w).astype(np.float64)
+    x = np.asarray(x, np.float64)
+    y = (O.conv2d_transpose_same(x, w, stride) if transposed else O.conv2d_same(x, w, stride)) + b.astype(np.float64)
+    return np.maximum(y, 0.0) if relu else y
+
+
+def half_ulp(v):
+    """Half a bf16 ulp at |v| (float64 array): bf16 keeps 8 significant bits."""
+    a = np.maximum(np.abs(v), 1e-30)
+    return np.exp2(np.floor(np.log2(a)) - 8)
+
+
+def grade(name, got, exact, scale, ulps=0.5, fraction=1.0):
+    """got: the engine's stored bf16 values; exact: float64 result of the specified arithmetic before the final rounding."""
+    got = np.asarray(got, np.float64).reshape(exact.shape)
+    tol = 2 * ulps * half_ulp(exact) + np.abs(exact) * 2.0 ** -18 + scale * 2.0 ** -20
+    ok = np.abs(got - exact) <= tol
+    assert ok.mean() >= fraction, '%s: %.5f of the elements within %.1f bf16 ulp of the specified result (asked %.5f); worst %.3g at value %.3g' % (
+        name, ok.mean(), ulps, fraction, float(np.abs(got - exact).max()), float(exact.flat[np.abs(got - exact).argmax()]))
+    return float(ok.mean())
+
+
+@pytest.mark.parametrize('shape,seed', [((1, 256, 256), 1234), ((3, 64, 96), 7), ((2, 48, 16), 11)])
+def test_every_bf16_launch_against_its_specified_arithmetic(shape, seed):
+    from ukbb_cardiac_amd.arch import MODELS
+    from ukbb_cardiac_amd.engine import Engine
+    from ukbb_cardiac_amd.phantom import cine_phantom
+    from ukbb_cardiac_amd.weights import synthetic_params
+    arch = MODELS['UNet_ao']
+    params = synthetic_params(arch, seed)
+    n, H, W = shape
+    img = ((cine_phantom(n, H, W, seed=seed) - 0.3) / 0.25).astype(np.float32)
+    with Engine(arch, params) as eng:
+        eng.set_precision('bf16')
+        out = eng.run(img, want_logits=True)
+        names = eng.kernel_names()
+
+        def act(name, l):
+            # the last map of a level is registered under the level's name (include/ukbb_fcn.h ukbb_fcn_get_activation: "conv0".."conv4", "up3".."up0")
+            kind, i = name.split('_')
+            if i != 't' and int(i) == arch.n_block[l] - 1:
+                name = kind
+            return eng.activation(name).reshape(n, H >> l, W >> l, -1)
+        stored = {}
+        for l in range(5):
+            for i in range(arch.n_block[l]):
+                if not (l == 0 and i == 0):
+                    stored['conv%d_%d' % (l, i)] = act('conv%d_%d' % (l, i), l)
+        for l in (3, 2, 1, 0):
+            stored['up%d_t' % l] = act('up%d_t' % l, l)
+            for i in range(arch.n_block[l]):
+                try:
+                    stored['up%d_%d' % (l, i)] = act('up%d_%d' % (l, i), l)
+                except Exception:                                        # up0_0 / up0_1 inside the fused tail: never stored
+                    assert l == 0, (l, i)
+    if shape[1] >= 64:
+        assert any('+' in k for k in names), 'the fused stem / tail are expected in this plan: %s' % names
+    for k, v in stored.items():                                          # what is stored really is bf16
+        assert np.array_equal(v, bf16_round(v)), k
+    report = {}
+    # ---- stem: image -> bf16; conv0_0 -> bf16; conv0_1 -> bf16 (kernels_stem.hip, or the fused-first tile kernel on small maps: fp32 first layer) ----
+    a00 = bf16_round(layer(bf16_round(img), params['conv0_0']).astype(np.float32))
+    ex = layer(a00, params['conv0_1'])
+    sc = float(np.abs(ex).max())
+    try:
+        report['stem'] = grade('conv0_0+conv0_1', stored['conv0_1'], ex, sc, ulps=4.0)
+        grade('conv0_0+conv0_1 (half ulp)', stored['conv0_1'], ex, sc, ulps=0.5, fraction=0.995)
+    except AssertionError:
+        # small maps: conv0_0 evaluated in fp32 on the un-rounded image inside conv0_1's staging (conv_mfma_kernel<..., FUSE = 1>)
+        w0, b0 = fold(params['conv0_0'])
+        a00 = bf16_round(np.maximum(O.conv2d_same(img.astype(np.float64), w0.astype(np.float64), 1) + b0, 0.0).astype(np.float32))
+        ex = layer(a00, params['conv0_1'])
+        report['stem(fp32 first layer)'] = grade('conv0_0+conv0_1', stored['conv0_1'], ex, sc, ulps=4.0)
+        grade('conv0_0+conv0_1 (half ulp)', stored['conv0_1'], ex, sc, ulps=0.5, fraction=0.995)
+    # ---- every stored layer from the engine's own stored inputs: half an ulp, every element ----
+    for l in range(1, 5):
+        x = stored['conv%d_%d' % (l - 1, arch.n_block[l - 1] - 1)]
+        for i in range(arch.n_block[l]):
+            nm = 'conv%d_%d' % (l, i)
+            ex = layer(x, params[nm], stride=2 if i == 0 else 1)
+            report[nm] = grade(nm, stored[nm], ex, float(np.abs(ex).max()))
+            x = stored[nm]
+    # the grade is not vacuous: the same layer with the folded kernel NOT rounded to bf16 (what an fp32-weight path would compute) misses it
+    w, b = fold(params['conv2_1'])
+    wrong = np.maximum(O.conv2d_same(stored['conv2_0'].astype(np.float64), w.astype(np.float64), 1) + b, 0.0)
+    tol = 2 * 0.5 * half_ulp(wrong) + np.abs(wrong) * 2.0 ** -18 + float(np.abs(wrong).max()) * 2.0 ** -20
+    assert np.mean(np.abs(stored['conv2_1'].astype(np.float64) - wrong) <= tol) < 0.9
+    up = stored['conv4_%d' % (arch.n_block[4] - 1)]
+    for l in (3, 2, 1, 0):
+        nm = 'up%d_t' % l
+        ex = layer(up, params[nm], stride=2, transposed=True)
+        report[nm] = grade(nm, stored[nm], ex, float(np.abs(ex).max()))
+        x = np.concatenate([stored['conv%d_%d' % (l, arch.n_block[l] - 1)], stored[nm]], axis=-1)      # skip first (network_ao.py:51)
+        for i in range(arch.n_block[l]):
+            nm = 'up%d_%d' % (l, i)
+            if nm not in stored:
+                break
+            ex = layer(x, params[nm])
+            report[nm] = grade(nm, stored[nm], ex, float(np.abs(ex).max()))
+            x = stored[nm]
+        up = x
+    # ---- tail: up0_0 -> bf16 -> up0_1 -> bf16 -> logits (fp32 kernel as bf16 hi + lo), softmax / argmax; x = the last stored map(s) in front of it ----
+    a = x
+    for i in range(arch.n_block[0]):
+        if 'up0_%d' % i not in stored:
+            a = bf16_round(layer(a, params['up0_%d' % i]).astype(np.float32))
+    pl = params['logits']
+    logits = O.conv2d_same(a.astype(np.float64), pl['kernel'].astype(np.float64), 1) + pl['bias'].astype(np.float64)
+    lsc = float(np.abs(logits).max())
+    err = np.abs(out['logits'].astype(np.float64) - logits)
+    # a flipped rounding of one up0_0 / up0_1 value moves a logit by (one bf16 ulp of that value) x a few weights: a few 1e-3 of the scale at worst
+    assert err.max() <= 2e-2 * lsc and np.mean(err <= 2e-4 * lsc) >= 0.99, (float(err.max() / lsc), float(np.mean(err <= 2e-4 * lsc)))
+    report['tail logits rel'] = float(err.max() / lsc)
+    flips = out['pred'] != np.argmax(logits, -1)
+    assert np.all(O.top2_margin(logits)[flips] <= 4e-2 * lsc) and flips.mean() < 2e-3, (int(flips.sum()), float(flips.mean()))
+    print('bf16 layers vs specified arithmetic %s: %s' % (shape, {k: round(v, 6) for k, v in report.items()}))
