@@ -1,6 +1,8 @@
 """r04 kernels of the aortic U-Net in UKBB_PREC_BF16, each against the kernel(s) it replaces on the same inputs (through the C ABI):
 the weight-stationary conv / transposed-conv tilings (kernels_ws.hip), the fused tail (kernels_tail.hip) and the fused stem
-(kernels_stem.hip).  The comparisons are those of tools/check_ws.py, check_tail.py and check_stem.py, run as the tools themselves."""
+(kernels_stem.hip).  The comparisons are those of tools/check_ws.py, check_tail.py and check_stem.py, run as the tools themselves.
+(Regression guards: each compares a kernel with the kernel(s) it replaced.  The parity statement of these kernels against an independent computation is
+tests/test_bf16_layers_gpu.py -- every stored map of the plan against numpy float64 on the bf16-rounded operands, half a bf16 ulp.)"""
 import os
 import subprocess
 import sys
