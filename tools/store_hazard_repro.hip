@@ -11,6 +11,7 @@
 // Variant 1: SOFF = an SGPR, PAD = s_nop 0    -- one wait state
 // Variant 2: SOFF = an SGPR, PAD = s_waitcnt expcnt(0); s_nop 7; s_nop 7  -- what store_b128_sofs ships
 // Variant 3: SOFF = 0 (constant), no PAD      -- the form hipcc DOES pad (2 wait states on gfx94x/95x); unpadded here to see the hardware
+// Variants 4, 5: buffer_store_dwordx2 / x3 with an SGPR soffset and no PAD -- where the hazard starts (the memset leaves the unwritten dwords of a piece 0)
 // Each variant runs alone and beside a streaming copy kernel on a second stream (memory back-pressure); the host counts 16-byte pieces that
 // hold a 0xDEAD.... value.  Nothing else is shared between the two kernels.
 #include <hip/hip_runtime.h>
@@ -38,7 +39,13 @@ __global__ __launch_bounds__(256) void victim(unsigned *out, int pieces_per_wave
             const unsigned tag = ((unsigned)wave << 12 | (unsigned)p) << 2;          // element j of the piece holds (tag | j), never 0xDEAD....
             const unsigned soff = __builtin_amdgcn_readfirstlane(p * 1024);
             const unsigned junk = 0xDEAD0000u | (unsigned)(p & 0xfff);
-            if constexpr (VARIANT == 3) {
+            if constexpr (VARIANT == 4 || VARIANT == 5) {     // narrower stores, SGPR soffset, no wait state: x2 (8 bytes: no hazard documented) and x3 (12 bytes)
+                asm volatile("v_or_b32 v100, %[t], 0\n\tv_or_b32 v101, %[t], 1\n\tv_or_b32 v102, %[t], 2\n\tv_or_b32 v103, %[t], 3\n\ts_nop 4\n\t"
+                             ".if %[variant] == 4\n\tbuffer_store_dwordx2 v[100:101], %[vo], %[rs], %[so] offen\n\t.else\n\tbuffer_store_dwordx3 v[100:102], %[vo], %[rs], %[so] offen\n\t.endif\n\t"
+                             "v_mov_b32 v100, %[j]\n\tv_mov_b32 v101, %[j]\n\tv_mov_b32 v102, %[j]\n\tv_mov_b32 v103, %[j]\n\t"
+                             :: [t] "v"(tag), [vo] "v"(voff), [rs] "s"(rsrc), [so] "s"(soff), [j] "v"(junk), [variant] "n"(VARIANT)
+                             : "v100", "v101", "v102", "v103", "memory");
+            } else if constexpr (VARIANT == 3) {
                 const unsigned vo = voff + soff;
                 asm volatile("v_or_b32 v100, %[t], 0\n\tv_or_b32 v101, %[t], 1\n\tv_or_b32 v102, %[t], 2\n\tv_or_b32 v103, %[t], 3\n\ts_nop 4\n\t"
                              "buffer_store_dwordx4 v[100:103], %[vo], %[rs], 0 offen\n\t"
@@ -95,5 +102,7 @@ int main() {
     run<1>("SGPR soffset, s_nop 0", d_out, h, waves, ppw, s0, s1, src, dst, ncopy);
     run<2>("SGPR soffset, expcnt(0) + 16 wait states (shipped)", d_out, h, waves, ppw, s0, s1, src, dst, ncopy);
     run<3>("constant soffset, no wait state (hipcc would pad this)", d_out, h, waves, ppw, s0, s1, src, dst, ncopy);
+    run<4>("dwordx2 (8 bytes), SGPR soffset, no wait state", d_out, h, waves, ppw, s0, s1, src, dst, ncopy);
+    run<5>("dwordx3 (12 bytes), SGPR soffset, no wait state", d_out, h, waves, ppw, s0, s1, src, dst, ncopy);
     return 0;
 }
