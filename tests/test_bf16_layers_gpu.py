@@ -163,3 +163,56 @@ def test_every_bf16_launch_against_its_specified_arithmetic(shape, seed):
     flips = out['pred'] != np.argmax(logits, -1)
     assert np.all(O.top2_margin(logits)[flips] <= 4e-2 * lsc) and flips.mean() < 2e-3, (int(flips.sum()), float(flips.mean()))
     print('bf16 layers vs specified arithmetic %s: %s' % (shape, {k: round(v, 6) for k, v in report.items()}))
+
+
+def test_bf16_conv_lstm_against_its_rounding_model():
+    """The bf16 ConvLSTM (kernels_ws.hip LS forms; reference common/network_ao.py:255-319) against numpy float64 with the roundings the header specifies
+    (include/ukbb_fcn.h UKBB_PREC_BF16 on a UNet-LSTM handle): gate kernels rounded to bf16; per direction the first step from the un-rounded x half of the
+    gates, later steps from gx ROUNDED TO bf16 (it is stored) + W_h * h; cell state fp32; every hidden map rounded to bf16 as stored; the output conv in
+    fp32 weights on those maps.  Input: the engine's own stored U-Net features (bf16).  A flipped rounding of one gx / h value (its exact value within fp32
+    error of a rounding boundary) moves what it feeds by a bf16 ulp, and nine steps carry it on, so the bound is on the logits, not per element of every
+    map: measured max 2.2e-3 of the logits' scale, 99.9 % within 1.2e-3, median 6e-5 -- three to four times closer than to the un-rounded float64 graph on
+    the same features (7.8e-3 / 3.6e-3), which is what says the roundings sit where they are specified."""
+    from ukbb_cardiac_amd.arch import MODELS
+    from ukbb_cardiac_amd.engine import Engine
+    from ukbb_cardiac_amd.phantom import cine_phantom
+    from ukbb_cardiac_amd.weights import synthetic_params
+    arch = MODELS['UNet-LSTM_ao']
+    params = synthetic_params(arch, 1234)
+    T, nh = arch.fc, arch.same_dim
+    N, H, W = 2, 64, 80
+    img = ((cine_phantom(N * T, H, W, seed=3) - 0.3) / 0.25).astype(np.float32).reshape(N, T, H, W, 1)
+    with Engine(arch, params) as eng:
+        eng.set_precision('bf16')
+        out = eng.run_seq(img, want_logits=True)
+        feats = eng.activation('up0').reshape(N, T, H, W, -1)
+    assert np.array_equal(feats, bf16_round(feats))
+    feats = feats.astype(np.float64)
+
+    def sig(x):
+        return 1.0 / (1.0 + np.exp(-x))
+
+    def direction(p, order):
+        k, b = bf16_round(p['kernel']).astype(np.float64), p['bias'].astype(np.float64)
+        kx, kh = k[:, :, :arch.n_filter[0]], k[:, :, arch.n_filter[0]:]
+        h = c = None
+        hs = {}
+        for step, t in enumerate(order):
+            gx = O.conv2d_same(feats[:, t], kx, 1) + b
+            z = gx if step == 0 else bf16_round(gx.astype(np.float32)).astype(np.float64) + O.conv2d_same(h, kh, 1)
+            i, j, f, o = np.split(z, 4, axis=-1)                          # gate order i, j, f, o; forget bias 1 (conv_lstm_cell in the oracle)
+            c = (sig(f + 1.0) * (0.0 if step == 0 else c) + sig(i) * np.tanh(j)).astype(np.float32).astype(np.float64)
+            h = bf16_round((np.tanh(c) * sig(o)).astype(np.float32)).astype(np.float64)
+            hs[t] = h
+        return hs
+    fw, bw = direction(params['lstm_fw'], list(range(T))), direction(params['lstm_bw'], list(range(T - 1, -1, -1)))
+    po = params['lstm_out']
+    model = np.stack([O.conv2d_same(np.concatenate([fw[t], bw[t]], -1), po['kernel'].astype(np.float64), 1) + po['bias'] for t in range(T)], 1)
+    sc = float(np.abs(model).max())
+    err = np.abs(out['logits'] - model) / sc
+    unrounded = np.abs(out['logits'] - O.biconv_lstm(feats, params, nh)) / sc
+    print('bf16 ConvLSTM vs its rounding model: max %.2e, 99.9 %% %.2e, median %.2e of the scale; vs the un-rounded graph: max %.2e, 99.9 %% %.2e' % (
+        err.max(), np.percentile(err, 99.9), np.median(err), unrounded.max(), np.percentile(unrounded, 99.9)))
+    assert err.max() <= 6e-3 and np.percentile(err, 99.9) <= 3e-3 and np.median(err) <= 2e-4
+    assert np.percentile(err, 99.9) < 0.6 * np.percentile(unrounded, 99.9)
+    assert (out['pred'] == model.argmax(-1)).mean() >= 0.999
